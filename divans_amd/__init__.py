@@ -1,0 +1,246 @@
+"""divans_amd -- MI355X-native literal coder of dropbox/divans behind a C ABI.
+
+Host-side mirror (Python) of the reference interface for this path.  The product path is the HIP
+extension ``libdivans_hip.so`` (hand-written gfx950 kernels + C ABI, see include/divans_gpu.h);
+this module only moves pointers: torch supplies device memory and streams, ctypes calls the ABI.
+There is no CPU fallback -- importing works anywhere, but every codec operation raises
+``DivansGpuError`` unless the extension is built and a HIP device is present.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_LITERAL_CONTEXT_MAP_SIZE = 256 * 64
+NUM_MIXING_VALUES = 8192
+
+# LiteralPredictionModeNibble values (brotli numbering)
+LITERAL_PREDICTION_MODE_LSB6 = 0
+LITERAL_PREDICTION_MODE_MSB6 = 1
+LITERAL_PREDICTION_MODE_UTF8 = 2
+LITERAL_PREDICTION_MODE_SIGN = 3
+
+
+class DivansGpuError(RuntimeError):
+    pass
+
+
+class Speed(ctypes.Structure):
+    """Speed(inc, lim), src/probability/interface.rs:298-375"""
+    _fields_ = [("inc", ctypes.c_int16), ("lim", ctypes.c_int16)]
+
+
+class LitConfig(ctypes.Structure):
+    """divans_lit_config (include/divans_gpu.h): LiteralBookKeeping after PredictionMode + BlockSwitchLiteral."""
+    _fields_ = [
+        ("literal_context_map", ctypes.c_uint8 * MAX_LITERAL_CONTEXT_MAP_SIZE),
+        ("mixing_mask", ctypes.c_uint8 * NUM_MIXING_VALUES),
+        ("prediction_mode", ctypes.c_uint8),
+        ("btype", ctypes.c_uint8),
+        ("context_mixing", ctypes.c_uint8),
+        ("reserved", ctypes.c_uint8),
+        ("literal_adaptation", Speed * 4),
+    ]
+
+
+class GpuInfo(ctypes.Structure):
+    _fields_ = [
+        ("rows_per_stream", ctypes.c_uint32), ("resident_groups", ctypes.c_uint32),
+        ("blocks", ctypes.c_uint32), ("threads", ctypes.c_uint32),
+        ("table_bytes", ctypes.c_uint64), ("scratch_bytes", ctypes.c_uint64),
+        ("last_model_ms", ctypes.c_float), ("last_rans_ms", ctypes.c_float), ("last_decode_ms", ctypes.c_float),
+    ]
+
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(_HERE, "libdivans_hip.so")
+
+
+def load_library():
+    """Loads libdivans_hip.so (in-tree).  Raises DivansGpuError when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise DivansGpuError(
+            f"{path} is missing: run `python -m divans_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64; it must be the first HIP runtime mapped
+    # into the process, and the extension (same SONAME) then binds to that copy.  Loading ours first
+    # maps /opt/rocm's runtime and torch can no longer see the GPU.
+    import torch  # noqa: F401  (plumbing: device memory + streams)
+    L = ctypes.CDLL(path)
+    vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+    L.divans_gpu_last_error.restype = ctypes.c_char_p
+    L.divans_lit_config_simple.argtypes = [ctypes.POINTER(LitConfig)]
+    L.divans_lit_config_context_mixing.argtypes = [ctypes.POINTER(LitConfig)]
+    L.divans_gpu_codec_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(LitConfig), ctypes.c_int, vp, u32]
+    L.divans_gpu_codec_destroy.argtypes = [vp]
+    L.divans_gpu_codec_destroy.restype = None
+    L.divans_gpu_lit_encode_bound.restype = ctypes.c_size_t
+    L.divans_gpu_lit_encode_bound.argtypes = [ctypes.c_size_t]
+    L.divans_gpu_lit_encode_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp, vp]
+    L.divans_gpu_lit_decode_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u32]
+    L.divans_gpu_pack_streams.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
+    L.divans_gpu_lit_encode_host.argtypes = [vp, vp, u32, u32, vp, ctypes.c_size_t, vp, vp, ctypes.POINTER(ctypes.c_size_t)]
+    L.divans_gpu_lit_decode_host.argtypes = [vp, vp, vp, vp, u32, vp, u32]
+    L.divans_gpu_codec_info.argtypes = [vp, ctypes.POINTER(GpuInfo)]
+    L.divans_gpu_codec_set_geometry.argtypes = [vp, u32, u32]
+    L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
+    _LIB = L
+    return L
+
+
+def exported_symbols():
+    """Entry points include/divans_gpu.h declares (used by the CPU-side ABI test)."""
+    return [
+        "divans_lit_config_simple", "divans_lit_config_context_mixing", "divans_gpu_codec_create",
+        "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
+        "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
+        "divans_gpu_lit_encode_host", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
+        "divans_gpu_codec_set_geometry", "divans_gpu_selftest_division",
+    ]
+
+
+def config_simple():
+    """BASELINE.json config 2: reference TestSimple (src/bin/benchmark.rs:195-206)."""
+    c = LitConfig()
+    load_library().divans_lit_config_simple(ctypes.byref(c))
+    return c
+
+
+def config_context_mixing():
+    """BASELINE.json config 3: reference TestContextMixing via bench_no_ir (src/bin/benchmark.rs:156-167,305-343)."""
+    c = LitConfig()
+    load_library().divans_lit_config_context_mixing(ctypes.byref(c))
+    return c
+
+
+def encode_bound(n):
+    return int(load_library().divans_gpu_lit_encode_bound(int(n)))
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().divans_gpu_last_error()
+        raise DivansGpuError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+class LiteralCodec:
+    """Batch literal-stream codec (one instance per GPU / configuration).
+
+    Mirrors what the reference does per stream with ``LiteralState::encode_or_decode_content_bytes``
+    (src/codec/literal.rs:404-494) and ``ANSEncoder`` / ``ANSDecoder`` (src/ans.rs), but over
+    thousands of independent streams per launch.  Tensors are torch uint8 CUDA(=HIP) tensors.
+    """
+
+    def __init__(self, config, max_stream_len, device=0, stream=None):
+        import torch  # device memory + streams only
+        if not torch.cuda.is_available():
+            raise DivansGpuError("no HIP device visible to torch: the literal coder has no CPU fallback")
+        self._torch = torch
+        self._lib = load_library()
+        self.device = int(device)
+        self.max_stream_len = int(max_stream_len)
+        self.config = config
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        self.stream = stream
+        h = ctypes.c_void_p()
+        _check(self._lib.divans_gpu_codec_create(ctypes.byref(h), ctypes.byref(config), self.device,
+                                                 ctypes.c_void_p(stream.cuda_stream), self.max_stream_len),
+               "divans_gpu_codec_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.divans_gpu_codec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_geometry(self, blocks):
+        _check(self._lib.divans_gpu_codec_set_geometry(self._h, int(blocks), 0), "set_geometry")
+
+    def info(self):
+        i = GpuInfo()
+        _check(self._lib.divans_gpu_codec_info(self._h, ctypes.byref(i)), "divans_gpu_codec_info")
+        return i
+
+    def selftest_division(self):
+        m = ctypes.c_uint64(0)
+        _check(self._lib.divans_gpu_selftest_division(self._h, ctypes.byref(m)), "selftest_division")
+        return int(m.value)
+
+    # ---- device-resident batch API -----------------------------------------------------------
+    def alloc_encode_outputs(self, n_streams, stream_len=None):
+        t = self._torch
+        slot = encode_bound(stream_len or self.max_stream_len)
+        dev = t.device("cuda", self.device)
+        return dict(slot=slot,
+                    out=t.empty(n_streams * slot + 64, dtype=t.uint8, device=dev),
+                    offsets=t.empty(n_streams, dtype=t.int64, device=dev),
+                    sizes=t.empty(n_streams, dtype=t.int32, device=dev))
+
+    def encode_batch(self, d_in, n_streams, stream_len, outputs):
+        """d_in: uint8 tensor of n_streams*stream_len bytes (stream i = rows i).  Fills outputs in place."""
+        _check(self._lib.divans_gpu_lit_encode_batch(
+            self._h, d_in.data_ptr(), None, None, int(stream_len), int(n_streams),
+            outputs["out"].data_ptr(), int(outputs["slot"]), outputs["offsets"].data_ptr(),
+            outputs["sizes"].data_ptr()), "divans_gpu_lit_encode_batch")
+
+    def decode_batch(self, d_coded, d_offsets, d_sizes, n_streams, stream_len, d_out):
+        _check(self._lib.divans_gpu_lit_decode_batch(
+            self._h, d_coded.data_ptr(), d_offsets.data_ptr(), d_sizes.data_ptr(), int(n_streams),
+            d_out.data_ptr(), None, None, int(stream_len)), "divans_gpu_lit_decode_batch")
+
+    def pack(self, outputs, n_streams):
+        t = self._torch
+        dev = outputs["out"].device
+        packed = t.empty_like(outputs["out"])
+        poff = t.empty(n_streams, dtype=t.int64, device=dev)
+        total = t.zeros(1, dtype=t.int64, device=dev)
+        _check(self._lib.divans_gpu_pack_streams(self._h, outputs["out"].data_ptr(), outputs["offsets"].data_ptr(),
+                                                 outputs["sizes"].data_ptr(), int(n_streams), packed.data_ptr(),
+                                                 poff.data_ptr(), total.data_ptr()), "divans_gpu_pack_streams")
+        return packed, poff, total
+
+    # ---- host convenience (numpy in / out) ---------------------------------------------------
+    def encode_host(self, data, stream_len):
+        """data: numpy uint8 of n*stream_len bytes -> (packed bytes, offsets, sizes) numpy arrays."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        n = data.size // stream_len
+        assert n * stream_len == data.size
+        cap = encode_bound(stream_len) * n + 64
+        out = np.empty(cap, dtype=np.uint8)
+        offs = np.empty(n, dtype=np.uint64)
+        sizes = np.empty(n, dtype=np.uint32)
+        total = ctypes.c_size_t(0)
+        _check(self._lib.divans_gpu_lit_encode_host(self._h, data.ctypes.data, int(stream_len), n, out.ctypes.data, cap,
+                                                    offs.ctypes.data, sizes.ctypes.data, ctypes.byref(total)),
+               "divans_gpu_lit_encode_host")
+        return out[:total.value].copy(), offs, sizes
+
+    def decode_host(self, packed, offsets, sizes, stream_len):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        n = offsets.size
+        out = np.empty(max(n * stream_len, 1), dtype=np.uint8)
+        _check(self._lib.divans_gpu_lit_decode_host(self._h, packed.ctypes.data, offsets.ctypes.data, sizes.ctypes.data,
+                                                    n, out.ctypes.data, int(stream_len)), "divans_gpu_lit_decode_host")
+        return out[:n * stream_len].reshape(n, stream_len) if stream_len else out[:0].reshape(n, 0)
+
+
+def build_extension(force=False):
+    return _build.build(force=force)

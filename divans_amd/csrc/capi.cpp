@@ -1,0 +1,416 @@
+// capi.cpp -- host side of the batch C ABI declared in include/divans_gpu.h.
+// Owns device memory (CDF tables, start/freq spill, configuration blob), derives the compact table
+// geometry from the stream configuration and launches the kernels in lit_kernels.hip.
+// There is NO CPU fallback: every entry point fails loudly when HIP is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/divans_gpu.h"
+#include "lit_kernels.h"
+
+using namespace divans_hip;
+
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(DIVANS_GPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+extern "C" const char* divans_gpu_last_error(void) { return g_last_error.c_str(); }
+
+// ---- configuration helpers -------------------------------------------------------------------
+static const divans_speed kSpeedMud = {0x10, 0x2000};  // probability/interface.rs:323 / codec/interface.rs:188-190
+
+extern "C" void divans_lit_config_simple(divans_lit_config* cfg) {
+    // TestSimple, bin/benchmark.rs:195-206: context map off => map stays zero, mixing values all 4
+    // (codec/context_map.rs:269-276, 386-387); lsb6; default MUD speeds
+    std::memset(cfg, 0, sizeof(*cfg));
+    std::memset(cfg->mixing_mask, 4, sizeof(cfg->mixing_mask));
+    for (auto& s : cfg->literal_adaptation) s = kSpeedMud;
+}
+
+extern "C" void divans_lit_config_context_mixing(divans_lit_config* cfg) {
+    // TestContextMixing through bench_no_ir, bin/benchmark.rs:156-167,305-343
+    std::memset(cfg, 0, sizeof(*cfg));
+    for (int i = 0; i < 256; ++i) cfg->literal_context_map[i] = (uint8_t)(i & 63);
+    std::memset(cfg->mixing_mask, 4, sizeof(cfg->mixing_mask));
+    cfg->prediction_mode = 2;
+    cfg->btype = 1;
+    cfg->context_mixing = 2;
+    for (auto& s : cfg->literal_adaptation) s = kSpeedMud;
+}
+
+// RFC 7932 section 7.1 context lookups (what constants.rs tabulates), by structure
+static uint8_t utf8_lut0(int b) {
+    static const uint8_t punct[32] = {8, 12, 16, 12, 12, 20, 12, 16, 24, 28, 12, 12, 32, 12, 36, 12,
+                                      44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 32, 32, 24, 40, 28, 12};
+    if (b < 32) return (b == 9 || b == 10 || b == 13) ? 4 : 0;
+    if (b < 64) return punct[b - 32];
+    if (b < 128) {
+        const bool lower = b >= 96;
+        const int c = b & 31;
+        if (c == 0) return 12;
+        if (c <= 26) return (uint8_t)((lower ? 56 : 48) + ((c == 1 || c == 5 || c == 9 || c == 15 || c == 21) ? 0 : 4));
+        if (c == 27) return 24;
+        if (c == 29) return 28;
+        if (c == 31) return lower ? 0 : 12;
+        return 12;
+    }
+    return (uint8_t)((b < 192 ? 0 : 2) + (b & 1));
+}
+static uint8_t utf8_lut1(int b) {
+    if (b <= 32 || b == 127) return 0;
+    if (b < 128) {
+        if ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z')) return 2;
+        if (b >= 'a' && b <= 'z') return 3;
+        return 1;
+    }
+    return b >= 224 ? 2 : 0;
+}
+static uint8_t signed3(int b) {
+    return b == 0 ? 0 : b < 16 ? 1 : b < 64 ? 2 : b < 128 ? 3 : b < 192 ? 4 : b < 240 ? 5 : b < 255 ? 6 : 7;
+}
+// codec/interface.rs:199-238 get_lut0 / get_lut1
+static void make_luts(uint8_t mode, uint8_t* lut0, uint8_t* lut1) {
+    for (int i = 0; i < 256; ++i) {
+        switch (mode) {
+        case 3: lut0[i] = (uint8_t)(signed3(i) << 3); lut1[i] = signed3(i); break;
+        case 2: lut0[i] = utf8_lut0(i); lut1[i] = utf8_lut1(i); break;
+        case 1: lut0[i] = (uint8_t)(i >> 2); lut1[i] = 0; break;
+        default: lut0[i] = (uint8_t)(i & 0x3f); lut1[i] = 0; break;
+        }
+    }
+}
+
+struct divans_gpu_codec {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    divans_lit_config cfg;
+    LitGeometry geom;
+    bool mix = false;
+    uint32_t max_stream_len = 0;
+    uint32_t num_cus = 256;
+    uint32_t blocks = 0;          // persistent grid of the model/decode kernels
+    uint8_t* d_blob = nullptr;
+    int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
+    uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
+    uint32_t* d_status = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
+    bool timing_pending_enc = false, timing_pending_dec = false;
+};
+
+static int derive_geometry(const divans_lit_config& cfg, LitGeometry& g, std::vector<uint8_t>& blob) {
+    if (cfg.prediction_mode > 3) return fail(DIVANS_GPU_EINVAL, "prediction_mode must be 0..3 (codec/interface.rs:252-256)");
+    if (cfg.context_mixing >= 15) return fail(DIVANS_GPU_EINVAL, "context_mixing must be < 15 (codec/interface.rs:359)");
+    for (int i = 0; i < 4; ++i) {
+        const divans_speed s = cfg.literal_adaptation[i];
+        // probability/interface.rs:341-365 debug_asserts inc,lim <= 0x4000; the kernels additionally rely on
+        // lim+inc staying inside i16 so a CDF total never wraps negative
+        if (s.inc < 0 || s.lim <= 0 || s.inc > 0x4000 || s.lim > 0x4000 || (int)s.inc + (int)s.lim > 0x7fff)
+            return fail(DIVANS_GPU_EINVAL, "literal_adaptation speed outside the supported range");
+    }
+    blob.assign(LIT_BLOB_BYTES, 0);
+    make_luts(cfg.prediction_mode, &blob[LIT_BLOB_LUT0], &blob[LIT_BLOB_LUT1]);
+    const uint8_t* cmap64 = cfg.literal_context_map + 64u * cfg.btype;  // literal.rs:114 cmap_index = sel + (btype << 6)
+    std::memcpy(&blob[LIT_BLOB_CMAP], cmap64, 64);
+    std::memcpy(&blob[LIT_BLOB_MIX], cfg.mixing_mask, DIVANS_GPU_NUM_MIXING_VALUES);
+    // which selected-context values can occur: lut0 | lut1 (both < 64 by construction)
+    bool sel_seen[64] = {false};
+    for (int a = 0; a < 256; ++a) for (int b = 0; b < 256; ++b) sel_seen[(blob[LIT_BLOB_LUT0 + a] | blob[LIT_BLOB_LUT1 + b]) & 63] = true;
+    bool ctx_seen[256] = {false};
+    uint32_t maxctx = 0; int first = -1; bool constant = true;
+    for (int s = 0; s < 64; ++s) {
+        if (!sel_seen[s]) continue;
+        const uint8_t c = cmap64[s];
+        ctx_seen[c] = true;
+        maxctx = std::max<uint32_t>(maxctx, c);
+        if (first < 0) first = c; else if (c != first) constant = false;
+    }
+    std::memset(&g, 0, sizeof(g));
+    g.nctx = maxctx + 1;
+    g.ctx_const = constant ? first : -1;
+    // reachable mixing values: index = ctx | nibble << 8 | (low ? 4096 : 0)  (literal.rs:176-183)
+    bool t_used[3] = {false, false, false};
+    bool any1 = false; int mmfirst = -1; bool mmconst = true;
+    for (int idx = 0; idx < DIVANS_GPU_NUM_MIXING_VALUES; ++idx) {
+        if (!ctx_seen[idx & 0xff]) continue;
+        const uint8_t m = cfg.mixing_mask[idx];
+        if (mmfirst < 0) mmfirst = m; else if (m != mmfirst) mmconst = false;
+        const int t = (m == 0 || m == 3) ? 0 : (m == 1 ? 2 : 1);
+        t_used[t] = true;
+        any1 |= (m == 1);
+    }
+    g.mm_uniform = mmconst ? mmfirst : -1;
+    uint32_t nplanes = 0;
+    uint32_t plane[3] = {0, 0, 0};
+    for (int t = 0; t < 3; ++t) if (t_used[t]) plane[t] = nplanes++;
+    g.plane0 = plane[0]; g.plane1 = plane[1]; g.plane2 = plane[2];
+    g.low_width = any1 ? 256u : 16u;
+    const uint32_t high_rows = nplanes * 256u * g.nctx;
+    const uint32_t low_rows = nplanes * 256u * g.low_width;
+    g.low_base = high_rows;
+    g.cm_base = high_rows + low_rows;
+    const bool mix = cfg.context_mixing > 1;  // Weights::should_mix, weights.rs:44-46
+    g.total_rows = g.cm_base + (mix ? 17u * g.nctx : 0u);
+    g.inc0 = cfg.literal_adaptation[0].inc; g.lim0 = cfg.literal_adaptation[0].lim;
+    g.inc1 = cfg.literal_adaptation[1].inc; g.lim1 = cfg.literal_adaptation[1].lim;
+    g.inc2 = cfg.literal_adaptation[2].inc; g.lim2 = cfg.literal_adaptation[2].lim;
+    g.inc3 = cfg.literal_adaptation[3].inc; g.lim3 = cfg.literal_adaptation[3].lim;
+    return 0;
+}
+
+static uint32_t resident_groups(const divans_gpu_codec* c) { return c->blocks * (LIT_THREADS / 16); }
+
+static int ensure_tables(divans_gpu_codec* c) {
+    const size_t need = (size_t)resident_groups(c) * c->geom.total_rows * 32u;
+    if (need <= c->tables_bytes) return 0;
+    if (c->d_tables) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }
+    if (hipMalloc(&c->d_tables, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(CDF tables) failed");
+    c->tables_bytes = need;
+    return 0;
+}
+
+static int ensure_sf(divans_gpu_codec* c, uint32_t n_streams) {
+    const size_t need = (size_t)n_streams * 2u * c->max_stream_len * sizeof(uint32_t);
+    if (need <= c->sf_bytes) return 0;
+    if (c->d_sf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_sf)); c->d_sf = nullptr; c->sf_bytes = 0; }
+    if (hipMalloc(&c->d_sf, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(start/freq spill) failed");
+    c->sf_bytes = need;
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_config* cfg, int device, void* hip_stream,
+                                       uint32_t max_stream_len) {
+    if (!out || !cfg || max_stream_len == 0) return fail(DIVANS_GPU_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DIVANS_GPU_EHIP, "no HIP device: the divans literal coder has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    divans_gpu_codec* c = new divans_gpu_codec();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->cfg = *cfg;
+    c->max_stream_len = max_stream_len;
+    std::vector<uint8_t> blob;
+    int rc = derive_geometry(*cfg, c->geom, blob);
+    if (rc) { delete c; return rc; }
+    c->mix = cfg->context_mixing > 1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
+    c->blocks = c->num_cus * 2u;  // 8 waves = 32 streams per CU (tuned on MI355X)
+    if (hipMalloc(&c->d_blob, LIT_BLOB_BYTES) != hipSuccess || hipMalloc(&c->d_status, 64) != hipSuccess) {
+        delete c; return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed");
+    }
+    HIP_TRY(hipMemcpy(c->d_blob, blob.data(), LIT_BLOB_BYTES, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(c->d_status, 0, 64));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    *out = c;
+    return 0;
+}
+
+extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_blob) (void)hipFree(c->d_blob);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_sf) (void)hipFree(c->d_sf);
+    if (c->d_status) (void)hipFree(c->d_status);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t threads_per_block) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (threads_per_block != 0 && threads_per_block != (uint32_t)LIT_THREADS) return fail(DIVANS_GPU_EINVAL, "threads_per_block is fixed at 256");
+    if (blocks) c->blocks = blocks;
+    return 0;
+}
+
+extern "C" size_t divans_gpu_lit_encode_bound(size_t n) {
+    // per 65 536-symbol chunk: 16 bytes of final states; every symbol grows a state by at most 15 bits
+    // (freq >= 1 of 2^15) and each 32-bit word emitted removes 32, so words <= ceil(15 * nsym / 32) + 2 per chunk
+    const size_t nsym = 2 * n;
+    const size_t nchunks = (nsym + 65535) / 65536;
+    const size_t words = (15 * nsym + 31) / 32 + 2 * nchunks;
+    const size_t bytes = 16 * nchunks + 4 * words;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+extern "C" int divans_gpu_lit_encode_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                                           const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                                           uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes) {
+    if (!c || !d_in || !d_out || !d_out_offsets || !d_out_sizes) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (n_streams == 0) return 0;
+    if ((d_in_offsets == nullptr) != (d_in_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
+    if (stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "stream_len exceeds the codec's max_stream_len");
+    if (out_slot % 16 != 0 || out_slot < divans_gpu_lit_encode_bound(d_in_sizes ? c->max_stream_len : stream_len))
+        return fail(DIVANS_GPU_ECAP, "out_slot must be a multiple of 16 and >= divans_gpu_lit_encode_bound()");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_tables(c); if (rc) return rc;
+    rc = ensure_sf(c, n_streams); if (rc) return rc;
+    LitBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
+    b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
+    b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
+    b.sf = c->d_sf;
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    RansBatch r;
+    r.sf = c->d_sf; r.n_streams = n_streams; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
+    r.in_sizes = d_in_sizes; r.out = d_out; r.out_slot = out_slot; r.out_offsets = d_out_offsets; r.out_sizes = d_out_sizes;
+    r.status = c->d_status;
+    HIP_TRY(launch_rans_encode(r, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    c->timing_pending_enc = true;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                                           const uint32_t* d_in_sizes, uint32_t n_streams, uint8_t* d_out,
+                                           const uint64_t* d_out_offsets, const uint32_t* d_out_sizes, uint32_t stream_len) {
+    if (!c || !d_in || !d_in_offsets || !d_in_sizes || !d_out) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (n_streams == 0) return 0;
+    if ((d_out_offsets == nullptr) != (d_out_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
+    if (stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "stream_len exceeds the codec's max_stream_len");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_tables(c); if (rc) return rc;
+    LitBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
+    b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
+    b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
+    b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes;
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    c->timing_pending_dec = true;
+    return 0;
+}
+
+extern "C" int divans_gpu_pack_streams(divans_gpu_codec* c, const uint8_t* d_slots, const uint64_t* d_offsets,
+                                       const uint32_t* d_sizes, uint32_t n_streams, uint8_t* d_packed,
+                                       uint64_t* d_packed_offsets, uint64_t* d_total) {
+    if (!c || !d_slots || !d_offsets || !d_sizes || !d_packed || !d_packed_offsets || !d_total) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (n_streams == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_pack(d_slots, d_offsets, d_sizes, n_streams, d_packed, d_packed_offsets, d_total, c->stream));
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info) {
+    if (!c || !info) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->timing_pending_enc) {
+        HIP_TRY(hipEventSynchronize(c->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&c->last_model_ms, c->ev[0], c->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&c->last_rans_ms, c->ev[1], c->ev[2]));
+        c->timing_pending_enc = false;
+    }
+    if (c->timing_pending_dec) {
+        HIP_TRY(hipEventSynchronize(c->ev[4]));
+        HIP_TRY(hipEventElapsedTime(&c->last_decode_ms, c->ev[3], c->ev[4]));
+        c->timing_pending_dec = false;
+    }
+    info->rows_per_stream = c->geom.total_rows;
+    info->resident_groups = resident_groups(c);
+    info->blocks = c->blocks; info->threads = LIT_THREADS;
+    info->table_bytes = (uint64_t)resident_groups(c) * c->geom.total_rows * 32u;
+    info->scratch_bytes = c->sf_bytes;
+    info->last_model_ms = c->last_model_ms; info->last_rans_ms = c->last_rans_ms; info->last_decode_ms = c->last_decode_ms;
+    return 0;
+}
+
+extern "C" int divans_gpu_selftest_division(divans_gpu_codec* c, uint64_t* mismatches) {
+    if (!c || !mismatches) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(*d)));
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof(*d), c->stream));
+    HIP_TRY(launch_selftest_division(d, c->stream));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d));
+    *mismatches = h;
+    return 0;
+}
+
+// ---- host-memory convenience wrappers ----------------------------------------------------------
+extern "C" int divans_gpu_lit_encode_host(divans_gpu_codec* c, const uint8_t* in, uint32_t stream_len, uint32_t n_streams,
+                                          uint8_t* out_packed, size_t out_cap, uint64_t* out_offsets, uint32_t* out_sizes,
+                                          size_t* out_total) {
+    if (!c || !in || !out_packed || !out_offsets || !out_sizes || !out_total) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)stream_len * n_streams;
+    const uint64_t slot = divans_gpu_lit_encode_bound(stream_len);
+    uint8_t *d_in = nullptr, *d_slots = nullptr, *d_packed = nullptr;
+    uint64_t *d_off = nullptr, *d_poff = nullptr, *d_total = nullptr; uint32_t* d_sz = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        (void)hipFree(d_in); (void)hipFree(d_slots); (void)hipFree(d_packed); (void)hipFree(d_off); (void)hipFree(d_poff);
+        (void)hipFree(d_total); (void)hipFree(d_sz);
+    };
+#define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(DIVANS_GPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    TRY_OR_CLEAN(hipMalloc(&d_in, in_bytes + 64));
+    TRY_OR_CLEAN(hipMalloc(&d_slots, slot * n_streams + 64));
+    TRY_OR_CLEAN(hipMalloc(&d_packed, slot * n_streams + 64));
+    TRY_OR_CLEAN(hipMalloc(&d_off, sizeof(uint64_t) * n_streams));
+    TRY_OR_CLEAN(hipMalloc(&d_poff, sizeof(uint64_t) * n_streams));
+    TRY_OR_CLEAN(hipMalloc(&d_total, sizeof(uint64_t)));
+    TRY_OR_CLEAN(hipMalloc(&d_sz, sizeof(uint32_t) * n_streams));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = divans_gpu_lit_encode_batch(c, d_in, nullptr, nullptr, stream_len, n_streams, d_slots, slot, d_off, d_sz);
+    if (rc) { cleanup(); return rc; }
+    rc = divans_gpu_pack_streams(c, d_slots, d_off, d_sz, n_streams, d_packed, d_poff, d_total);
+    if (rc) { cleanup(); return rc; }
+    uint64_t total = 0; uint32_t status = 0;
+    TRY_OR_CLEAN(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(&status, c->d_status, sizeof(status), hipMemcpyDeviceToHost, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(out_offsets, d_poff, sizeof(uint64_t) * n_streams, hipMemcpyDeviceToHost, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(out_sizes, d_sz, sizeof(uint32_t) * n_streams, hipMemcpyDeviceToHost, c->stream));
+    TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
+    if (status) { (void)hipMemset(c->d_status, 0, 64); cleanup(); return fail(DIVANS_GPU_EINVAL, "model produced an invalid (start,freq): unsupported speed/CDF state"); }
+    if (total > out_cap) { cleanup(); return fail(DIVANS_GPU_ECAP, "out_cap too small for the packed streams"); }
+    TRY_OR_CLEAN(hipMemcpy(out_packed, d_packed, total, hipMemcpyDeviceToHost));
+    *out_total = total;
+    cleanup();
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_decode_host(divans_gpu_codec* c, const uint8_t* in_packed, const uint64_t* in_offsets,
+                                          const uint32_t* in_sizes, uint32_t n_streams, uint8_t* out, uint32_t stream_len) {
+    if (!c || !in_packed || !in_offsets || !in_sizes || !out) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t total = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (in_offsets[i] % 4) return fail(DIVANS_GPU_EINVAL, "coded streams must start 4-byte aligned");
+        total = std::max<size_t>(total, in_offsets[i] + in_sizes[i]);
+    }
+    uint8_t *d_in = nullptr, *d_out = nullptr; uint64_t* d_off = nullptr; uint32_t* d_sz = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_off); (void)hipFree(d_sz); };
+    TRY_OR_CLEAN(hipMalloc(&d_in, total + 128));
+    TRY_OR_CLEAN(hipMalloc(&d_out, (size_t)stream_len * n_streams + 64));
+    TRY_OR_CLEAN(hipMalloc(&d_off, sizeof(uint64_t) * n_streams));
+    TRY_OR_CLEAN(hipMalloc(&d_sz, sizeof(uint32_t) * n_streams));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_in, in_packed, total, hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_off, in_offsets, sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice, c->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_sz, in_sizes, sizeof(uint32_t) * n_streams, hipMemcpyHostToDevice, c->stream));
+    int rc = divans_gpu_lit_decode_batch(c, d_in, d_off, d_sz, n_streams, d_out, nullptr, nullptr, stream_len);
+    if (rc) { cleanup(); return rc; }
+    TRY_OR_CLEAN(hipMemcpyAsync(out, d_out, (size_t)stream_len * n_streams, hipMemcpyDeviceToHost, c->stream));
+    TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
+    cleanup();
+    return 0;
+}

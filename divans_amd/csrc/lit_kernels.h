@@ -1,0 +1,57 @@
+// lit_kernels.h -- shared between the HIP kernels and the C-ABI host code (not a public header).
+#ifndef DIVANS_LIT_KERNELS_H_
+#define DIVANS_LIT_KERNELS_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace divans_hip {
+
+constexpr int LIT_THREADS = 256;    // 4 waves = 16 streams per workgroup
+constexpr int RANS_THREADS = 64;    // one wave, one lane per stream
+
+// per-batch constant tables staged in LDS by every workgroup
+constexpr uint32_t LIT_BLOB_LUT0 = 0;       // literal_lut0[256]   codec/interface.rs:199-222
+constexpr uint32_t LIT_BLOB_LUT1 = 256;     // literal_lut1[256]   codec/interface.rs:223-238
+constexpr uint32_t LIT_BLOB_CMAP = 512;     // literal_context_map[btype*64 .. +64]
+constexpr uint32_t LIT_BLOB_MIX = 576;      // mixing_mask[8192]
+constexpr uint32_t LIT_BLOB_BYTES = 576 + 8192;
+
+// How the (3 x 256 x 256) prior cube of LiteralNibblePriors (codec/priors.rs:35-37) is compacted for
+// one configuration: only the planes / context columns the configuration can reach are materialised.
+struct LitGeometry {
+    uint32_t nctx;        // number of context-map output values (columns of the high-nibble table)
+    uint32_t low_width;   // 16, or 256 when some mixing value is 1 (index_c carries context bits)
+    uint32_t plane0, plane1, plane2;  // compact plane index of t = (mm>>7)^(opt_1_f_mask>>2)
+    uint32_t low_base;    // first row of the low-nibble table
+    uint32_t cm_base;     // first row of LiteralCommandPriorsCM (FirstNibble then SecondNibble)
+    uint32_t total_rows;  // rows per stream
+    int32_t mm_uniform;   // the mixing value when every reachable entry is equal, else -1
+    int32_t ctx_const;    // the context when the context map is constant, else -1
+    int32_t inc0, lim0, inc1, lim1, inc2, lim2, inc3, lim3;  // literal_adaptation Speeds (scalars: no dynamic indexing of kernargs)
+};
+
+struct LitBatch {
+    const uint8_t* blob;        // LIT_BLOB_BYTES of configuration tables
+    LitGeometry geom;
+    int16_t* tables;            // [resident groups][total_rows][16]
+    uint32_t n_streams, stream_len, max_stream_len;
+    // encode: literal bytes in, (start|freq<<16) out.  decode: coded bytes in, literal bytes out.
+    const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
+    uint8_t* out; const uint64_t* out_offsets; const uint32_t* out_sizes;
+    uint32_t* sf;               // encode only: [n_streams][2*max_stream_len]
+};
+
+struct RansBatch {
+    const uint32_t* sf; uint32_t n_streams, stream_len, max_stream_len; const uint32_t* in_sizes;
+    uint8_t* out; uint64_t out_slot; uint64_t* out_offsets; uint32_t* out_sizes; uint32_t* status;
+};
+
+hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
+hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st);
+hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
+hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
+                       uint64_t* dst_off, uint64_t* total, hipStream_t st);
+hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);
+
+}  // namespace divans_hip
+#endif

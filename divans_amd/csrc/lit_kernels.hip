@@ -1,0 +1,514 @@
+// lit_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the divans literal coder.
+//
+// Mapping: one 16-lane DPP row owns one stream; lane i of the row holds cdf[i] of
+// the CDF row being coded, so blend / search / start-freq are one VALU op per step for all 16
+// entries, and the stream's scalar state (rANS states, context bytes, weights) is replicated
+// across the 16 lanes.  Four streams share a wave64, sixteen a 256-thread workgroup.
+//
+// What each device function restates (paths relative to the reference tree):
+//   exact_div            probability/numeric.rs:25-31 (any exact division is bit-compatible, make_div_lut.rs:37-39)
+//   start/freq           probability/interface.rs:97-108 sym_to_start_and_freq
+//   symbol search        probability/interface.rs:136-198 cdf_offset_to_sym_start_and_freq
+//   blend_row            probability/frequentist_cdf.rs:74-85
+//   average_rows         probability/frequentist_cdf.rs:58-72
+//   weights_update       codec/weights.rs:23-133
+//   select_rows          codec/literal.rs:154-259 (index math of code_nibble)
+//   decode_step          ans.rs:225-252 (get_nibble + helper_advance_sym), refill ans.rs:428-442
+//   rans_encode_kernel   ans.rs:302-378 (reverse_put_sym / flush_chunk)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lit_kernels.h"
+
+namespace divans_hip {
+
+#define DPP_ROW_SHR1 0x111
+#define DPP_ROW_BCAST(n) (0x150 + (n))
+
+// value of lane `n` of this 16-lane row, broadcast to the whole row (v_mov_b32_dpp row_newbcast)
+template <int N>
+__device__ __forceinline__ int row_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST(N), 0xf, 0xf, false);
+}
+// value of the previous lane in the row, 0 for the first lane
+__device__ __forceinline__ int row_prev_or_zero(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR1, 0xf, 0xf, true);
+}
+// value of lane (row_base + idx) -- idx is row-uniform but not compile-time
+__device__ __forceinline__ int row_gather(int v, int row_base_lane, int idx) {
+    return __builtin_amdgcn_ds_bpermute((row_base_lane + idx) << 2, v);
+}
+__device__ __forceinline__ int sext16(int v) { return (int)(short)v; }
+
+// floor(n / d) for 0 <= n < 2^31, 1 <= d < 2^15, given rcp ~= 1/d (v_rcp_f32, 1 ulp).
+// The float estimate is within 2^-6 of the true quotient, so one step of correction makes it exact.
+__device__ __forceinline__ uint32_t exact_div(uint32_t n, uint32_t d, float rcp) {
+    uint32_t q = (uint32_t)((float)n * rcp);
+    int32_t r = (int32_t)(n - q * d);
+    if (r < 0) { q -= 1; }
+    else if (r >= (int32_t)d) { q += 1; }
+    return q;
+}
+
+struct RowSel {
+    uint32_t stride_row;   // row index inside the stream's table
+    uint32_t cm_row;       // context-map row (mixing only)
+    bool use_default;      // mm_opts == 2: code with a fresh default CDF, never blend (non-mixing path)
+    bool no_blend;         // mm_opts == 2: stride row is not blended
+};
+
+// codec/literal.rs:176-208.  All inputs are row-uniform.
+template <bool HIGH>
+__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* __restrict__ lds_mix,
+                                              uint32_t ctx, uint32_t prev_byte, uint64_t last8, uint32_t hi_nib) {
+    uint32_t mm_index = ctx | (HIGH ? ((prev_byte >> 4) << 8) : (((hi_nib & 0xf) << 8) | 4096));
+    uint32_t mm_opts = g.mm_uniform >= 0 ? (uint32_t)g.mm_uniform : (uint32_t)lds_mix[mm_index];
+    uint32_t fast_cm = (mm_opts != 3) ? 0xffu : 0u;
+    uint32_t mm = (mm_opts != 0 && mm_opts != 3) ? 0xffu : 0u;
+    uint32_t opt1 = (mm_opts == 1) ? 0xfu : 0u;
+    uint32_t stride_offset = 0;
+    if (mm_opts >= 4) { uint32_t x = mm_opts ^ 4u; stride_offset = (x < 7u ? x : 7u) << 3; }
+    uint32_t sb = (uint32_t)(last8 >> (56 - stride_offset)) & 0xffu;
+    uint32_t b, c, width;
+    if (HIGH) { b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx; }
+    else { b = ((mm & sb) | (~mm & ctx)) & 0xffu; c = (hi_nib & fast_cm) | ((ctx & opt1) << 4); width = g.low_width; }
+    uint32_t t = (mm >> 7) ^ (opt1 >> 2);
+    uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);
+    RowSel r;
+    r.stride_row = (HIGH ? 0u : g.low_base) + (plane * 256u + b) * width + c;
+    r.cm_row = g.cm_base + (HIGH ? ctx : g.nctx + hi_nib + 16u * ctx);
+    r.use_default = mm_opts == 2;
+    r.no_blend = mm_opts == 2;
+    return r;
+}
+
+// frequentist_cdf.rs:74-85 on one entry per lane (li = lane index in row)
+__device__ __forceinline__ int blend_row(int c, int li, int sym, int inc, int lim) {
+    c = (li >= sym) ? sext16(c + inc) : c;
+    int c15 = row_bcast<15>(c);
+    if (c15 >= lim) {
+        int t = sext16(c + li + 1);
+        c = sext16(t - (t >> 2));
+    }
+    return c;
+}
+
+// frequentist_cdf.rs:58-72: self = cm row, other = stride row
+__device__ __forceinline__ int average_rows(int cm, int st, int mix_rate) {
+    int ourmax = row_bcast<15>(cm);
+    int othermax = row_bcast<15>(st);
+    uint32_t prod = (uint32_t)(ourmax * othermax);
+    int lz = __clz((int)prod);
+    lz = lz > 17 ? 17 : lz;
+    int sh = 17 - lz;
+    int inv = (1 << 15) - mix_rate;
+    int rs = (cm * othermax) >> sh;
+    int ro = (st * ourmax) >> sh;
+    return sext16((int)((uint32_t)rs * (uint32_t)mix_rate + (uint32_t)ro * (uint32_t)inv + 1u) >> 15);
+}
+
+struct Weights { int w0, w1; int norm; };  // weights.rs:4-8 (norm = normalized_weight as u16)
+
+__device__ __forceinline__ int clz64(uint64_t x) { return x ? __clzll((long long)x) : 64; }
+
+// weights.rs:110-133
+__device__ __forceinline__ int new_weight(int prob_i, int pmix, int wi) {
+    uint64_t p1 = (uint64_t)(int64_t)pmix;
+    uint64_t total = 1ull << 15;
+    uint64_t p0 = total - p1;
+    uint64_t error = total - p1;
+    uint64_t efficacy = total * (uint64_t)(int64_t)prob_i - p1 * total;
+    int lg = 64 - clz64(p1 * p0);
+    int64_t adj = (int64_t)(error * efficacy) >> (lg & 63);
+    int nw = (int)(uint32_t)((uint64_t)(int64_t)wi + (uint64_t)adj);
+    return nw > 1 ? nw : 1;
+}
+
+// weights.rs:23-38 + normalize_weights :64-80 + compute_normalized_weight :54-62
+__device__ __forceinline__ void weights_update(Weights& w, int p_cm, int p_stride, int pmix) {
+    if (((w.w0 | w.w1) & 0x7f000000) != 0) {
+        int lz0 = __clz(w.w0), lz1 = __clz(w.w1);
+        int ilog = 32 - (lz0 < lz1 ? lz0 : lz1);
+        if (ilog >= 24) { w.w0 >>= (ilog - 24); w.w1 >>= (ilog - 24); }
+    }
+    int n0 = new_weight(p_cm, pmix, w.w0);
+    int n1 = new_weight(p_stride, pmix, w.w1);
+    w.w0 = n0; w.w1 = n1;
+    int64_t total = (int64_t)n0 + (int64_t)n1;
+    int shift = 56 - clz64((uint64_t)total);
+    shift = shift < 0 ? 0 : shift;
+    uint32_t t8 = (uint32_t)(total >> shift) & 0xffu;
+    uint32_t num = ((uint32_t)(n0 >> shift) << 8) & 0xffffu;
+    uint32_t q = t8 ? num / t8 : 0u;   // fast_divide_16bit_by_8bit == exact '/' (make_div_lut.rs:11-23); RECIPROCAL8[0]==0
+    w.norm = (int)((q << 7) & 0xffffu);
+}
+
+__device__ __forceinline__ void load_config_to_lds(uint8_t* lds, const uint8_t* __restrict__ blob) {
+    const uint32_t* src = (const uint32_t*)blob;
+    uint32_t* dst = (uint32_t*)lds;
+    for (uint32_t i = threadIdx.x; i < LIT_BLOB_BYTES / 4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// Fill this stream's table with default rows (ffi/alloc_util.rs:77-79: allocations are default-initialised).
+__device__ __forceinline__ void init_table(int16_t* tbl, uint32_t rows, int li) {
+    // row = 16 x i16 = two 16-byte halves; even lanes write the first half, odd lanes the second
+    uint4 lo, hi;
+    lo.x = 4u | (8u << 16); lo.y = 12u | (16u << 16); lo.z = 20u | (24u << 16); lo.w = 28u | (32u << 16);
+    hi.x = 36u | (40u << 16); hi.y = 44u | (48u << 16); hi.z = 52u | (56u << 16); hi.w = 60u | (64u << 16);
+    uint4 v = (li & 1) ? hi : lo;
+    uint4* p = (uint4*)tbl;
+    for (uint32_t i = (uint32_t)li; i < rows * 2u; i += 16u) p[i] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the row loads that follow must see the fill
+}
+
+__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds, uint64_t last8) {
+    if (g.ctx_const >= 0) return (uint32_t)g.ctx_const;
+    uint32_t prev = (uint32_t)(last8 >> 56), pp = (uint32_t)(last8 >> 48) & 0xffu;
+    uint32_t sel = lds[LIT_BLOB_LUT0 + prev] | lds[LIT_BLOB_LUT1 + pp];
+    return lds[LIT_BLOB_CMAP + (sel & 63u)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encode, pass 1: adaptive model.  bytes -> (start | freq << 16) per nibble.
+// ---------------------------------------------------------------------------------------------
+template <bool HIGH, bool MIX>
+__device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const uint8_t* lds, int16_t* tbl, int li, int rbase,
+                                                 uint32_t ctx, uint32_t prev, uint64_t last8, uint32_t hi_nib, int sym,
+                                                 Weights& w) {
+    RowSel rs = select_rows<HIGH>(g, lds + LIT_BLOB_MIX, ctx, prev, last8, hi_nib);
+    int16_t* srow = tbl + (size_t)rs.stride_row * 16u + li;
+    int st = (int)*srow;
+    uint32_t packed;
+    if (MIX) {
+        int16_t* crow = tbl + (size_t)rs.cm_row * 16u + li;
+        int cm = (int)*crow;
+        int p = average_rows(cm, st, w.norm);
+        int pmax = row_bcast<15>(p), cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
+        uint32_t dp = exact_div((uint32_t)p << 15, (uint32_t)pmax, __builtin_amdgcn_rcpf((float)pmax));
+        uint32_t dc = exact_div((uint32_t)cm << 15, (uint32_t)cmax, __builtin_amdgcn_rcpf((float)cmax));
+        uint32_t ds = exact_div((uint32_t)st << 15, (uint32_t)smax, __builtin_amdgcn_rcpf((float)smax));
+        int dpp = row_prev_or_zero((int)dp), dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
+        uint32_t sf = ((uint32_t)(dpp + 1) & 0xffffu) | ((uint32_t)((int)dp - dpp - 1) << 16);
+        uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
+        packed = (uint32_t)row_gather((int)sf, rbase, sym);
+        uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
+        weights_update(w, sext16((int)(freqs & 0xffffu)), sext16((int)(freqs >> 16)), sext16((int)(packed >> 16)));
+        cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
+        *crow = (int16_t)cm;
+    } else {
+        int cv = rs.use_default ? 4 * (li + 1) : st;
+        int mx = row_bcast<15>(cv);
+        uint32_t d = exact_div((uint32_t)cv << 15, (uint32_t)mx, __builtin_amdgcn_rcpf((float)mx));
+        int dprev = row_prev_or_zero((int)d);
+        uint32_t sf = ((uint32_t)(dprev + 1) & 0xffffu) | ((uint32_t)((int)d - dprev - 1) << 16);
+        packed = (uint32_t)row_gather((int)sf, rbase, sym);
+    }
+    if (!rs.no_blend) {
+        st = blend_row(st, li, sym, g.inc0, g.lim0);   // literal_adaptation[0] for both nibbles, literal.rs:320,354
+        *srow = (int16_t)st;
+    }
+    return packed;
+}
+
+template <bool MIX>
+__global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(LitBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    load_config_to_lds(lds, b.blob);
+    const LitGeometry& g = b.geom;
+    const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48;
+    const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
+    const uint32_t G = gridDim.x * (LIT_THREADS / 16);
+    int16_t* tbl = b.tables + (size_t)gg * g.total_rows * 16u;
+    for (uint32_t s = gg; s < b.n_streams; s += G) {
+        const uint8_t* in = b.in + (b.in_offsets ? b.in_offsets[s] : (uint64_t)s * b.stream_len);
+        const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
+        uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
+        init_table(tbl, g.total_rows, li);
+        Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};  // model_weights[1]=high, [0]=low (literal.rs:230)
+        uint64_t last8 = 0;
+        uint32_t pend_a = 0, pend_b = 0;  // lane li keeps the pairs of nibbles 16k+li (hi) / (lo)
+        for (uint32_t base = 0; base < len; base += 16) {
+            // each lane fetches one literal byte of the next 16 (coalesced 16-byte read per stream)
+            uint32_t mine = (base + li < len) ? in[base + li] : 0u;
+            uint32_t cnt = len - base < 16u ? len - base : 16u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                uint32_t byte = (uint32_t)row_gather((int)mine, rbase, (int)k);
+                uint32_t prev = (uint32_t)(last8 >> 56);
+                uint32_t ctx = context_of(g, lds, last8);
+                uint32_t hi = byte >> 4, lo = byte & 15u;
+                uint32_t ph = model_nibble<true, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, 0u, (int)hi, wh);
+                uint32_t pl = model_nibble<false, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, hi, (int)lo, wl);
+                last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                // pairs of byte k go to lane k: nibble 2k -> pend_a, 2k+1 -> pend_b
+                if ((uint32_t)li == k) { pend_a = ph; pend_b = pl; }
+            }
+            // nibble index of byte (base+li) is 2*(base+li): each lane stores its two 4-byte pairs (8 B, coalesced 128 B per row)
+            if (base + li < len) {
+                uint2 v; v.x = pend_a; v.y = pend_b;
+                *(uint2*)(sf + 2u * (size_t)(base + li)) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encode, pass 2: rANS.  One lane per stream, walks the (start,freq) pairs newest -> oldest and
+// writes the coded bytes right-aligned into the stream's slot.  ans.rs:302-378.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t div31(uint32_t n, uint32_t d, float rcp, uint32_t& rem) {
+    uint32_t q = (uint32_t)((float)n * rcp);
+    int32_t r = (int32_t)(n - q * d);
+    if (r < 0) { q -= 1; r += (int32_t)d; }
+    else if (r >= (int32_t)d) { q += 1; r -= (int32_t)d; }
+    rem = (uint32_t)r;
+    return q;
+}
+
+__device__ __forceinline__ uint64_t rans_put(uint64_t state, uint32_t start, uint32_t freq, uint32_t*& wp) {
+    // rescale_lim = ((2^31 >> 15) << 32) * freq = freq << 48
+    if (state >= ((uint64_t)freq << 48)) { *--wp = (uint32_t)state; state >>= 32; }
+    // state < freq * 2^48: long division by the 15-bit freq in three <2^31 / freq steps
+    float rcp = __builtin_amdgcn_rcpf((float)freq);
+    uint32_t hi = (uint32_t)(state >> 32), lo = (uint32_t)state;
+    uint32_t r1, r2, r3;
+    uint32_t q1 = div31(hi, freq, rcp, r1);
+    uint32_t q2 = div31((r1 << 16) | (lo >> 16), freq, rcp, r2);
+    uint32_t q3 = div31((r2 << 16) | (lo & 0xffffu), freq, rcp, r3);
+    uint64_t q = ((uint64_t)q1 << 32) | ((uint64_t)q2 << 16) | (uint64_t)q3;
+    return (q << 15) + (uint64_t)r3 + (uint64_t)start;
+}
+
+__global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(RansBatch b) {
+    const uint32_t s = blockIdx.x * RANS_THREADS + threadIdx.x;
+    if (s >= b.n_streams) return;
+    const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
+    const uint32_t nsym = 2u * len;
+    const uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
+    uint8_t* slot_end = b.out + (uint64_t)(s + 1) * b.out_slot;
+    uint32_t* wp = (uint32_t*)slot_end;
+    uint32_t bad = 0;
+    // chunk k covers symbols [k*65536, min((k+1)*65536, nsym)); later chunks sit later in the stream
+    uint32_t nchunks = (nsym + 65535u) >> 16;
+    for (uint32_t ck = nchunks; ck-- > 0;) {
+        uint32_t beg = ck << 16;
+        uint32_t end = beg + 65536u < nsym ? beg + 65536u : nsym;
+        uint64_t a = 1ull << 31, bst = 1ull << 31;
+        for (uint32_t i = end; i-- > beg;) {
+            uint32_t p = sf[i];
+            uint32_t start = p & 0xffffu, freq = p >> 16;
+            bad |= (freq == 0u) | (freq >> 15) | (start >> 15);
+            freq = freq ? freq : 1u;
+            uint64_t x = rans_put(a, start, freq, wp);
+            a = bst; bst = x;
+        }
+        // unconditional swap (ans.rs:354-356), then [state_a][state_b] little-endian in front of the words
+        uint64_t fa = bst, fb = a;
+        *--wp = (uint32_t)(fb >> 32); *--wp = (uint32_t)fb;
+        *--wp = (uint32_t)(fa >> 32); *--wp = (uint32_t)fa;
+    }
+    uint64_t off = (uint64_t)((uint8_t*)wp - b.out);
+    b.out_offsets[s] = off;
+    b.out_sizes[s] = (uint32_t)(slot_end - (uint8_t*)wp);
+    if (bad) atomicOr(b.status, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decode: fused rANS decode + CDF search + blend.
+// ---------------------------------------------------------------------------------------------
+struct WordWindow {        // 16 upcoming 32-bit words of the coded stream, one per lane of the row
+    const uint32_t* in; uint32_t nwords; uint32_t base, pos; uint32_t w;
+    __device__ __forceinline__ void reload(int li) { base = pos; w = (base + li < nwords) ? in[base + li] : 0u; }
+    __device__ __forceinline__ uint32_t next(int li, int rbase) {
+        uint32_t v = (uint32_t)row_gather((int)w, rbase, (int)(pos - base));
+        pos += 1;
+        if (pos - base == 16u) reload(li);
+        return v;
+    }
+};
+
+template <bool HIGH, bool MIX>
+__device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const uint8_t* lds, int16_t* tbl, int li, int rbase,
+                                                  uint32_t ctx, uint32_t prev, uint64_t last8, uint32_t hi_nib,
+                                                  uint64_t& S, Weights& w) {
+    RowSel rs = select_rows<HIGH>(g, lds + LIT_BLOB_MIX, ctx, prev, last8, hi_nib);
+    int16_t* srow = tbl + (size_t)rs.stride_row * 16u + li;
+    int st = (int)*srow;
+    int16_t* crow = nullptr;
+    int cm = 0;
+    int cv;
+    if (MIX) {
+        crow = tbl + (size_t)rs.cm_row * 16u + li;
+        cm = (int)*crow;
+        cv = average_rows(cm, st, w.norm);
+    } else {
+        cv = rs.use_default ? 4 * (li + 1) : st;
+    }
+    // cdf_offset_to_sym_start_and_freq: first i<15 with rescaled < cdf[i]
+    uint32_t slot = (uint32_t)S & 0x7fffu;
+    int mx = row_bcast<15>(cv);
+    int rescaled = sext16((int)((slot * (uint32_t)mx) >> 15));
+    unsigned long long ge = __ballot(rescaled >= cv);
+    int sym = __popc((uint32_t)(ge >> rbase) & 0x7fffu);
+    uint32_t d = exact_div((uint32_t)cv << 15, (uint32_t)mx, __builtin_amdgcn_rcpf((float)mx));
+    int dprev = row_prev_or_zero((int)d);
+    uint32_t sf = ((uint32_t)(dprev + 1) & 0xffffu) | ((uint32_t)((int)d - dprev - 1) << 16);
+    uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
+    int64_t start = (int64_t)sext16((int)(packed & 0xffffu));
+    int64_t freq = (int64_t)sext16((int)(packed >> 16));
+    // helper_advance_sym ans.rs:238: x = freq * (state >> 15) + (state & mask) - start
+    S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;
+    if (MIX) {
+        int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
+        uint32_t dc = exact_div((uint32_t)cm << 15, (uint32_t)cmax, __builtin_amdgcn_rcpf((float)cmax));
+        uint32_t ds = exact_div((uint32_t)st << 15, (uint32_t)smax, __builtin_amdgcn_rcpf((float)smax));
+        int dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
+        uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
+        uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
+        weights_update(w, sext16((int)(freqs & 0xffffu)), sext16((int)(freqs >> 16)), (int)freq);
+        cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
+        *crow = (int16_t)cm;
+    }
+    if (!rs.no_blend) {
+        st = blend_row(st, li, sym, g.inc0, g.lim0);
+        *srow = (int16_t)st;
+    }
+    return (uint32_t)sym;
+}
+
+template <bool MIX>
+__global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(LitBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    load_config_to_lds(lds, b.blob);
+    const LitGeometry& g = b.geom;
+    const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48;
+    const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
+    const uint32_t G = gridDim.x * (LIT_THREADS / 16);
+    int16_t* tbl = b.tables + (size_t)gg * g.total_rows * 16u;
+    for (uint32_t s = gg; s < b.n_streams; s += G) {
+        const uint32_t len = b.out_sizes ? b.out_sizes[s] : b.stream_len;
+        uint8_t* out = b.out + (b.out_offsets ? b.out_offsets[s] : (uint64_t)s * b.stream_len);
+        WordWindow ww;
+        ww.in = (const uint32_t*)(b.in + b.in_offsets[s]);
+        ww.nwords = b.in_sizes[s] >> 2;
+        ww.pos = 0;
+        ww.reload(li);
+        init_table(tbl, g.total_rows, li);
+        Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};
+        uint64_t last8 = 0;
+        uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
+        uint32_t outb = 0;
+        for (uint32_t i = 0; i < len; ++i) {
+            if ((i & 32767u) == 0u) {
+                // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
+                uint32_t a0 = ww.next(li, rbase), a1 = ww.next(li, rbase), b0 = ww.next(li, rbase), b1 = ww.next(li, rbase);
+                SA = ((uint64_t)a1 << 32) | a0;
+                SB = ((uint64_t)b1 << 32) | b0;
+            }
+            uint32_t prev = (uint32_t)(last8 >> 56);
+            uint32_t ctx = context_of(g, lds, last8);
+            // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
+            if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
+            uint32_t hi = decode_nibble<true, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, 0u, SA, wh);
+            if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
+            uint32_t lo = decode_nibble<false, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, hi, SB, wl);
+            uint32_t byte = (hi << 4) | lo;
+            last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+            if ((uint32_t)li == (i & 15u)) outb = byte;
+            if ((i & 15u) == 15u || i + 1 == len) {
+                uint32_t basei = i & ~15u;
+                if (basei + li <= i) out[basei + li] = (uint8_t)outb;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack_streams: exclusive scan of the 4-byte-rounded sizes (single block, 3 phases) + coalesced copy
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_sizes_kernel(const uint32_t* sizes, uint32_t n, uint64_t* offsets, uint64_t* total) {
+    __shared__ uint64_t partial[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t beg = t * per, end = beg + per < n ? beg + per : n;
+    uint64_t sum = 0;
+    for (uint32_t i = beg; i < end; ++i) sum += (sizes[i] + 3u) & ~3u;
+    partial[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        uint64_t v = t >= off ? partial[t - off] : 0;
+        __syncthreads();
+        partial[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = t ? partial[t - 1] : 0;
+    for (uint32_t i = beg; i < end; ++i) { offsets[i] = run; run += (sizes[i] + 3u) & ~3u; }
+    if (t == 1023u) *total = partial[1023];
+}
+
+__global__ __launch_bounds__(256) void pack_copy_kernel(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes,
+                                                        uint32_t n, uint8_t* packed, const uint64_t* dst_off) {
+    // one wave per stream, 4 bytes per lane per step (coded streams are whole 32-bit words)
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const uint32_t nw = (gridDim.x * 256u) >> 6;
+    for (uint32_t s = wave; s < n; s += nw) {
+        const uint32_t* src = (const uint32_t*)(slots + src_off[s]);
+        uint32_t* dst = (uint32_t*)(packed + dst_off[s]);
+        const uint32_t words = (sizes[s] + 3u) >> 2;
+        for (uint32_t i = lane; i < words; i += 64u) dst[i] = src[i];
+    }
+}
+
+// exhaustive check of exact_div against '/' (tests): grid-stride over max in [1, 32767]
+__global__ void selftest_division_kernel(unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (uint32_t mx = blockIdx.x + 1; mx < 32768u; mx += gridDim.x) {
+        float rcp = __builtin_amdgcn_rcpf((float)mx);
+        for (uint32_t c = threadIdx.x; c <= mx; c += blockDim.x) {
+            uint32_t n = c << 15;
+            bad += exact_div(n, mx, rcp) != n / mx;
+        }
+        // the rANS long division uses numerators up to 2^31 - 1
+        for (uint32_t k = threadIdx.x; k < 4096u; k += blockDim.x) {
+            uint32_t n = (mx << 16) - 1u - k * 7u;
+            uint32_t rem;
+            uint32_t q = div31(n, mx, rcp, rem);
+            bad += (q != n / mx) | (rem != n % mx);
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers (called from capi.cpp)
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
+    if (mix) hipLaunchKernelGGL(lit_model_encode_kernel<true>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+    else hipLaunchKernelGGL(lit_model_encode_kernel<false>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+    return hipGetLastError();
+}
+hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
+    uint32_t blocks = (b.n_streams + RANS_THREADS - 1) / RANS_THREADS;
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(blocks), dim3(RANS_THREADS), 0, st, b);
+    return hipGetLastError();
+}
+hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
+    if (mix) hipLaunchKernelGGL(lit_decode_kernel<true>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+    else hipLaunchKernelGGL(lit_decode_kernel<false>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+    return hipGetLastError();
+}
+hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
+                       uint64_t* dst_off, uint64_t* total, hipStream_t st) {
+    hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, st, sizes, n, dst_off, total);
+    uint32_t blocks = (n + 3) / 4;
+    blocks = blocks > 2048 ? 2048 : (blocks ? blocks : 1);
+    hipLaunchKernelGGL(pack_copy_kernel, dim3(blocks), dim3(256), 0, st, slots, src_off, sizes, n, packed, dst_off);
+    return hipGetLastError();
+}
+hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st) {
+    hipLaunchKernelGGL(selftest_division_kernel, dim3(1024), dim3(256), 0, st, d_mismatches);
+    return hipGetLastError();
+}
+
+}  // namespace divans_hip

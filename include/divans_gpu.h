@@ -1,0 +1,117 @@
+/*
+ * divans_gpu.h -- batch C ABI of the MI355X literal-stream coder (NEW entry points).
+ *
+ * The reference's per-stream C ABI (c/divans/ffi.h, mirrored in include/divans_ffi.h) feeds one
+ * stream at a time through divans_encode()/divans_decode(); it cannot express "65 536 independent
+ * streams in one launch".  These entry points are what a reference-side binding would call where
+ * it today drives the literal coder:
+ *   encode : LiteralState::encode_or_decode_content_bytes -> code_nibble_array
+ *            (src/codec/literal.rs:404-494, 261-394) + ANSEncoder::put_nibble/flush_chunk
+ *            (src/ans.rs:279-378)
+ *   decode : the same generic function instantiated with ANSDecoder (src/ans.rs:225-252,428-442)
+ * Each stream is an independent LIT_CODER byte stream (src/codec/interface.rs:48-50) with fresh
+ * priors: exactly the bytes ANSEncoder hands to the Mux for stream 1, chunk after chunk.
+ *
+ * All buffers named d_* are DEVICE pointers (HBM); nothing here touches torch types.
+ * Every function returns 0 on success, a negative DIVANS_GPU_E* code otherwise.
+ */
+#ifndef DIVANS_GPU_H_
+#define DIVANS_GPU_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIVANS_GPU_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define DIVANS_GPU_ENOMEM (-2)   /* device allocation failed */
+#define DIVANS_GPU_EHIP (-3)     /* HIP runtime error (see divans_gpu_last_error) */
+#define DIVANS_GPU_ECAP (-4)     /* an output slot was too small */
+
+#define DIVANS_GPU_MAX_LITERAL_CONTEXT_MAP_SIZE (256 * 64) /* brotli MAX_LITERAL_CONTEXT_MAP_SIZE */
+#define DIVANS_GPU_NUM_MIXING_VALUES 8192                  /* codec/interface.rs:137 */
+
+/* Speed(inc, lim): src/probability/interface.rs:298-375 */
+typedef struct divans_speed { int16_t inc, lim; } divans_speed;
+
+/* What LiteralBookKeeping (src/codec/interface.rs:125-140) holds once the stream's PredictionMode
+ * and BlockSwitchLiteral commands have been observed (obs_prediction_mode_context_map :285-319). */
+typedef struct divans_lit_config {
+    uint8_t literal_context_map[DIVANS_GPU_MAX_LITERAL_CONTEXT_MAP_SIZE];
+    uint8_t mixing_mask[DIVANS_GPU_NUM_MIXING_VALUES];
+    uint8_t prediction_mode;   /* LSB6=0 MSB6=1 UTF8=2 SIGN=3 (LiteralPredictionModeNibble) */
+    uint8_t btype;             /* literal block type of the stream's BlockSwitchLiteral */
+    uint8_t context_mixing;    /* dynamic_context_mixing; >1 selects MixingTrait (specializations.rs:27-47) */
+    uint8_t reserved;
+    divans_speed literal_adaptation[4]; /* [0..2) stride, [2..4) context map (codec/interface.rs:303-308) */
+} divans_lit_config;
+
+/* reference TestSimple (src/bin/benchmark.rs:195-206) and TestContextMixing via bench_no_ir (:156-167,305-343) */
+void divans_lit_config_simple(divans_lit_config *cfg);
+void divans_lit_config_context_mixing(divans_lit_config *cfg);
+
+typedef struct divans_gpu_codec divans_gpu_codec;
+
+/* Creates a codec bound to `device`.  All launches go to `hip_stream` (a hipStream_t, may be NULL for
+ * the default stream).  `max_stream_len` bounds the byte length of any one stream in later calls. */
+int divans_gpu_codec_create(divans_gpu_codec **out, const divans_lit_config *cfg, int device, void *hip_stream,
+                            uint32_t max_stream_len);
+void divans_gpu_codec_destroy(divans_gpu_codec *c);
+const char *divans_gpu_last_error(void);
+
+/* Worst-case coded bytes for an n-byte stream (16 B of state per 65 536-symbol chunk plus at most
+ * one 32-bit renormalisation word per symbol... see DESIGN.md): size your output slots with this. */
+size_t divans_gpu_lit_encode_bound(size_t n);
+
+/* Encode n_streams independent streams.
+ *   d_in + in_offsets[i] .. +in_sizes[i]   : literal bytes of stream i (d_in_offsets/d_in_sizes may be NULL:
+ *                                            then stream i is d_in + i*stream_len, stream_len bytes)
+ *   d_out + i*out_slot                     : output slot of stream i (out_slot % 16 == 0,
+ *                                            out_slot >= divans_gpu_lit_encode_bound(len))
+ * On return (stream-ordered): d_out_offsets[i] = byte offset in d_out where stream i's coded bytes
+ * start (they are RIGHT-aligned in the slot because rANS emits last-byte-first), d_out_sizes[i] = length. */
+int divans_gpu_lit_encode_batch(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
+                                const uint32_t *d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                                uint8_t *d_out, uint64_t out_slot, uint64_t *d_out_offsets, uint32_t *d_out_sizes);
+
+/* Decode n_streams streams: coded bytes at d_in + d_in_offsets[i] (4-byte aligned), d_in_sizes[i] long;
+ * stream i decodes to d_out + (d_out_offsets ? d_out_offsets[i] : i*stream_len), d_out_sizes[i] (or stream_len) bytes. */
+int divans_gpu_lit_decode_batch(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
+                                const uint32_t *d_in_sizes, uint32_t n_streams, uint8_t *d_out,
+                                const uint64_t *d_out_offsets, const uint32_t *d_out_sizes, uint32_t stream_len);
+
+/* Compacts the right-aligned slots into one contiguous buffer (4-byte aligned starts):
+ * d_packed_offsets[i] = exclusive prefix sum of round_up(sizes,4); returns total via *d_total (device u64). */
+int divans_gpu_pack_streams(divans_gpu_codec *c, const uint8_t *d_slots, const uint64_t *d_offsets,
+                            const uint32_t *d_sizes, uint32_t n_streams, uint8_t *d_packed,
+                            uint64_t *d_packed_offsets, uint64_t *d_total);
+
+/* Convenience wrappers over host memory (H2D, launch, D2H, synchronous).  out_offsets/out_sizes are host arrays. */
+int divans_gpu_lit_encode_host(divans_gpu_codec *c, const uint8_t *in, uint32_t stream_len, uint32_t n_streams,
+                               uint8_t *out_packed, size_t out_cap, uint64_t *out_offsets, uint32_t *out_sizes,
+                               size_t *out_total);
+int divans_gpu_lit_decode_host(divans_gpu_codec *c, const uint8_t *in_packed, const uint64_t *in_offsets,
+                               const uint32_t *in_sizes, uint32_t n_streams, uint8_t *out, uint32_t stream_len);
+
+/* Introspection for benchmarks/tests. */
+typedef struct divans_gpu_info {
+    uint32_t rows_per_stream;      /* 32-byte CDF rows held per in-flight stream */
+    uint32_t resident_groups;      /* streams decoded concurrently (16-lane groups in the persistent grid) */
+    uint32_t blocks, threads;      /* launch geometry of the model/decode kernels */
+    uint64_t table_bytes;          /* HBM bytes of the CDF tables */
+    uint64_t scratch_bytes;        /* HBM bytes of the start/freq spill (encode) */
+    float last_model_ms, last_rans_ms, last_decode_ms; /* hipEvent timings of the last batch calls */
+} divans_gpu_info;
+int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);
+/* geometry knobs (0 keeps the default): groups-per-CU occupancy and block count, for tuning runs */
+int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t threads_per_block);
+
+/* Exhaustive self-check of the reciprocal division used by the kernels against integer '/':
+ * returns the number of mismatches over every (cdf<<15)/max with 1<=max<32768, 0<=cdf<=max. */
+int divans_gpu_selftest_division(divans_gpu_codec *c, uint64_t *mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

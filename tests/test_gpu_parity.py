@@ -1,0 +1,74 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact on both ANS byte streams."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+import workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _codec(cfg_name, max_len):
+    import divans_amd as da
+    cfg = da.config_simple() if cfg_name == "simple" else da.config_context_mixing()
+    return da, da.LiteralCodec(cfg, max_len)
+
+
+def _oracle_cfg(cfg_name):
+    return po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
+
+
+def _compare(cfg_name, blocks):
+    n, L = blocks.shape
+    da, codec = _codec(cfg_name, max(L, 1))
+    packed, offs, sizes = codec.encode_host(blocks, L)
+    ocfg = _oracle_cfg(cfg_name)
+    for i in range(n):
+        ref = po.lit_encode(ocfg, blocks[i])
+        got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
+        assert got.size == ref.size, (cfg_name, i, got.size, ref.size)
+        assert (got == ref).all(), (cfg_name, i, int(np.argmax(got != ref)))
+    back = codec.decode_host(packed, offs, sizes, L)
+    assert (back == blocks).all()
+    codec.close()
+
+
+def test_division_selftest():
+    da, codec = _codec("simple", 64)
+    assert codec.selftest_division() == 0
+    codec.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+@pytest.mark.parametrize("length", [1, 2, 15, 16, 17, 255, 4096, 32768, 32769, 65536])
+def test_lengths_bit_exact(cfg_name, length, corpus):
+    blocks = workload.make_blocks(corpus, 3, 5, block_len=length, perturb_per_block=max(length // 100, 0))
+    _compare(cfg_name, blocks)
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_many_streams_bit_exact(cfg_name, corpus):
+    # more streams than resident groups so every group recycles its table
+    blocks = workload.make_blocks(corpus, 0, 9000, block_len=1024)
+    _compare(cfg_name, blocks[:9000:7].copy())
+    n = blocks.shape[0]
+    da, codec = _codec(cfg_name, 1024)
+    packed, offs, sizes = codec.encode_host(blocks, 1024)
+    back = codec.decode_host(packed, offs, sizes, 1024)
+    assert (back == blocks).all()
+    # spot-check a spread of streams against the oracle
+    ocfg = _oracle_cfg(cfg_name)
+    for i in range(0, n, 257):
+        ref = po.lit_encode(ocfg, blocks[i])
+        assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == ref).all()
+    codec.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_adversarial_inputs(cfg_name, shuffle384):
+    rng = np.random.default_rng(5)
+    L = 40000
+    rows = [np.zeros(L, np.uint8), np.full(L, 255, np.uint8), np.resize(shuffle384, L),
+            rng.integers(0, 256, L, dtype=np.uint8), np.resize(np.arange(256, dtype=np.uint8), L),
+            np.resize(np.frombuffer(b"@" * 7 + b"X", dtype=np.uint8), L)]
+    _compare(cfg_name, np.stack(rows))
