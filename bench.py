@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X literal coder.
+
+Metric (BASELINE.json): MB/s encode+decode per GPU on 64 KiB metablocks, bit-exact vs the CPU path.
+A "step" = one encode pass + one decode pass of the hot path over the whole batch of independent
+64 KiB streams (configs[1]: 65 536 streams, stride-1 / context-map-off = reference TestSimple), inputs
+resident in HBM.  value = N * 65536 bytes * n_gpus / (t_enc + t_dec) in MB/s (10^6 B/s), whole job.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--config simple|mixing]
+Multi-GPU: one process per GPU (torch.distributed.run); streams are sharded by rank, no data-path
+collective (every stream is independent), weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_device_blocks(torch, workload, corpus, first, count, block_len, device, chunk=2048):
+    out = torch.empty((count, block_len), dtype=torch.uint8, device=device)
+    for c0 in range(0, count, chunk):
+        c1 = min(count, c0 + chunk)
+        blk = workload.make_blocks(corpus, first + c0, c1 - c0, block_len=block_len)
+        out[c0:c1].copy_(torch.from_numpy(blk), non_blocking=False)
+    return out
+
+
+def cpu_baseline(cfg_name, workload, corpus, block_len, seconds_target=15.0):
+    """The C oracle ("port" of the reference CPU path) timed on this box's host cores, one independent
+    stream per worker thread, on a bounded sample of the same workload."""
+    import ctypes
+    import numpy as np
+    import pyoracle as po
+    try:
+        lib = po.lib(native=True)
+    except Exception:
+        lib = po.lib()
+    cfg = po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
+    cores = os.cpu_count() or 1
+    # ~5 MB/s/core encode+decode: size the sample for roughly seconds_target of wall time
+    per_core = max(4, int(seconds_target * 5e6 / block_len))
+    n = min(cores * per_core, 8192)
+    blocks = workload.make_blocks(corpus, 0, n, block_len=block_len)
+    enc = ctypes.c_double(0); dec = ctypes.c_double(0); coded = ctypes.c_uint64(0)
+    t0 = time.time()
+    rc = lib.orc_lit_batch_roundtrip(ctypes.byref(cfg), blocks.ctypes.data, n, block_len, cores,
+                                     ctypes.byref(enc), ctypes.byref(dec), ctypes.byref(coded))
+    wall = time.time() - t0
+    assert rc == 0, "oracle round trip failed"
+    total = n * block_len
+    return {
+        "value": round(total / 1e6 / (enc.value + dec.value), 2), "unit": "MB/s", "cores": cores, "kind": "port",
+        "sample": f"{n} x {block_len} B streams of the same workload, {cores} threads (1 stream/thread), "
+                  f"enc {enc.value:.2f}s + dec {dec.value:.2f}s busiest-thread time, wall {wall:.1f}s",
+        "encode_MBps": round(total / 1e6 / enc.value, 2), "decode_MBps": round(total / 1e6 / dec.value, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=65536, help="independent 64 KiB streams per GPU")
+    ap.add_argument("--block-len", type=int, default=65536)
+    ap.add_argument("--config", choices=["simple", "mixing"], default="simple")
+    ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--diag-data", choices=["corpus", "zeros"], default="corpus",
+                    help="diagnostics only: 'zeros' touches two CDF rows per stream (cache-resident ceiling)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import divans_amd as da
+    import workload
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    N, L = args.streams, args.block_len
+    corpus = workload.load_corpus()
+    if args.diag_data == "zeros":
+        d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev)
+    else:
+        d_in = make_device_blocks(torch, workload, corpus, rank * N, N, L, dev)   # rank r owns blocks [r*N, (r+1)*N)
+    cfg = da.config_simple() if args.config == "simple" else da.config_context_mixing()
+    codec = da.LiteralCodec(cfg, L, device=local_rank)
+    if args.blocks_per_cu:
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        codec.set_geometry(max(1, int(cus * args.blocks_per_cu)))
+    outs = codec.alloc_encode_outputs(N, L)
+    d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    enc_ms, dec_ms, model_ms, rans_ms, dkern_ms = [], [], [], [], []
+
+    def step(record):
+        # the codec launches on torch's current stream, so these events bracket its kernels
+        ev[0].record()
+        codec.encode_batch(d_in, N, L, outs)
+        ev[1].record()
+        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
+        ev[2].record()
+        if record:
+            torch.cuda.synchronize()
+            enc_ms.append(ev[0].elapsed_time(ev[1])); dec_ms.append(ev[1].elapsed_time(ev[2]))
+            inf = codec.info()   # hipEvent timings taken inside the C ABI around each kernel launch
+            model_ms.append(inf.last_model_ms); rans_ms.append(inf.last_rans_ms); dkern_ms.append(inf.last_decode_ms)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sizes = outs["sizes"].to(torch.int64)
+    coded_total = int(sizes.sum().item())
+    ok = True
+    if not args.no_verify:
+        ok = bool(torch.equal(d_back, d_in))
+        # bit-exactness of the coded streams against the CPU oracle on a spread of streams (outside the timed region)
+        import pyoracle as po
+        ocfg = po.config_simple() if args.config == "simple" else po.config_context_mixing()
+        offs = outs["offsets"].cpu().numpy(); sz = outs["sizes"].cpu().numpy()
+        for i in sorted(set([0, N // 2, N - 1] + list(range(0, N, max(1, N // 8))))):
+            ref = po.lit_encode(ocfg, d_in[i].cpu().numpy())
+            got = outs["out"][int(offs[i]):int(offs[i]) + int(sz[i])].cpu().numpy()
+            ok = ok and got.size == ref.size and bool((got == ref).all())
+    if world > 1:
+        t = torch.tensor([coded_total, int(ok)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        coded_all, ok_all = int(t[0].item()), int(t[1].item()) == world
+    else:
+        coded_all, ok_all = coded_total, ok
+
+    if rank == 0:
+        K = args.steps
+        ms_per_step = elapsed * 1e3 / K
+        total_bytes = N * L * world
+        value = total_bytes / 1e6 / (elapsed / K)
+        avg = lambda xs: sum(xs) / max(len(xs), 1)
+        # dominant kernel: the one with the largest average launch duration
+        kern = {"lit_decode_kernel": avg(dkern_ms), "lit_model_encode_kernel": avg(model_ms), "rans_encode_kernel": avg(rans_ms)}
+        dom = max(kern, key=kern.get)
+        raw, coded = N * L, coded_total
+        # algorithmic bytes per launch: decode reads C + writes raw; the model pass reads raw and
+        # hands 4 B per nibble to the rANS pass; the rANS pass reads that spill and writes C
+        alg = {"lit_decode_kernel": raw + coded, "lit_model_encode_kernel": raw + 8 * raw, "rans_encode_kernel": 8 * raw + coded}[dom]
+        achieved = alg / 1e9 / (kern[dom] / 1e3)
+        line = {
+            "metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU",
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16/u64 integer", "data": "synthetic",
+            "config": {"workload": f"{N} independent {L} B streams per GPU cut from alice29||asyoulik (stride 4099, 1% xorshift64* "
+                                   f"perturbation); {'TestSimple: stride 1, context map off (BASELINE configs[1])' if args.config == 'simple' else 'TestContextMixing: context map + dynamic_context_mixing=2 (BASELINE configs[2])'}",
+                       "streams_per_gpu": N, "block_bytes": L, "sharding": "streams split by rank, no collective"},
+            "bit_exact": bool(ok_all),
+            "compressed_ratio": round(coded_all / float(total_bytes), 4),
+            "encode_MBps": round(N * L / 1e6 / (avg(enc_ms) / 1e3), 2), "decode_MBps": round(N * L / 1e6 / (avg(dec_ms) / 1e3), 2),
+            "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, workload, corpus, L)
+        print(json.dumps(line))
+        if not ok_all:
+            sys.exit("bench: GPU output is NOT bit-exact / round-trip failed")
+    codec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,26 +114,38 @@ static int derive_geometry(const divans_lit_config& cfg, LitGeometry& g, std::ve
     for (int i = 0; i < 4; ++i) {
         const divans_speed s = cfg.literal_adaptation[i];
         // probability/interface.rs:341-365 debug_asserts inc,lim <= 0x4000; the kernels additionally rely on
-        // lim+inc staying inside i16 so a CDF total never wraps negative
-        if (s.inc < 0 || s.lim <= 0 || s.inc > 0x4000 || s.lim > 0x4000 || (int)s.inc + (int)s.lim > 0x7fff)
+        // lim+inc+16 staying inside i16 so neither the count nor the renormalisation bias can wrap (blend_row)
+        if (s.inc < 0 || s.lim <= 0 || s.inc > 0x4000 || s.lim > 0x4000 || (int)s.inc + (int)s.lim + 16 > 0x7fff)
             return fail(DIVANS_GPU_EINVAL, "literal_adaptation speed outside the supported range");
     }
     blob.assign(LIT_BLOB_BYTES, 0);
-    make_luts(cfg.prediction_mode, &blob[LIT_BLOB_LUT0], &blob[LIT_BLOB_LUT1]);
+    uint8_t lut0[256], lut1[256];
+    make_luts(cfg.prediction_mode, lut0, lut1);
     const uint8_t* cmap64 = cfg.literal_context_map + 64u * cfg.btype;  // literal.rs:114 cmap_index = sel + (btype << 6)
-    std::memcpy(&blob[LIT_BLOB_CMAP], cmap64, 64);
     std::memcpy(&blob[LIT_BLOB_MIX], cfg.mixing_mask, DIVANS_GPU_NUM_MIXING_VALUES);
-    // which selected-context values can occur: lut0 | lut1 (both < 64 by construction)
-    bool sel_seen[64] = {false};
-    for (int a = 0; a < 256; ++a) for (int b = 0; b < 256; ++b) sel_seen[(blob[LIT_BLOB_LUT0 + a] | blob[LIT_BLOB_LUT1 + b]) & 63] = true;
+    // lut1 takes at most 8 distinct values (SIGN: 0..7, UTF8: 0..3, MSB6/LSB6: 0): class them so the kernel
+    // can fold lut0 | lut1 | context map into one LDS read keyed by (prev, class(prev_prev))
+    int class_of_value[256]; std::memset(class_of_value, -1, sizeof(class_of_value));
+    uint8_t class_value[8] = {0}; int nclass = 0;
+    for (int b = 0; b < 256; ++b) {
+        if (class_of_value[lut1[b]] < 0) {
+            if (nclass == 8) return fail(DIVANS_GPU_EINVAL, "literal_lut1 has more than 8 distinct values");
+            class_value[nclass] = lut1[b]; class_of_value[lut1[b]] = nclass++;
+        }
+        blob[LIT_BLOB_LUT1CLASS + b] = (uint8_t)class_of_value[lut1[b]];
+    }
     bool ctx_seen[256] = {false};
     uint32_t maxctx = 0; int first = -1; bool constant = true;
-    for (int s = 0; s < 64; ++s) {
-        if (!sel_seen[s]) continue;
-        const uint8_t c = cmap64[s];
-        ctx_seen[c] = true;
-        maxctx = std::max<uint32_t>(maxctx, c);
-        if (first < 0) first = c; else if (c != first) constant = false;
+    for (int prev = 0; prev < 256; ++prev) {
+        for (int k = 0; k < 8; ++k) {
+            const uint8_t sel = (uint8_t)((lut0[prev] | class_value[k < nclass ? k : 0]) & 63);
+            const uint8_t c = cmap64[sel];
+            blob[LIT_BLOB_CTXF + prev * 8 + k] = c;
+            if (k >= nclass) continue;
+            ctx_seen[c] = true;
+            maxctx = std::max<uint32_t>(maxctx, c);
+            if (first < 0) first = c; else if (c != first) constant = false;
+        }
     }
     std::memset(&g, 0, sizeof(g));
     g.nctx = maxctx + 1;

@@ -10,11 +10,10 @@ constexpr int LIT_THREADS = 256;    // 4 waves = 16 streams per workgroup
 constexpr int RANS_THREADS = 64;    // one wave, one lane per stream
 
 // per-batch constant tables staged in LDS by every workgroup
-constexpr uint32_t LIT_BLOB_LUT0 = 0;       // literal_lut0[256]   codec/interface.rs:199-222
-constexpr uint32_t LIT_BLOB_LUT1 = 256;     // literal_lut1[256]   codec/interface.rs:223-238
-constexpr uint32_t LIT_BLOB_CMAP = 512;     // literal_context_map[btype*64 .. +64]
-constexpr uint32_t LIT_BLOB_MIX = 576;      // mixing_mask[8192]
-constexpr uint32_t LIT_BLOB_BYTES = 576 + 8192;
+constexpr uint32_t LIT_BLOB_LUT1CLASS = 0;  // class (<8) of literal_lut1[b]: index of its value among the distinct lut1 values
+constexpr uint32_t LIT_BLOB_CTXF = 256;     // [prev][class]: literal_context_map[(lut0[prev] | lut1 value) + 64*btype], literal.rs:97-115
+constexpr uint32_t LIT_BLOB_MIX = 256 + 2048;  // mixing_mask[8192]
+constexpr uint32_t LIT_BLOB_BYTES = 256 + 2048 + 8192;
 
 // How the (3 x 256 x 256) prior cube of LiteralNibblePriors (codec/priors.rs:35-37) is compacted for
 // one configuration: only the planes / context columns the configuration can reach are materialised.

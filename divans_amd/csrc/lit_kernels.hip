@@ -3,7 +3,9 @@
 // Mapping: one 16-lane DPP row owns one stream; lane i of the row holds cdf[i] of
 // the CDF row being coded, so blend / search / start-freq are one VALU op per step for all 16
 // entries, and the stream's scalar state (rANS states, context bytes, weights) is replicated
-// across the 16 lanes.  Four streams share a wave64, sixteen a 256-thread workgroup.
+// across the 16 lanes.  Four streams share a wave64, sixteen a 256-thread workgroup.  Each stream's
+// CDF rows live in an HBM table private to its row of lanes (L2 / Infinity-Cache resident while the
+// stream is in flight) and are reached with buffer_load/store_short through one per-workgroup SRD.
 //
 // What each device function restates (paths relative to the reference tree):
 //   exact_div            probability/numeric.rs:25-31 (any exact division is bit-compatible, make_div_lut.rs:37-39)
@@ -13,8 +15,13 @@
 //   average_rows         probability/frequentist_cdf.rs:58-72
 //   weights_update       codec/weights.rs:23-133
 //   select_rows          codec/literal.rs:154-259 (index math of code_nibble)
-//   decode_step          ans.rs:225-252 (get_nibble + helper_advance_sym), refill ans.rs:428-442
+//   decode_nibble        ans.rs:225-252 (get_nibble + helper_advance_sym), refill ans.rs:428-442
 //   rans_encode_kernel   ans.rs:302-378 (reverse_put_sym / flush_chunk)
+//
+// Template parameters specialise the per-nibble index math at compile time:
+//   MM   : the mixing value when the whole reachable mixing_mask is uniform (0..8), or -1 = look it up
+//   CTXC : the context map is constant (context = geom.ctx_const), else context comes from the LDS tables
+//   MIX  : CodecTraits::MIXING_PRIORS (specializations.rs:27-36)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,6 +31,8 @@ namespace divans_hip {
 
 #define DPP_ROW_SHR1 0x111
 #define DPP_ROW_BCAST(n) (0x150 + (n))
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // value of lane `n` of this 16-lane row, broadcast to the whole row (v_mov_b32_dpp row_newbcast)
 template <int N>
@@ -38,73 +47,80 @@ __device__ __forceinline__ int row_prev_or_zero(int v) {
 __device__ __forceinline__ int row_gather(int v, int row_base_lane, int idx) {
     return __builtin_amdgcn_ds_bpermute((row_base_lane + idx) << 2, v);
 }
-__device__ __forceinline__ int sext16(int v) { return (int)(short)v; }
 
 // floor(n / d) for 0 <= n < 2^31, 1 <= d < 2^15, given rcp ~= 1/d (v_rcp_f32, 1 ulp).
 // The float estimate is within 2^-6 of the true quotient, so one step of correction makes it exact.
 __device__ __forceinline__ uint32_t exact_div(uint32_t n, uint32_t d, float rcp) {
     uint32_t q = (uint32_t)((float)n * rcp);
     int32_t r = (int32_t)(n - q * d);
-    if (r < 0) { q -= 1; }
-    else if (r >= (int32_t)d) { q += 1; }
+    q = r < 0 ? q - 1u : q;
+    q = r >= (int32_t)d ? q + 1u : q;
     return q;
 }
+
+// Per-row view of the stream's CDF table: SRD of the workgroup's table slab + this lane's byte offset.
+struct Table {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t lane_off;   // row-of-lanes slab offset + 2 * lane-in-row
+    __device__ __forceinline__ int load(uint32_t row) const {
+        return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, 0);
+    }
+    __device__ __forceinline__ void store(uint32_t row, int v) const {
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, rsrc, lane_off + (row << 5), 0, 0);
+    }
+};
 
 struct RowSel {
     uint32_t stride_row;   // row index inside the stream's table
     uint32_t cm_row;       // context-map row (mixing only)
-    bool use_default;      // mm_opts == 2: code with a fresh default CDF, never blend (non-mixing path)
-    bool no_blend;         // mm_opts == 2: stride row is not blended
+    bool is_default;       // mm_opts == 2: code with a fresh default CDF / never blend the stride row
 };
 
 // codec/literal.rs:176-208.  All inputs are row-uniform.
-template <bool HIGH>
-__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* __restrict__ lds_mix,
-                                              uint32_t ctx, uint32_t prev_byte, uint64_t last8, uint32_t hi_nib) {
-    uint32_t mm_index = ctx | (HIGH ? ((prev_byte >> 4) << 8) : (((hi_nib & 0xf) << 8) | 4096));
-    uint32_t mm_opts = g.mm_uniform >= 0 ? (uint32_t)g.mm_uniform : (uint32_t)lds_mix[mm_index];
-    uint32_t fast_cm = (mm_opts != 3) ? 0xffu : 0u;
-    uint32_t mm = (mm_opts != 0 && mm_opts != 3) ? 0xffu : 0u;
-    uint32_t opt1 = (mm_opts == 1) ? 0xfu : 0u;
+template <bool HIGH, int MM>
+__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* lds, uint32_t ctx, uint64_t last8, uint32_t hi_nib) {
+    const uint32_t prev_byte = (uint32_t)(last8 >> 56);
+    uint32_t mm_opts;
+    if (MM >= 0) mm_opts = (uint32_t)MM;
+    else mm_opts = lds[LIT_BLOB_MIX + (ctx | (HIGH ? ((prev_byte >> 4) << 8) : ((hi_nib << 8) | 4096u)))];
+    const uint32_t fast_cm = (mm_opts != 3) ? 0xffu : 0u;
+    const uint32_t mm = (mm_opts != 0 && mm_opts != 3) ? 0xffu : 0u;
+    const uint32_t opt1 = (mm_opts == 1) ? 0xfu : 0u;
     uint32_t stride_offset = 0;
     if (mm_opts >= 4) { uint32_t x = mm_opts ^ 4u; stride_offset = (x < 7u ? x : 7u) << 3; }
-    uint32_t sb = (uint32_t)(last8 >> (56 - stride_offset)) & 0xffu;
+    const uint32_t sb = (uint32_t)(last8 >> (56 - stride_offset)) & 0xffu;
     uint32_t b, c, width;
     if (HIGH) { b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx; }
     else { b = ((mm & sb) | (~mm & ctx)) & 0xffu; c = (hi_nib & fast_cm) | ((ctx & opt1) << 4); width = g.low_width; }
-    uint32_t t = (mm >> 7) ^ (opt1 >> 2);
-    uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);
+    const uint32_t t = (mm >> 7) ^ (opt1 >> 2);
+    const uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);
     RowSel r;
     r.stride_row = (HIGH ? 0u : g.low_base) + (plane * 256u + b) * width + c;
     r.cm_row = g.cm_base + (HIGH ? ctx : g.nctx + hi_nib + 16u * ctx);
-    r.use_default = mm_opts == 2;
-    r.no_blend = mm_opts == 2;
+    r.is_default = mm_opts == 2;
     return r;
 }
 
-// frequentist_cdf.rs:74-85 on one entry per lane (li = lane index in row)
+// frequentist_cdf.rs:74-85 on one entry per lane (li = lane index in row).  The host rejects speeds with
+// inc + lim + 16 > 0x7fff, so no i16 wrap can occur and plain 32-bit arithmetic is exact.
 __device__ __forceinline__ int blend_row(int c, int li, int sym, int inc, int lim) {
-    c = (li >= sym) ? sext16(c + inc) : c;
+    c = (li >= sym) ? c + inc : c;
     int c15 = row_bcast<15>(c);
-    if (c15 >= lim) {
-        int t = sext16(c + li + 1);
-        c = sext16(t - (t >> 2));
-    }
-    return c;
+    int t = c + li + 1;
+    int renorm = t - (t >> 2);
+    return c15 >= lim ? renorm : c;
 }
 
 // frequentist_cdf.rs:58-72: self = cm row, other = stride row
-__device__ __forceinline__ int average_rows(int cm, int st, int mix_rate) {
-    int ourmax = row_bcast<15>(cm);
-    int othermax = row_bcast<15>(st);
-    uint32_t prod = (uint32_t)(ourmax * othermax);
+__device__ __forceinline__ int average_rows(int cm, int st, int cmax, int smax, int mix_rate) {
+    uint32_t prod = (uint32_t)(cmax * smax);
     int lz = __clz((int)prod);
     lz = lz > 17 ? 17 : lz;
     int sh = 17 - lz;
     int inv = (1 << 15) - mix_rate;
-    int rs = (cm * othermax) >> sh;
-    int ro = (st * ourmax) >> sh;
-    return sext16((int)((uint32_t)rs * (uint32_t)mix_rate + (uint32_t)ro * (uint32_t)inv + 1u) >> 15);
+    int rs = (cm * smax) >> sh;
+    int ro = (st * cmax) >> sh;
+    return (int)((uint32_t)rs * (uint32_t)mix_rate + (uint32_t)ro * (uint32_t)inv + 1u) >> 15;
 }
 
 struct Weights { int w0, w1; int norm; };  // weights.rs:4-8 (norm = normalized_weight as u16)
@@ -139,7 +155,8 @@ __device__ __forceinline__ void weights_update(Weights& w, int p_cm, int p_strid
     shift = shift < 0 ? 0 : shift;
     uint32_t t8 = (uint32_t)(total >> shift) & 0xffu;
     uint32_t num = ((uint32_t)(n0 >> shift) << 8) & 0xffffu;
-    uint32_t q = t8 ? num / t8 : 0u;   // fast_divide_16bit_by_8bit == exact '/' (make_div_lut.rs:11-23); RECIPROCAL8[0]==0
+    // fast_divide_16bit_by_8bit == exact '/' (make_div_lut.rs:11-23); RECIPROCAL8[0] == 0
+    uint32_t q = t8 ? exact_div(num, t8, __builtin_amdgcn_rcpf((float)t8)) : 0u;
     w.norm = (int)((q << 7) & 0xffffu);
 }
 
@@ -151,101 +168,112 @@ __device__ __forceinline__ void load_config_to_lds(uint8_t* lds, const uint8_t* 
 }
 
 // Fill this stream's table with default rows (ffi/alloc_util.rs:77-79: allocations are default-initialised).
-__device__ __forceinline__ void init_table(int16_t* tbl, uint32_t rows, int li) {
+__device__ __forceinline__ void init_table(const Table& t, uint32_t rows, int li) {
     // row = 16 x i16 = two 16-byte halves; even lanes write the first half, odd lanes the second
-    uint4 lo, hi;
-    lo.x = 4u | (8u << 16); lo.y = 12u | (16u << 16); lo.z = 20u | (24u << 16); lo.w = 28u | (32u << 16);
-    hi.x = 36u | (40u << 16); hi.y = 44u | (48u << 16); hi.z = 52u | (56u << 16); hi.w = 60u | (64u << 16);
-    uint4 v = (li & 1) ? hi : lo;
-    uint4* p = (uint4*)tbl;
-    for (uint32_t i = (uint32_t)li; i < rows * 2u; i += 16u) p[i] = v;
+    u32x4 lo = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
+    u32x4 hi = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
+    u32x4 v = (li & 1) ? hi : lo;
+    const uint32_t base = t.lane_off - 2u * (uint32_t)li + 16u * (uint32_t)li;
+    for (uint32_t i = 0; i < rows * 32u; i += 256u) {
+        if (i + 16u * (uint32_t)li < rows * 32u) __builtin_amdgcn_raw_buffer_store_b128(v, t.rsrc, base + i, 0, 0);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the row loads that follow must see the fill
+    __builtin_amdgcn_s_waitcnt(0);  // the row loads that follow must see the fill
 }
 
-__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds, uint64_t last8) {
-    if (g.ctx_const >= 0) return (uint32_t)g.ctx_const;
-    uint32_t prev = (uint32_t)(last8 >> 56), pp = (uint32_t)(last8 >> 48) & 0xffu;
-    uint32_t sel = lds[LIT_BLOB_LUT0 + prev] | lds[LIT_BLOB_LUT1 + pp];
-    return lds[LIT_BLOB_CMAP + (sel & 63u)];
+// Context of the next byte: literal.rs:87-117 with lut0 / lut1 / context map fused on the host into
+// LIT_BLOB_CTXF[prev][lut1 class of prev_prev]; `k1` (that class) is carried over from the previous byte.
+template <bool CTXC>
+__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds, uint32_t prev, uint32_t k1) {
+    if (CTXC) return (uint32_t)g.ctx_const;
+    return lds[LIT_BLOB_CTXF + (prev << 3) + k1];
+}
+
+__device__ __forceinline__ Table make_table(const LitBatch& b, int li) {
+    const uint32_t slab = b.geom.total_rows * 32u;           // bytes of one stream's table
+    Table t;
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab),
+                                               0, (LIT_THREADS / 16) * slab, 0x00020000);
+    t.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
+    return t;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Encode, pass 1: adaptive model.  bytes -> (start | freq << 16) per nibble.
 // ---------------------------------------------------------------------------------------------
-template <bool HIGH, bool MIX>
-__device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const uint8_t* lds, int16_t* tbl, int li, int rbase,
-                                                 uint32_t ctx, uint32_t prev, uint64_t last8, uint32_t hi_nib, int sym,
-                                                 Weights& w) {
-    RowSel rs = select_rows<HIGH>(g, lds + LIT_BLOB_MIX, ctx, prev, last8, hi_nib);
-    int16_t* srow = tbl + (size_t)rs.stride_row * 16u + li;
-    int st = (int)*srow;
+template <bool HIGH, int MM, bool MIX>
+__device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const uint8_t* lds, const Table& tb, int li, int rbase,
+                                                 uint32_t ctx, uint64_t last8, uint32_t hi_nib, int sym, Weights& w) {
+    const RowSel rs = select_rows<HIGH, MM>(g, lds, ctx, last8, hi_nib);
+    int st = tb.load(rs.stride_row);
     uint32_t packed;
     if (MIX) {
-        int16_t* crow = tbl + (size_t)rs.cm_row * 16u + li;
-        int cm = (int)*crow;
-        int p = average_rows(cm, st, w.norm);
-        int pmax = row_bcast<15>(p), cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
+        int cm = tb.load(rs.cm_row);
+        int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
+        int p = average_rows(cm, st, cmax, smax, w.norm);
+        int pmax = row_bcast<15>(p);
         uint32_t dp = exact_div((uint32_t)p << 15, (uint32_t)pmax, __builtin_amdgcn_rcpf((float)pmax));
         uint32_t dc = exact_div((uint32_t)cm << 15, (uint32_t)cmax, __builtin_amdgcn_rcpf((float)cmax));
         uint32_t ds = exact_div((uint32_t)st << 15, (uint32_t)smax, __builtin_amdgcn_rcpf((float)smax));
         int dpp = row_prev_or_zero((int)dp), dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
-        uint32_t sf = ((uint32_t)(dpp + 1) & 0xffffu) | ((uint32_t)((int)dp - dpp - 1) << 16);
+        uint32_t sf = (uint32_t)(dpp + 1) | ((uint32_t)((int)dp - dpp - 1) << 16);
         uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
         packed = (uint32_t)row_gather((int)sf, rbase, sym);
         uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
-        weights_update(w, sext16((int)(freqs & 0xffffu)), sext16((int)(freqs >> 16)), sext16((int)(packed >> 16)));
+        weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)(packed >> 16));
         cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
-        *crow = (int16_t)cm;
+        tb.store(rs.cm_row, cm);
     } else {
-        int cv = rs.use_default ? 4 * (li + 1) : st;
+        int cv = ((MM < 0 || MM == 2) && rs.is_default) ? 4 * (li + 1) : st;
         int mx = row_bcast<15>(cv);
         uint32_t d = exact_div((uint32_t)cv << 15, (uint32_t)mx, __builtin_amdgcn_rcpf((float)mx));
         int dprev = row_prev_or_zero((int)d);
-        uint32_t sf = ((uint32_t)(dprev + 1) & 0xffffu) | ((uint32_t)((int)d - dprev - 1) << 16);
+        uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
         packed = (uint32_t)row_gather((int)sf, rbase, sym);
     }
-    if (!rs.no_blend) {
+    if (!((MM < 0 || MM == 2) && rs.is_default)) {
         st = blend_row(st, li, sym, g.inc0, g.lim0);   // literal_adaptation[0] for both nibbles, literal.rs:320,354
-        *srow = (int16_t)st;
+        tb.store(rs.stride_row, st);
     }
     return packed;
 }
 
-template <bool MIX>
-__global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(LitBatch b) {
+template <int MM, bool CTXC, bool MIX>
+__global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     load_config_to_lds(lds, b.blob);
     const LitGeometry& g = b.geom;
     const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48;
     const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
     const uint32_t G = gridDim.x * (LIT_THREADS / 16);
-    int16_t* tbl = b.tables + (size_t)gg * g.total_rows * 16u;
+    const Table tb = make_table(b, li);
     for (uint32_t s = gg; s < b.n_streams; s += G) {
         const uint8_t* in = b.in + (b.in_offsets ? b.in_offsets[s] : (uint64_t)s * b.stream_len);
         const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
         uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
-        init_table(tbl, g.total_rows, li);
+        init_table(tb, g.total_rows, li);
         Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};  // model_weights[1]=high, [0]=low (literal.rs:230)
         uint64_t last8 = 0;
-        uint32_t pend_a = 0, pend_b = 0;  // lane li keeps the pairs of nibbles 16k+li (hi) / (lo)
+        uint32_t k1 = lds[LIT_BLOB_LUT1CLASS];               // lut1 class of prev_prev = 0
         for (uint32_t base = 0; base < len; base += 16) {
             // each lane fetches one literal byte of the next 16 (coalesced 16-byte read per stream)
-            uint32_t mine = (base + li < len) ? in[base + li] : 0u;
-            uint32_t cnt = len - base < 16u ? len - base : 16u;
+            const uint32_t mine = (base + li < len) ? in[base + li] : 0u;
+            const uint32_t cnt = len - base < 16u ? len - base : 16u;
+            uint32_t pend_a = 0, pend_b = 0;  // lane k keeps the two pairs of byte base+k
             for (uint32_t k = 0; k < cnt; ++k) {
-                uint32_t byte = (uint32_t)row_gather((int)mine, rbase, (int)k);
-                uint32_t prev = (uint32_t)(last8 >> 56);
-                uint32_t ctx = context_of(g, lds, last8);
-                uint32_t hi = byte >> 4, lo = byte & 15u;
-                uint32_t ph = model_nibble<true, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, 0u, (int)hi, wh);
-                uint32_t pl = model_nibble<false, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, hi, (int)lo, wl);
+                const uint32_t byte = (uint32_t)row_gather((int)mine, rbase, (int)k);
+                const uint32_t prev = (uint32_t)(last8 >> 56);
+                const uint32_t ctx = context_of<CTXC>(g, lds, prev, k1);
+                if (!CTXC) k1 = lds[LIT_BLOB_LUT1CLASS + prev];
+                const uint32_t hi = byte >> 4, lo = byte & 15u;
+                const uint32_t ph = model_nibble<true, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, 0u, (int)hi, wh);
+                const uint32_t pl = model_nibble<false, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, hi, (int)lo, wl);
                 last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-                // pairs of byte k go to lane k: nibble 2k -> pend_a, 2k+1 -> pend_b
-                if ((uint32_t)li == k) { pend_a = ph; pend_b = pl; }
+                pend_a = (uint32_t)li == k ? ph : pend_a;
+                pend_b = (uint32_t)li == k ? pl : pend_b;
             }
-            // nibble index of byte (base+li) is 2*(base+li): each lane stores its two 4-byte pairs (8 B, coalesced 128 B per row)
-            if (base + li < len) {
+            // nibble index of byte (base+li) is 2*(base+li): each lane stores its two pairs (8 B; 128 B coalesced per row)
+            if ((uint32_t)li < cnt) {
                 uint2 v; v.x = pend_a; v.y = pend_b;
                 *(uint2*)(sf + 2u * (size_t)(base + li)) = v;
             }
@@ -280,7 +308,7 @@ __device__ __forceinline__ uint64_t rans_put(uint64_t state, uint32_t start, uin
     return (q << 15) + (uint64_t)r3 + (uint64_t)start;
 }
 
-__global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(RansBatch b) {
+__global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBatch b) {
     const uint32_t s = blockIdx.x * RANS_THREADS + threadIdx.x;
     if (s >= b.n_streams) return;
     const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
@@ -328,64 +356,59 @@ struct WordWindow {        // 16 upcoming 32-bit words of the coded stream, one 
     }
 };
 
-template <bool HIGH, bool MIX>
-__device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const uint8_t* lds, int16_t* tbl, int li, int rbase,
-                                                  uint32_t ctx, uint32_t prev, uint64_t last8, uint32_t hi_nib,
-                                                  uint64_t& S, Weights& w) {
-    RowSel rs = select_rows<HIGH>(g, lds + LIT_BLOB_MIX, ctx, prev, last8, hi_nib);
-    int16_t* srow = tbl + (size_t)rs.stride_row * 16u + li;
-    int st = (int)*srow;
-    int16_t* crow = nullptr;
-    int cm = 0;
+template <bool HIGH, int MM, bool MIX>
+__device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const uint8_t* lds, const Table& tb, int li, int rbase,
+                                                  uint32_t ctx, uint64_t last8, uint32_t hi_nib, uint64_t& S, Weights& w) {
+    const RowSel rs = select_rows<HIGH, MM>(g, lds, ctx, last8, hi_nib);
+    int st = tb.load(rs.stride_row);
+    int cm = 0, cmax = 0, smax = 0;
     int cv;
     if (MIX) {
-        crow = tbl + (size_t)rs.cm_row * 16u + li;
-        cm = (int)*crow;
-        cv = average_rows(cm, st, w.norm);
+        cm = tb.load(rs.cm_row);
+        cmax = row_bcast<15>(cm); smax = row_bcast<15>(st);
+        cv = average_rows(cm, st, cmax, smax, w.norm);
     } else {
-        cv = rs.use_default ? 4 * (li + 1) : st;
+        cv = ((MM < 0 || MM == 2) && rs.is_default) ? 4 * (li + 1) : st;
     }
     // cdf_offset_to_sym_start_and_freq: first i<15 with rescaled < cdf[i]
-    uint32_t slot = (uint32_t)S & 0x7fffu;
-    int mx = row_bcast<15>(cv);
-    int rescaled = sext16((int)((slot * (uint32_t)mx) >> 15));
-    unsigned long long ge = __ballot(rescaled >= cv);
-    int sym = __popc((uint32_t)(ge >> rbase) & 0x7fffu);
-    uint32_t d = exact_div((uint32_t)cv << 15, (uint32_t)mx, __builtin_amdgcn_rcpf((float)mx));
-    int dprev = row_prev_or_zero((int)d);
-    uint32_t sf = ((uint32_t)(dprev + 1) & 0xffffu) | ((uint32_t)((int)d - dprev - 1) << 16);
-    uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
-    int64_t start = (int64_t)sext16((int)(packed & 0xffffu));
-    int64_t freq = (int64_t)sext16((int)(packed >> 16));
+    const uint32_t slot = (uint32_t)S & 0x7fffu;
+    const int mx = row_bcast<15>(cv);
+    const int rescaled = (int)((slot * (uint32_t)mx) >> 15);
+    const unsigned long long ge = __ballot(rescaled >= cv);
+    const int sym = __popc((uint32_t)(ge >> rbase) & 0x7fffu);
+    const uint32_t d = exact_div((uint32_t)cv << 15, (uint32_t)mx, __builtin_amdgcn_rcpf((float)mx));
+    const int dprev = row_prev_or_zero((int)d);
+    const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
+    const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
+    const uint32_t start = packed & 0xffffu, freq = packed >> 16;
     // helper_advance_sym ans.rs:238: x = freq * (state >> 15) + (state & mask) - start
     S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;
     if (MIX) {
-        int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
         uint32_t dc = exact_div((uint32_t)cm << 15, (uint32_t)cmax, __builtin_amdgcn_rcpf((float)cmax));
         uint32_t ds = exact_div((uint32_t)st << 15, (uint32_t)smax, __builtin_amdgcn_rcpf((float)smax));
         int dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
         uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
         uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
-        weights_update(w, sext16((int)(freqs & 0xffffu)), sext16((int)(freqs >> 16)), (int)freq);
+        weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)freq);
         cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
-        *crow = (int16_t)cm;
+        tb.store(rs.cm_row, cm);
     }
-    if (!rs.no_blend) {
+    if (!((MM < 0 || MM == 2) && rs.is_default)) {
         st = blend_row(st, li, sym, g.inc0, g.lim0);
-        *srow = (int16_t)st;
+        tb.store(rs.stride_row, st);
     }
     return (uint32_t)sym;
 }
 
-template <bool MIX>
-__global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(LitBatch b) {
+template <int MM, bool CTXC, bool MIX>
+__global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     load_config_to_lds(lds, b.blob);
     const LitGeometry& g = b.geom;
     const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48;
     const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
     const uint32_t G = gridDim.x * (LIT_THREADS / 16);
-    int16_t* tbl = b.tables + (size_t)gg * g.total_rows * 16u;
+    const Table tb = make_table(b, li);
     for (uint32_t s = gg; s < b.n_streams; s += G) {
         const uint32_t len = b.out_sizes ? b.out_sizes[s] : b.stream_len;
         uint8_t* out = b.out + (b.out_offsets ? b.out_offsets[s] : (uint64_t)s * b.stream_len);
@@ -394,31 +417,36 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(LitBatch b) {
         ww.nwords = b.in_sizes[s] >> 2;
         ww.pos = 0;
         ww.reload(li);
-        init_table(tbl, g.total_rows, li);
+        init_table(tb, g.total_rows, li);
         Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};
         uint64_t last8 = 0;
+        uint32_t k1 = lds[LIT_BLOB_LUT1CLASS];
         uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
-        uint32_t outb = 0;
-        for (uint32_t i = 0; i < len; ++i) {
-            if ((i & 32767u) == 0u) {
-                // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
+        for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
+            // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
+            {
                 uint32_t a0 = ww.next(li, rbase), a1 = ww.next(li, rbase), b0 = ww.next(li, rbase), b1 = ww.next(li, rbase);
                 SA = ((uint64_t)a1 << 32) | a0;
                 SB = ((uint64_t)b1 << 32) | b0;
             }
-            uint32_t prev = (uint32_t)(last8 >> 56);
-            uint32_t ctx = context_of(g, lds, last8);
-            // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
-            if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
-            uint32_t hi = decode_nibble<true, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, 0u, SA, wh);
-            if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
-            uint32_t lo = decode_nibble<false, MIX>(g, lds, tbl, li, rbase, ctx, prev, last8, hi, SB, wl);
-            uint32_t byte = (hi << 4) | lo;
-            last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-            if ((uint32_t)li == (i & 15u)) outb = byte;
-            if ((i & 15u) == 15u || i + 1 == len) {
-                uint32_t basei = i & ~15u;
-                if (basei + li <= i) out[basei + li] = (uint8_t)outb;
+            const uint32_t cend = cbeg + 32768u < len ? cbeg + 32768u : len;
+            for (uint32_t base = cbeg; base < cend; base += 16u) {
+                const uint32_t cnt = cend - base < 16u ? cend - base : 16u;
+                uint32_t outb = 0;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t prev = (uint32_t)(last8 >> 56);
+                    const uint32_t ctx = context_of<CTXC>(g, lds, prev, k1);
+                    if (!CTXC) k1 = lds[LIT_BLOB_LUT1CLASS + prev];
+                    // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
+                    if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
+                    const uint32_t hi = decode_nibble<true, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, 0u, SA, wh);
+                    if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
+                    const uint32_t lo = decode_nibble<false, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, hi, SB, wl);
+                    const uint32_t byte = (hi << 4) | lo;
+                    last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                    outb = (uint32_t)li == k ? byte : outb;
+                }
+                if ((uint32_t)li < cnt) out[base + li] = (uint8_t)outb;
             }
         }
     }
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(const uint32_t* sizes,
     __shared__ uint64_t partial[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t beg = t * per, end = beg + per < n ? beg + per : n;
+    const uint32_t beg = t * per < n ? t * per : n, end = beg + per < n ? beg + per : n;
     uint64_t sum = 0;
     for (uint32_t i = beg; i < end; ++i) sum += (sizes[i] + 3u) & ~3u;
     partial[t] = sum;
@@ -483,9 +511,26 @@ __global__ void selftest_division_kernel(unsigned long long* mismatches) {
 // ---------------------------------------------------------------------------------------------
 // launch helpers (called from capi.cpp)
 // ---------------------------------------------------------------------------------------------
+typedef void (*LitKernel)(const LitBatch);
+
+#define LIT_PICK(KERNEL)                                                                                     \
+    static LitKernel pick_##KERNEL(int mm, bool ctxc, bool mix) {                                            \
+        const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 4 + (ctxc ? 2 : 0) + (mix ? 1 : 0);              \
+        switch (key) {                                                                                       \
+        case 0: return KERNEL<-1, false, false>; case 1: return KERNEL<-1, false, true>;                     \
+        case 2: return KERNEL<-1, true, false>;  case 3: return KERNEL<-1, true, true>;                      \
+        case 4: return KERNEL<0, false, false>;  case 5: return KERNEL<0, false, true>;                      \
+        case 6: return KERNEL<0, true, false>;   case 7: return KERNEL<0, true, true>;                       \
+        case 8: return KERNEL<4, false, false>;  case 9: return KERNEL<4, false, true>;                      \
+        case 10: return KERNEL<4, true, false>;  default: return KERNEL<4, true, true>;                      \
+        }                                                                                                    \
+    }
+LIT_PICK(lit_model_encode_kernel)
+LIT_PICK(lit_decode_kernel)
+
 hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
-    if (mix) hipLaunchKernelGGL(lit_model_encode_kernel<true>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
-    else hipLaunchKernelGGL(lit_model_encode_kernel<false>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+    LitKernel k = pick_lit_model_encode_kernel(b.geom.mm_uniform, b.geom.ctx_const >= 0, mix);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
     return hipGetLastError();
 }
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
@@ -494,8 +539,8 @@ hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
-    if (mix) hipLaunchKernelGGL(lit_decode_kernel<true>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
-    else hipLaunchKernelGGL(lit_decode_kernel<false>, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+    LitKernel k = pick_lit_decode_kernel(b.geom.mm_uniform, b.geom.ctx_const >= 0, mix);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
     return hipGetLastError();
 }
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,

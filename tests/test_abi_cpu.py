@@ -1,0 +1,59 @@
+"""CPU-side checks of the C ABI: the in-tree library loads and exports every symbol include/divans_gpu.h declares,
+and refuses to compute without a GPU (no silent CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(divans_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import divans_amd as da
+    da.build_extension()
+    L = da.load_library()
+    declared = _declared("divans_gpu.h")
+    assert set(declared) == set(da.exported_symbols())
+    for sym in declared:
+        assert hasattr(L, sym), sym
+
+
+def test_config_helpers_match_oracle_configs():
+    import divans_amd as da
+    import pyoracle as po
+    for g, o in ((da.config_simple(), po.config_simple()), (da.config_context_mixing(), po.config_context_mixing())):
+        assert bytes(g) == bytes(o)      # same struct layout and contents as the oracle's orc_lit_config
+
+
+def test_no_cpu_fallback():
+    import torch
+    import divans_amd as da
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(da.DivansGpuError):
+        da.LiteralCodec(da.config_simple(), 4096)
+    # and the raw ABI says so too
+    L = da.load_library()
+    h = ctypes.c_void_p()
+    cfg = da.config_simple()
+    rc = L.divans_gpu_codec_create(ctypes.byref(h), ctypes.byref(cfg), 0, None, 4096)
+    assert rc != 0 and b"no HIP device" in L.divans_gpu_last_error()
+
+
+def test_encode_bound_is_monotone_and_sufficient_for_worst_case_model():
+    import divans_amd as da
+    prev = 0
+    for n in (0, 1, 2, 100, 32768, 32769, 65536, 1 << 20):
+        b = da.encode_bound(n)
+        assert b % 16 == 0 and b >= prev
+        nsym = 2 * n
+        chunks = (nsym + 65535) // 65536
+        assert b >= 16 * chunks + 4 * ((15 * nsym + 31) // 32)
+        prev = b
