@@ -73,9 +73,10 @@ def main():
     ap.add_argument("--block-len", type=int, default=65536)
     ap.add_argument("--config", choices=["simple", "mixing"], default="simple")
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
+    ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--diag-data", choices=["corpus", "zeros"], default="corpus",
+    ap.add_argument("--diag-data", choices=["corpus", "zeros", "random", "repeat1k"], default="corpus",
                     help="diagnostics only: 'zeros' touches two CDF rows per stream (cache-resident ceiling)")
     args = ap.parse_args()
 
@@ -98,13 +99,20 @@ def main():
     corpus = workload.load_corpus()
     if args.diag_data == "zeros":
         d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev)
+    elif args.diag_data == "random":
+        d_in = torch.randint(0, 256, (N, L), dtype=torch.uint8, device=dev)
+    elif args.diag_data == "repeat1k":
+        d_in = make_device_blocks(torch, workload, corpus, rank * N, N, L, dev)
+        d_in = d_in[:, :1024].repeat(1, L // 1024).contiguous()
     else:
         d_in = make_device_blocks(torch, workload, corpus, rank * N, N, L, dev)   # rank r owns blocks [r*N, (r+1)*N)
     cfg = da.config_simple() if args.config == "simple" else da.config_context_mixing()
     codec = da.LiteralCodec(cfg, L, device=local_rank)
     if args.blocks_per_cu:
         cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        codec.set_geometry(max(1, int(cus * args.blocks_per_cu)))
+        codec.set_geometry(blocks=max(1, int(cus * args.blocks_per_cu)))
+    if args.cache_rows >= 0:
+        codec.set_geometry(cache_rows=args.cache_rows)
     outs = codec.alloc_encode_outputs(N, L)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
 

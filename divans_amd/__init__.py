@@ -169,8 +169,9 @@ class LiteralCodec:
         except Exception:
             pass
 
-    def set_geometry(self, blocks):
-        _check(self._lib.divans_gpu_codec_set_geometry(self._h, int(blocks), 0), "set_geometry")
+    def set_geometry(self, blocks=0, cache_rows=None):
+        cr = 0xFFFFFFFF if cache_rows is None else int(cache_rows)
+        _check(self._lib.divans_gpu_codec_set_geometry(self._h, int(blocks), cr), "set_geometry")
 
     def info(self):
         i = GpuInfo()

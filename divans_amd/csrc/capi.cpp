@@ -99,6 +99,7 @@ struct divans_gpu_codec {
     uint32_t max_stream_len = 0;
     uint32_t num_cus = 256;
     uint32_t blocks = 0;          // persistent grid of the model/decode kernels
+    uint32_t cache_rows = 0;      // per-stream LDS row cache (0 = tables accessed in HBM/L2 directly)
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
@@ -218,7 +219,8 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->mix = cfg->context_mixing > 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
-    c->blocks = c->num_cus * 2u;  // 8 waves = 32 streams per CU (tuned on MI355X)
+    c->blocks = c->num_cus * 8u;  // 32 waves = 128 streams per CU, 32-row LDS cache each (tuned on MI355X)
+    c->cache_rows = c->geom.total_rows < 0x7fffu ? 32u : 0u;
     if (hipMalloc(&c->d_blob, LIT_BLOB_BYTES) != hipSuccess || hipMalloc(&c->d_status, 64) != hipSuccess) {
         delete c; return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed");
     }
@@ -241,9 +243,14 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     delete c;
 }
 
-extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t threads_per_block) {
+extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t cache_rows) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    if (threads_per_block != 0 && threads_per_block != (uint32_t)LIT_THREADS) return fail(DIVANS_GPU_EINVAL, "threads_per_block is fixed at 256");
+    if (cache_rows != 0xffffffffu) {
+        if (cache_rows != 0 && (cache_rows < 32 || (cache_rows & (cache_rows - 1)) != 0 || cache_rows > 256))
+            return fail(DIVANS_GPU_EINVAL, "cache_rows must be 0 or a power of two in [32, 256]");
+        if (cache_rows && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
+        c->cache_rows = cache_rows;
+    }
     if (blocks) c->blocks = blocks;
     return 0;
 }
@@ -276,6 +283,7 @@ extern "C" int divans_gpu_lit_encode_batch(divans_gpu_codec* c, const uint8_t* d
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
     b.sf = c->d_sf;
+    b.cache_rows = c->cache_rows; b.cache_bytes_per_wg = (LIT_THREADS / 16) * c->cache_rows * 34u;
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -304,6 +312,7 @@ extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes;
+    b.cache_rows = c->cache_rows; b.cache_bytes_per_wg = (LIT_THREADS / 16) * c->cache_rows * 34u;
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));

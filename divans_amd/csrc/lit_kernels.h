@@ -13,6 +13,7 @@ constexpr int RANS_THREADS = 64;    // one wave, one lane per stream
 constexpr uint32_t LIT_BLOB_LUT1CLASS = 0;  // class (<8) of literal_lut1[b]: index of its value among the distinct lut1 values
 constexpr uint32_t LIT_BLOB_CTXF = 256;     // [prev][class]: literal_context_map[(lut0[prev] | lut1 value) + 64*btype], literal.rs:97-115
 constexpr uint32_t LIT_BLOB_MIX = 256 + 2048;  // mixing_mask[8192]
+constexpr uint32_t LIT_BLOB_CTX_BYTES = 256 + 2048;
 constexpr uint32_t LIT_BLOB_BYTES = 256 + 2048 + 8192;
 
 // How the (3 x 256 x 256) prior cube of LiteralNibblePriors (codec/priors.rs:35-37) is compacted for
@@ -38,6 +39,8 @@ struct LitBatch {
     const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
     uint8_t* out; const uint64_t* out_offsets; const uint32_t* out_sizes;
     uint32_t* sf;               // encode only: [n_streams][2*max_stream_len]
+    uint32_t cache_rows;        // rows of the per-stream LDS row cache (power of two >= 32, or 0 = no cache)
+    uint32_t cache_bytes_per_wg;  // 16 * cache_rows * (32 + 2)
 };
 
 struct RansBatch {
@@ -45,6 +48,7 @@ struct RansBatch {
     uint8_t* out; uint64_t out_slot; uint64_t* out_offsets; uint32_t* out_sizes; uint32_t* status;
 };
 
+uint32_t lit_lds_bytes(const LitBatch& b);
 hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st);
 hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);

@@ -58,15 +58,67 @@ __device__ __forceinline__ uint32_t exact_div(uint32_t n, uint32_t d, float rcp)
     return q;
 }
 
-// Per-row view of the stream's CDF table: SRD of the workgroup's table slab + this lane's byte offset.
+// floor((c << 15) / d) for 0 <= c <= d < 2^15 with a reciprocal biased low: `rcp_lo` = rcp(d) * 2^15 * (1 - 2^-20).
+// (float)c is exact, the product's relative error is < 2^-22, so the truncated estimate is q or q-1 (never above)
+// and a single compare finishes it.  Checked exhaustively on the GPU (selftest_division_kernel).
+__device__ __forceinline__ float biased_rcp15(int d) {
+    return __builtin_amdgcn_rcpf((float)d) * (32768.0f * (1.0f - 9.5367431640625e-07f));
+}
+__device__ __forceinline__ uint32_t scaled_div(int c, int d, float rcp_lo) {
+    uint32_t q = (uint32_t)((float)c * rcp_lo);
+    int32_t r = (c << 15) - __mul24((int)q, d);      // q < 2^16, d < 2^15: 24-bit multiply is exact
+    return r >= d ? q + 1u : q;
+}
+
+// Per-row view of the stream's CDF table: SRD of the workgroup's table slab + this lane's byte offset,
+// fronted (CACHE) by a private 2-way set-associative write-back row cache in LDS:
+//   tag word per set = way0 row id (15 bits) | way1 row id << 15 | MRU way << 31, 0x7fff = empty way.
+// Every table access of the coder is a read-modify-write of one whole row, so a cached row is always dirty;
+// a miss writes the victim row back to HBM and fetches the new one.
+struct RowRef { uint32_t row; uint32_t slot_addr; };
+
+template <bool CACHE>
 struct Table {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t lane_off;   // row-of-lanes slab offset + 2 * lane-in-row
-    __device__ __forceinline__ int load(uint32_t row) const {
+    uint8_t* lds;        // workgroup LDS base
+    uint32_t data_off;   // LDS byte offset of this stream's cached rows + 2 * lane-in-row
+    uint32_t tag_off;    // LDS byte offset of this stream's tag words
+    uint32_t set_mask;   // sets - 1
+    __device__ __forceinline__ int gload(uint32_t row) const {
         return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, 0);
     }
-    __device__ __forceinline__ void store(uint32_t row, int v) const {
+    __device__ __forceinline__ void gstore(uint32_t row, int v) const {
         __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, rsrc, lane_off + (row << 5), 0, 0);
+    }
+    __device__ __forceinline__ int load(uint32_t row, RowRef& ref) const {
+        ref.row = row;
+        if (!CACHE) return gload(row);
+        const uint32_t set = (row ^ (row >> 4) ^ (row >> 9)) & set_mask;
+        uint32_t* tagp = (uint32_t*)(lds + tag_off + (set << 2));
+        uint32_t tp = *tagp;
+        const uint32_t t0 = tp & 0x7fffu, t1 = (tp >> 15) & 0x7fffu;
+        const bool h0 = t0 == row, h1 = t1 == row;
+        const uint32_t way = h0 ? 0u : (h1 ? 1u : ((tp >> 31) ^ 1u));
+        ref.slot_addr = data_off + (((set << 1) + way) << 5);
+        int v = (int)*(uint16_t*)(lds + ref.slot_addr);
+        if (!(h0 || h1)) {
+            const uint32_t victim = way ? t1 : t0;
+            if (victim != 0x7fffu) gstore(victim, v);
+            v = gload(row);
+            tp = way ? ((tp & ~(0x7fffu << 15)) | (row << 15)) : ((tp & ~0x7fffu) | row);
+        }
+        *tagp = (tp & 0x7fffffffu) | (way << 31);
+        return v;
+    }
+    __device__ __forceinline__ void store(const RowRef& ref, int v) const {
+        if (CACHE) *(uint16_t*)(lds + ref.slot_addr) = (uint16_t)v;
+        else gstore(ref.row, v);
+    }
+    // start of a stream: every way empty
+    __device__ __forceinline__ void reset_cache(int li) const {
+        if (!CACHE) return;
+        for (uint32_t s = (uint32_t)li; s <= set_mask; s += 16u) *(uint32_t*)(lds + tag_off + (s << 2)) = 0x3fffffffu;
     }
 };
 
@@ -78,11 +130,11 @@ struct RowSel {
 
 // codec/literal.rs:176-208.  All inputs are row-uniform.
 template <bool HIGH, int MM>
-__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* lds, uint32_t ctx, uint64_t last8, uint32_t hi_nib) {
+__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* lds_mix, uint32_t ctx, uint64_t last8, uint32_t hi_nib) {
     const uint32_t prev_byte = (uint32_t)(last8 >> 56);
     uint32_t mm_opts;
     if (MM >= 0) mm_opts = (uint32_t)MM;
-    else mm_opts = lds[LIT_BLOB_MIX + (ctx | (HIGH ? ((prev_byte >> 4) << 8) : ((hi_nib << 8) | 4096u)))];
+    else mm_opts = lds_mix[ctx | (HIGH ? ((prev_byte >> 4) << 8) : ((hi_nib << 8) | 4096u))];
     const uint32_t fast_cm = (mm_opts != 3) ? 0xffu : 0u;
     const uint32_t mm = (mm_opts != 0 && mm_opts != 3) ? 0xffu : 0u;
     const uint32_t opt1 = (mm_opts == 1) ? 0xfu : 0u;
@@ -160,15 +212,32 @@ __device__ __forceinline__ void weights_update(Weights& w, int p_cm, int p_strid
     w.norm = (int)((q << 7) & 0xffffu);
 }
 
-__device__ __forceinline__ void load_config_to_lds(uint8_t* lds, const uint8_t* __restrict__ blob) {
-    const uint32_t* src = (const uint32_t*)blob;
-    uint32_t* dst = (uint32_t*)lds;
-    for (uint32_t i = threadIdx.x; i < LIT_BLOB_BYTES / 4; i += blockDim.x) dst[i] = src[i];
+// LDS layout of a workgroup: [16 x row cache (data, then tags)] [context tables unless CTXC] [mixing_mask if MM < 0]
+struct LdsView { uint8_t* base; const uint8_t* ctx; const uint8_t* mix; };
+
+template <int MM, bool CTXC>
+__device__ __forceinline__ LdsView load_config_to_lds(uint8_t* lds, const LitBatch& b) {
+    LdsView v;
+    v.base = lds;
+    uint8_t* p = lds + b.cache_bytes_per_wg;
+    v.ctx = p;
+    if (!CTXC) {
+        const uint32_t* src = (const uint32_t*)(b.blob + LIT_BLOB_LUT1CLASS);
+        for (uint32_t i = threadIdx.x; i < LIT_BLOB_CTX_BYTES / 4; i += blockDim.x) ((uint32_t*)p)[i] = src[i];
+        p += LIT_BLOB_CTX_BYTES;
+    }
+    v.mix = p;
+    if (MM < 0) {
+        const uint32_t* src = (const uint32_t*)(b.blob + LIT_BLOB_MIX);
+        for (uint32_t i = threadIdx.x; i < 8192 / 4; i += blockDim.x) ((uint32_t*)p)[i] = src[i];
+    }
     __syncthreads();
+    return v;
 }
 
 // Fill this stream's table with default rows (ffi/alloc_util.rs:77-79: allocations are default-initialised).
-__device__ __forceinline__ void init_table(const Table& t, uint32_t rows, int li) {
+template <bool CACHE>
+__device__ __forceinline__ void init_table(const Table<CACHE>& t, uint32_t rows, int li) {
     // row = 16 x i16 = two 16-byte halves; even lanes write the first half, odd lanes the second
     u32x4 lo = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
     u32x4 hi = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
@@ -177,6 +246,7 @@ __device__ __forceinline__ void init_table(const Table& t, uint32_t rows, int li
     for (uint32_t i = 0; i < rows * 32u; i += 256u) {
         if (i + 16u * (uint32_t)li < rows * 32u) __builtin_amdgcn_raw_buffer_store_b128(v, t.rsrc, base + i, 0, 0);
     }
+    t.reset_cache(li);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);  // the row loads that follow must see the fill
 }
@@ -184,37 +254,44 @@ __device__ __forceinline__ void init_table(const Table& t, uint32_t rows, int li
 // Context of the next byte: literal.rs:87-117 with lut0 / lut1 / context map fused on the host into
 // LIT_BLOB_CTXF[prev][lut1 class of prev_prev]; `k1` (that class) is carried over from the previous byte.
 template <bool CTXC>
-__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds, uint32_t prev, uint32_t k1) {
+__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds_ctx, uint32_t prev, uint32_t k1) {
     if (CTXC) return (uint32_t)g.ctx_const;
-    return lds[LIT_BLOB_CTXF + (prev << 3) + k1];
+    return lds_ctx[LIT_BLOB_CTXF + (prev << 3) + k1];
 }
 
-__device__ __forceinline__ Table make_table(const LitBatch& b, int li) {
+template <bool CACHE>
+__device__ __forceinline__ Table<CACHE> make_table(const LitBatch& b, uint8_t* lds, int li) {
     const uint32_t slab = b.geom.total_rows * 32u;           // bytes of one stream's table
-    Table t;
+    Table<CACHE> t;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab),
                                                0, (LIT_THREADS / 16) * slab, 0x00020000);
     t.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
+    t.lds = lds;
+    const uint32_t per_stream = b.cache_rows * 32u + b.cache_rows * 2u;   // rows + one tag word per 2-way set
+    t.data_off = (threadIdx.x >> 4) * per_stream + 2u * (uint32_t)li;
+    t.tag_off = (threadIdx.x >> 4) * per_stream + b.cache_rows * 32u;
+    t.set_mask = (b.cache_rows >> 1) - 1u;
     return t;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Encode, pass 1: adaptive model.  bytes -> (start | freq << 16) per nibble.
 // ---------------------------------------------------------------------------------------------
-template <bool HIGH, int MM, bool MIX>
-__device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const uint8_t* lds, const Table& tb, int li, int rbase,
+template <bool HIGH, int MM, bool MIX, bool CACHE>
+__device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb, int li, int rbase,
                                                  uint32_t ctx, uint64_t last8, uint32_t hi_nib, int sym, Weights& w) {
-    const RowSel rs = select_rows<HIGH, MM>(g, lds, ctx, last8, hi_nib);
-    int st = tb.load(rs.stride_row);
+    const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
+    RowRef sref, cref;
+    int st = tb.load(rs.stride_row, sref);
     uint32_t packed;
     if (MIX) {
-        int cm = tb.load(rs.cm_row);
+        int cm = tb.load(rs.cm_row, cref);
         int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
         int p = average_rows(cm, st, cmax, smax, w.norm);
         int pmax = row_bcast<15>(p);
-        uint32_t dp = exact_div((uint32_t)p << 15, (uint32_t)pmax, __builtin_amdgcn_rcpf((float)pmax));
-        uint32_t dc = exact_div((uint32_t)cm << 15, (uint32_t)cmax, __builtin_amdgcn_rcpf((float)cmax));
-        uint32_t ds = exact_div((uint32_t)st << 15, (uint32_t)smax, __builtin_amdgcn_rcpf((float)smax));
+        uint32_t dp = scaled_div(p, pmax, biased_rcp15(pmax));
+        uint32_t dc = scaled_div(cm, cmax, biased_rcp15(cmax));
+        uint32_t ds = scaled_div(st, smax, biased_rcp15(smax));
         int dpp = row_prev_or_zero((int)dp), dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
         uint32_t sf = (uint32_t)(dpp + 1) | ((uint32_t)((int)dp - dpp - 1) << 16);
         uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
@@ -222,31 +299,29 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const uin
         uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
         weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)(packed >> 16));
         cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
-        tb.store(rs.cm_row, cm);
+        tb.store(cref, cm);
     } else {
         int cv = ((MM < 0 || MM == 2) && rs.is_default) ? 4 * (li + 1) : st;
         int mx = row_bcast<15>(cv);
-        uint32_t d = exact_div((uint32_t)cv << 15, (uint32_t)mx, __builtin_amdgcn_rcpf((float)mx));
+        uint32_t d = scaled_div(cv, mx, biased_rcp15(mx));
         int dprev = row_prev_or_zero((int)d);
         uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
         packed = (uint32_t)row_gather((int)sf, rbase, sym);
     }
-    if (!((MM < 0 || MM == 2) && rs.is_default)) {
-        st = blend_row(st, li, sym, g.inc0, g.lim0);   // literal_adaptation[0] for both nibbles, literal.rs:320,354
-        tb.store(rs.stride_row, st);
-    }
+    if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0);   // literal_adaptation[0] for both nibbles, literal.rs:320,354
+    if (CACHE || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);   // a cached way must hold its row even when it is not blended
     return packed;
 }
 
-template <int MM, bool CTXC, bool MIX>
+template <int MM, bool CTXC, bool MIX, bool CACHE>
 __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    load_config_to_lds(lds, b.blob);
+    const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
     const LitGeometry& g = b.geom;
     const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48;
     const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
     const uint32_t G = gridDim.x * (LIT_THREADS / 16);
-    const Table tb = make_table(b, li);
+    const Table<CACHE> tb = make_table<CACHE>(b, lds, li);
     for (uint32_t s = gg; s < b.n_streams; s += G) {
         const uint8_t* in = b.in + (b.in_offsets ? b.in_offsets[s] : (uint64_t)s * b.stream_len);
         const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
@@ -254,20 +329,21 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
         init_table(tb, g.total_rows, li);
         Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};  // model_weights[1]=high, [0]=low (literal.rs:230)
         uint64_t last8 = 0;
-        uint32_t k1 = lds[LIT_BLOB_LUT1CLASS];               // lut1 class of prev_prev = 0
+        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];   // lut1 class of prev_prev = 0
+        // each lane holds one literal byte of the current and of the next 16-byte window (coalesced reads)
+        uint32_t mine = ((uint32_t)li < len) ? in[li] : 0u;
+        uint32_t nxt = (16u + li < len) ? in[16u + li] : 0u;
         for (uint32_t base = 0; base < len; base += 16) {
-            // each lane fetches one literal byte of the next 16 (coalesced 16-byte read per stream)
-            const uint32_t mine = (base + li < len) ? in[base + li] : 0u;
             const uint32_t cnt = len - base < 16u ? len - base : 16u;
             uint32_t pend_a = 0, pend_b = 0;  // lane k keeps the two pairs of byte base+k
             for (uint32_t k = 0; k < cnt; ++k) {
                 const uint32_t byte = (uint32_t)row_gather((int)mine, rbase, (int)k);
                 const uint32_t prev = (uint32_t)(last8 >> 56);
-                const uint32_t ctx = context_of<CTXC>(g, lds, prev, k1);
-                if (!CTXC) k1 = lds[LIT_BLOB_LUT1CLASS + prev];
+                const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
+                if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                 const uint32_t hi = byte >> 4, lo = byte & 15u;
-                const uint32_t ph = model_nibble<true, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, 0u, (int)hi, wh);
-                const uint32_t pl = model_nibble<false, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, hi, (int)lo, wl);
+                const uint32_t ph = model_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, (int)hi, wh);
+                const uint32_t pl = model_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, (int)lo, wl);
                 last8 = (last8 >> 8) | ((uint64_t)byte << 56);
                 pend_a = (uint32_t)li == k ? ph : pend_a;
                 pend_b = (uint32_t)li == k ? pl : pend_b;
@@ -277,6 +353,8 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
                 uint2 v; v.x = pend_a; v.y = pend_b;
                 *(uint2*)(sf + 2u * (size_t)(base + li)) = v;
             }
+            mine = nxt;
+            nxt = (base + 32u + li < len) ? in[base + 32u + li] : 0u;
         }
     }
 }
@@ -345,26 +423,30 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
 // ---------------------------------------------------------------------------------------------
 // Decode: fused rANS decode + CDF search + blend.
 // ---------------------------------------------------------------------------------------------
-struct WordWindow {        // 16 upcoming 32-bit words of the coded stream, one per lane of the row
-    const uint32_t* in; uint32_t nwords; uint32_t base, pos; uint32_t w;
-    __device__ __forceinline__ void reload(int li) { base = pos; w = (base + li < nwords) ? in[base + li] : 0u; }
+struct WordWindow {
+    // 16 upcoming 32-bit words of the coded stream, one per lane of the row (`w`), plus the 16 after them (`wn`),
+    // requested one window early so that handing a word to the decoder (ds_bpermute on `w`) never waits on memory.
+    const uint32_t* in; uint32_t nwords; uint32_t base, pos; uint32_t w, wn;
+    __device__ __forceinline__ uint32_t fetch(uint32_t first, int li) const { return (first + li < nwords) ? in[first + li] : 0u; }
+    __device__ __forceinline__ void start(int li) { base = 0; pos = 0; w = fetch(0, li); wn = fetch(16, li); }
     __device__ __forceinline__ uint32_t next(int li, int rbase) {
         uint32_t v = (uint32_t)row_gather((int)w, rbase, (int)(pos - base));
         pos += 1;
-        if (pos - base == 16u) reload(li);
+        if (pos - base == 16u) { base = pos; w = wn; wn = fetch(base + 16u, li); }
         return v;
     }
 };
 
-template <bool HIGH, int MM, bool MIX>
-__device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const uint8_t* lds, const Table& tb, int li, int rbase,
+template <bool HIGH, int MM, bool MIX, bool CACHE>
+__device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb, int li, int rbase,
                                                   uint32_t ctx, uint64_t last8, uint32_t hi_nib, uint64_t& S, Weights& w) {
-    const RowSel rs = select_rows<HIGH, MM>(g, lds, ctx, last8, hi_nib);
-    int st = tb.load(rs.stride_row);
+    const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
+    RowRef sref, cref;
+    int st = tb.load(rs.stride_row, sref);
     int cm = 0, cmax = 0, smax = 0;
     int cv;
     if (MIX) {
-        cm = tb.load(rs.cm_row);
+        cm = tb.load(rs.cm_row, cref);
         cmax = row_bcast<15>(cm); smax = row_bcast<15>(st);
         cv = average_rows(cm, st, cmax, smax, w.norm);
     } else {
@@ -373,10 +455,10 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const ui
     // cdf_offset_to_sym_start_and_freq: first i<15 with rescaled < cdf[i]
     const uint32_t slot = (uint32_t)S & 0x7fffu;
     const int mx = row_bcast<15>(cv);
-    const int rescaled = (int)((slot * (uint32_t)mx) >> 15);
+    const int rescaled = (int)((uint32_t)__umul24(slot, (uint32_t)mx) >> 15);
     const unsigned long long ge = __ballot(rescaled >= cv);
     const int sym = __popc((uint32_t)(ge >> rbase) & 0x7fffu);
-    const uint32_t d = exact_div((uint32_t)cv << 15, (uint32_t)mx, __builtin_amdgcn_rcpf((float)mx));
+    const uint32_t d = scaled_div(cv, mx, biased_rcp15(mx));
     const int dprev = row_prev_or_zero((int)d);
     const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
     const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
@@ -384,43 +466,40 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const ui
     // helper_advance_sym ans.rs:238: x = freq * (state >> 15) + (state & mask) - start
     S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;
     if (MIX) {
-        uint32_t dc = exact_div((uint32_t)cm << 15, (uint32_t)cmax, __builtin_amdgcn_rcpf((float)cmax));
-        uint32_t ds = exact_div((uint32_t)st << 15, (uint32_t)smax, __builtin_amdgcn_rcpf((float)smax));
+        uint32_t dc = scaled_div(cm, cmax, biased_rcp15(cmax));
+        uint32_t ds = scaled_div(st, smax, biased_rcp15(smax));
         int dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
         uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
         uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
         weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)freq);
         cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
-        tb.store(rs.cm_row, cm);
+        tb.store(cref, cm);
     }
-    if (!((MM < 0 || MM == 2) && rs.is_default)) {
-        st = blend_row(st, li, sym, g.inc0, g.lim0);
-        tb.store(rs.stride_row, st);
-    }
+    if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0);
+    if (CACHE || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);
     return (uint32_t)sym;
 }
 
-template <int MM, bool CTXC, bool MIX>
+template <int MM, bool CTXC, bool MIX, bool CACHE>
 __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    load_config_to_lds(lds, b.blob);
+    const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
     const LitGeometry& g = b.geom;
     const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48;
     const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
     const uint32_t G = gridDim.x * (LIT_THREADS / 16);
-    const Table tb = make_table(b, li);
+    const Table<CACHE> tb = make_table<CACHE>(b, lds, li);
     for (uint32_t s = gg; s < b.n_streams; s += G) {
         const uint32_t len = b.out_sizes ? b.out_sizes[s] : b.stream_len;
         uint8_t* out = b.out + (b.out_offsets ? b.out_offsets[s] : (uint64_t)s * b.stream_len);
         WordWindow ww;
         ww.in = (const uint32_t*)(b.in + b.in_offsets[s]);
         ww.nwords = b.in_sizes[s] >> 2;
-        ww.pos = 0;
-        ww.reload(li);
+        ww.start(li);
         init_table(tb, g.total_rows, li);
         Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};
         uint64_t last8 = 0;
-        uint32_t k1 = lds[LIT_BLOB_LUT1CLASS];
+        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];
         uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
         for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
             // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
@@ -435,13 +514,13 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                 uint32_t outb = 0;
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const uint32_t prev = (uint32_t)(last8 >> 56);
-                    const uint32_t ctx = context_of<CTXC>(g, lds, prev, k1);
-                    if (!CTXC) k1 = lds[LIT_BLOB_LUT1CLASS + prev];
+                    const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
+                    if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                     // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
                     if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
-                    const uint32_t hi = decode_nibble<true, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, 0u, SA, wh);
+                    const uint32_t hi = decode_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, SA, wh);
                     if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
-                    const uint32_t lo = decode_nibble<false, MM, MIX>(g, lds, tb, li, rbase, ctx, last8, hi, SB, wl);
+                    const uint32_t lo = decode_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, SB, wl);
                     const uint32_t byte = (hi << 4) | lo;
                     last8 = (last8 >> 8) | ((uint64_t)byte << 56);
                     outb = (uint32_t)li == k ? byte : outb;
@@ -496,6 +575,7 @@ __global__ void selftest_division_kernel(unsigned long long* mismatches) {
         for (uint32_t c = threadIdx.x; c <= mx; c += blockDim.x) {
             uint32_t n = c << 15;
             bad += exact_div(n, mx, rcp) != n / mx;
+            bad += scaled_div((int)c, (int)mx, biased_rcp15((int)mx)) != n / mx;
         }
         // the rANS long division uses numerators up to 2^31 - 1
         for (uint32_t k = threadIdx.x; k < 4096u; k += blockDim.x) {
@@ -514,23 +594,39 @@ __global__ void selftest_division_kernel(unsigned long long* mismatches) {
 typedef void (*LitKernel)(const LitBatch);
 
 #define LIT_PICK(KERNEL)                                                                                     \
+    template <bool CACHE>                                                                                    \
     static LitKernel pick_##KERNEL(int mm, bool ctxc, bool mix) {                                            \
         const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 4 + (ctxc ? 2 : 0) + (mix ? 1 : 0);              \
         switch (key) {                                                                                       \
-        case 0: return KERNEL<-1, false, false>; case 1: return KERNEL<-1, false, true>;                     \
-        case 2: return KERNEL<-1, true, false>;  case 3: return KERNEL<-1, true, true>;                      \
-        case 4: return KERNEL<0, false, false>;  case 5: return KERNEL<0, false, true>;                      \
-        case 6: return KERNEL<0, true, false>;   case 7: return KERNEL<0, true, true>;                       \
-        case 8: return KERNEL<4, false, false>;  case 9: return KERNEL<4, false, true>;                      \
-        case 10: return KERNEL<4, true, false>;  default: return KERNEL<4, true, true>;                      \
+        case 0: return KERNEL<-1, false, false, CACHE>; case 1: return KERNEL<-1, false, true, CACHE>;       \
+        case 2: return KERNEL<-1, true, false, CACHE>;  case 3: return KERNEL<-1, true, true, CACHE>;        \
+        case 4: return KERNEL<0, false, false, CACHE>;  case 5: return KERNEL<0, false, true, CACHE>;        \
+        case 6: return KERNEL<0, true, false, CACHE>;   case 7: return KERNEL<0, true, true, CACHE>;         \
+        case 8: return KERNEL<4, false, false, CACHE>;  case 9: return KERNEL<4, false, true, CACHE>;        \
+        case 10: return KERNEL<4, true, false, CACHE>;  default: return KERNEL<4, true, true, CACHE>;        \
         }                                                                                                    \
     }
 LIT_PICK(lit_model_encode_kernel)
 LIT_PICK(lit_decode_kernel)
 
-hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
-    LitKernel k = pick_lit_model_encode_kernel(b.geom.mm_uniform, b.geom.ctx_const >= 0, mix);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+// specialisation that will actually run: only 0 and 4 have dedicated MM instances
+static int effective_mm(int mm) { return (mm == 0 || mm == 4) ? mm : -1; }
+
+uint32_t lit_lds_bytes(const LitBatch& b) {
+    uint32_t bytes = b.cache_bytes_per_wg;
+    if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTX_BYTES;
+    if (effective_mm(b.geom.mm_uniform) < 0) bytes += 8192u;
+    return bytes;
+}
+
+hipError_t launch_model_encode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
+    const LitBatch& b = b_in;
+    const int mm = effective_mm(b.geom.mm_uniform);
+    LitKernel k = b.cache_rows ? pick_lit_model_encode_kernel<true>(mm, b.geom.ctx_const >= 0, mix)
+                               : pick_lit_model_encode_kernel<false>(mm, b.geom.ctx_const >= 0, mix);
+    const uint32_t lds = lit_lds_bytes(b);
+    if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);
     return hipGetLastError();
 }
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
@@ -538,9 +634,14 @@ hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
     hipLaunchKernelGGL(rans_encode_kernel, dim3(blocks), dim3(RANS_THREADS), 0, st, b);
     return hipGetLastError();
 }
-hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
-    LitKernel k = pick_lit_decode_kernel(b.geom.mm_uniform, b.geom.ctx_const >= 0, mix);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), LIT_BLOB_BYTES, st, b);
+hipError_t launch_decode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
+    const LitBatch& b = b_in;
+    const int mm = effective_mm(b.geom.mm_uniform);
+    LitKernel k = b.cache_rows ? pick_lit_decode_kernel<true>(mm, b.geom.ctx_const >= 0, mix)
+                               : pick_lit_decode_kernel<false>(mm, b.geom.ctx_const >= 0, mix);
+    const uint32_t lds = lit_lds_bytes(b);
+    if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);
     return hipGetLastError();
 }
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,

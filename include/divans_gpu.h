@@ -104,8 +104,9 @@ typedef struct divans_gpu_info {
     float last_model_ms, last_rans_ms, last_decode_ms; /* hipEvent timings of the last batch calls */
 } divans_gpu_info;
 int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);
-/* geometry knobs (0 keeps the default): groups-per-CU occupancy and block count, for tuning runs */
-int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t threads_per_block);
+/* tuning knobs: `blocks` = persistent grid of 256-thread workgroups (0 keeps the current value);
+ * `cache_rows` = rows of the per-stream LDS row cache (0 = off, power of two in [32,256], 0xffffffff keeps). */
+int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t cache_rows);
 
 /* Exhaustive self-check of the reciprocal division used by the kernels against integer '/':
  * returns the number of mismatches over every (cdf<<15)/max with 1<=max<32768, 0<=cdf<=max. */

@@ -18,9 +18,11 @@ def _oracle_cfg(cfg_name):
     return po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
 
 
-def _compare(cfg_name, blocks):
+def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0):
     n, L = blocks.shape
     da, codec = _codec(cfg_name, max(L, 1))
+    if cache_rows is not None or blocks_grid:
+        codec.set_geometry(blocks=blocks_grid, cache_rows=cache_rows)
     packed, offs, sizes = codec.encode_host(blocks, L)
     ocfg = _oracle_cfg(cfg_name)
     for i in range(n):
@@ -72,3 +74,14 @@ def test_adversarial_inputs(cfg_name, shuffle384):
             rng.integers(0, 256, L, dtype=np.uint8), np.resize(np.arange(256, dtype=np.uint8), L),
             np.resize(np.frombuffer(b"@" * 7 + b"X", dtype=np.uint8), L)]
     _compare(cfg_name, np.stack(rows))
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+@pytest.mark.parametrize("cache_rows", [0, 32, 64, 128, 256])
+def test_row_cache_sizes_bit_exact(cfg_name, cache_rows, corpus, shuffle384):
+    # the LDS row cache (any size, or none) must not change a single coded byte; few resident rows of lanes
+    # so that every one of them recycles its table and cache across several streams
+    blocks = workload.make_blocks(corpus, 100, 70, block_len=20000)
+    blocks[3] = np.resize(shuffle384, 20000)
+    blocks[4] = np.random.default_rng(1).integers(0, 256, 20000, dtype=np.uint8)
+    _compare(cfg_name, blocks, cache_rows=cache_rows, blocks_grid=2)
