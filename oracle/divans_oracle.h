@@ -141,6 +141,46 @@ size_t orc_lit_stream_encode_trace(const orc_lit_config *cfg, const uint8_t *in,
 int orc_lit_batch_roundtrip(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len,
                             int nthreads, double *enc_seconds, double *dec_seconds, uint64_t *coded_bytes);
 
+/* ---- complete literal-only .divans streams (stream.c) ---- */
+typedef struct {
+    int window_size;                 /* header byte 5, clamped to [10,24] (divans_compressor.rs:89) */
+    uint8_t dynamic_context_mixing;  /* DivansCompressorOptions, src/interface.rs:444-484 */
+    uint8_t prior_depth;
+    int use_context_map;
+    uint8_t force_stride;            /* StrideSelection 0..8, 9 = UseBrotliRec */
+    int has_literal_adaptation; orc_speed literal_adaptation[4];
+    size_t call_buffer_size;         /* size of the output buffer the caller hands to each encode/flush call */
+} orc_stream_options;
+void orc_stream_options_default(orc_stream_options *o);
+
+/* PredictionModeContextMap as the encoder receives it (brotli::enc::interface, field accessors used by context_map.rs) */
+typedef struct {
+    uint8_t prediction_mode, is_adv_context_map;
+    const uint8_t *literal_context_map; size_t n_literal_context_map;
+    const uint8_t *distance_context_map; size_t n_distance_context_map;
+    const uint8_t *mixing_values;    /* 8192 or NULL */
+    int has_context_speeds;
+    uint8_t context_map_speed_f8[2][2], stride_speed_f8[2][2], combined_stride_speed_f8[2][2]; /* (inc,lim) f8 pairs */
+} orc_prediction_mode;
+typedef struct {                     /* what the codec's own PredictionModeContextMap holds afterwards */
+    uint8_t prediction_mode, mixing_math;
+    orc_speed literal_adaptation[4];
+    const uint8_t *literal_context_map;  /* 16384 */
+    const uint8_t *mixing_values;        /* 8192 */
+} orc_prediction_mode_result;
+enum { ORC_CMD_PREDICTION_MODE = 7, ORC_CMD_BLOCK_SWITCH_LITERAL = 4, ORC_CMD_LITERAL = 3 };
+typedef struct {
+    int kind;
+    orc_prediction_mode pm;
+    uint8_t btype, stride;
+    const uint8_t *data; size_t len;
+} orc_stream_command;
+/* returns the number of bytes written, (size_t)-1 on failure */
+size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command *cmds, size_t n_cmds, uint8_t *out, size_t cap);
+size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, size_t n, uint8_t *out, size_t cap);
+int orc_stream_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+int orc_mux_demux(const uint8_t *in, size_t n, uint8_t *s0, size_t *n0, uint8_t *s1, size_t *n1, size_t *consumed);
+
 /* ---- CRC-32C, src/codec/crc32.rs ---- */
 uint32_t orc_crc32c_update(uint32_t crc, const uint8_t *buf, size_t len);
 

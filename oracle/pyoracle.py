@@ -28,6 +28,26 @@ class LitConfig(ctypes.Structure):
     ]
 
 
+class StreamOptions(ctypes.Structure):
+    _fields_ = [("window_size", ctypes.c_int), ("dynamic_context_mixing", ctypes.c_uint8), ("prior_depth", ctypes.c_uint8),
+                ("use_context_map", ctypes.c_int), ("force_stride", ctypes.c_uint8), ("has_literal_adaptation", ctypes.c_int),
+                ("literal_adaptation", Speed * 4), ("call_buffer_size", ctypes.c_size_t)]
+
+
+class PredictionMode(ctypes.Structure):
+    _fields_ = [("prediction_mode", ctypes.c_uint8), ("is_adv_context_map", ctypes.c_uint8),
+                ("literal_context_map", ctypes.c_void_p), ("n_literal_context_map", ctypes.c_size_t),
+                ("distance_context_map", ctypes.c_void_p), ("n_distance_context_map", ctypes.c_size_t),
+                ("mixing_values", ctypes.c_void_p), ("has_context_speeds", ctypes.c_int),
+                ("context_map_speed_f8", (ctypes.c_uint8 * 2) * 2), ("stride_speed_f8", (ctypes.c_uint8 * 2) * 2),
+                ("combined_stride_speed_f8", (ctypes.c_uint8 * 2) * 2)]
+
+
+class StreamCommand(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("pm", PredictionMode), ("btype", ctypes.c_uint8), ("stride", ctypes.c_uint8),
+                ("data", ctypes.c_void_p), ("len", ctypes.c_size_t)]
+
+
 class Cdf16(ctypes.Structure):
     _fields_ = [("cdf", ctypes.c_int16 * 16)]
 
@@ -96,6 +116,19 @@ def lib(native=False):
     L.orc_get_lut1.argtypes = [ctypes.c_uint8, u8p]
     L.orc_lit_config_simple.argtypes = [ctypes.POINTER(LitConfig)]
     L.orc_lit_config_context_mixing.argtypes = [ctypes.POINTER(LitConfig)]
+    L.orc_stream_options_default.argtypes = [ctypes.POINTER(StreamOptions)]
+    L.orc_stream_compress.restype = ctypes.c_size_t
+    L.orc_stream_compress.argtypes = [ctypes.POINTER(StreamOptions), ctypes.POINTER(StreamCommand), ctypes.c_size_t,
+                                      ctypes.c_void_p, ctypes.c_size_t]
+    L.orc_stream_compress_raw.restype = ctypes.c_size_t
+    L.orc_stream_compress_raw.argtypes = [ctypes.POINTER(StreamOptions), ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p, ctypes.c_size_t]
+    L.orc_stream_decompress.restype = ctypes.c_int
+    L.orc_stream_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_size_t)]
+    L.orc_mux_demux.restype = ctypes.c_int
+    L.orc_mux_demux.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t),
+                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     if not native:
         _LIB = L
     return L
@@ -136,3 +169,49 @@ def lit_decode(cfg, coded, n):
     if r != 0:
         raise RuntimeError("oracle decode starved")
     return out[:n]
+
+
+def stream_options(**kw):
+    o = StreamOptions()
+    lib().orc_stream_options_default(ctypes.byref(o))
+    for k, v in kw.items():
+        if k == "literal_adaptation":
+            o.has_literal_adaptation = 1
+            for i, (inc, lim) in enumerate(v):
+                o.literal_adaptation[i] = Speed(inc, lim)
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def stream_compress_raw(data, opts=None):
+    """the literal-only internal compressor (use_brotli = UseInternalCommandSelection)"""
+    opts = opts or stream_options()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    cap = 2 * data.size + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    r = lib().orc_stream_compress_raw(ctypes.byref(opts), data.ctypes.data, data.size, out.ctypes.data, cap)
+    if r == ctypes.c_size_t(-1).value:
+        raise RuntimeError("oracle stream compress failed")
+    return out[:r].copy()
+
+
+def stream_compress_commands(cmds, opts, keepalive):
+    arr = (StreamCommand * len(cmds))(*cmds)
+    total = sum(c.len for c in cmds)
+    cap = 2 * total + 65536
+    out = np.empty(cap, dtype=np.uint8)
+    r = lib().orc_stream_compress(ctypes.byref(opts), arr, len(cmds), out.ctypes.data, cap)
+    if r == ctypes.c_size_t(-1).value:
+        raise RuntimeError("oracle stream compress failed")
+    return out[:r].copy()
+
+
+def stream_decompress(coded, max_out):
+    coded = np.ascontiguousarray(coded, dtype=np.uint8)
+    out = np.empty(max(max_out, 1), dtype=np.uint8)
+    n = ctypes.c_size_t(0)
+    rc = lib().orc_stream_decompress(coded.ctypes.data, coded.size, out.ctypes.data, max_out, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"oracle stream decompress failed rc={rc}")
+    return out[:n.value].copy()

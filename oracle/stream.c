@@ -1,0 +1,716 @@
+/*
+ * stream.c -- ORACLE (test infrastructure): a complete literal-only .divans stream.
+ * Restates, for streams made of PredictionMode / BlockSwitchLiteral / Literal commands:
+ *   src/codec/mod.rs:143-158,409-560,652-792 (command type nibble, flush, checksum trailer)
+ *   src/codec/context_map.rs:105-428        (PredictionMode wire format)
+ *   src/codec/block_type.rs:31-194          (BlockSwitchLiteral)
+ *   src/codec/literal.rs:496-661            (literal length)
+ *   src/mux.rs                              (two-stream interleaving)
+ *   src/divans_compressor.rs:126-174,276-426 + src/raw_to_cmd/mod.rs:105-181 (internal compressor)
+ *   src/divans_decompressor.rs:38-52        (header)
+ * Compressed bytes unpinned (see divans_oracle.h); pinned: mux KAT, CRC KATs, round trips and the
+ * reference's compressed-size bounds.
+ */
+#include "divans_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ Mux, src/mux.rs */
+#define MUX_MAX_HEADER_SIZE 3
+#define MUX_MAX_FLUSH_VARIANCE 131073
+
+typedef struct { uint8_t *buf; size_t cap, start, end; } mux_stream; /* AllocatedMemoryRange */
+typedef struct {
+    mux_stream s[2];
+    uint32_t cur_stream_bytes_avail;
+    uint8_t cur_stream;
+    size_t last_flush[2];
+    size_t bytes_flushed;
+    int eof;                 /* 0 Running, 1 EofStart, 2 EofMid, 3 EofDone */
+} orc_mux;
+
+static void mux_free(orc_mux *m) { free(m->s[0].buf); free(m->s[1].buf); memset(m, 0, sizeof(*m)); }
+
+/* mux.rs:285-329 prep_push_for_n_bytes */
+static void mux_prep_push(orc_mux *m, int id, size_t data_len) {
+    mux_stream *b = &m->s[id];
+    if (b->cap - b->end >= data_len) return;
+    size_t have = b->end - b->start;
+    if (b->cap >= have + data_len + MUX_MAX_HEADER_SIZE &&
+        (b->start == b->end || (b->start >= 16384 && b->start > have + MUX_MAX_HEADER_SIZE))) {
+        memmove(b->buf + MUX_MAX_HEADER_SIZE, b->buf + b->start, have);
+        b->end = MUX_MAX_HEADER_SIZE + have;
+        b->start = MUX_MAX_HEADER_SIZE;
+        return;
+    }
+    uint64_t desired = (uint64_t)(MUX_MAX_HEADER_SIZE + data_len + have);
+    uint32_t log_desired = (uint32_t)(64 - __builtin_clzll(desired)) + 1;
+    if (log_desired < 9) log_desired = 9;
+    size_t ncap = (size_t)1 << log_desired;
+    uint8_t *nb = (uint8_t *)calloc(ncap, 1);
+    if (have) memcpy(nb + MUX_MAX_HEADER_SIZE, b->buf + b->start, have);
+    free(b->buf);
+    b->buf = nb; b->cap = ncap;
+    b->end = MUX_MAX_HEADER_SIZE + have;
+    b->start = MUX_MAX_HEADER_SIZE;
+}
+
+static void mux_push_data(orc_mux *m, int id, const uint8_t *data, size_t n) { /* mux.rs:278-281 */
+    mux_prep_push(m, id, n);
+    memcpy(m->s[id].buf + m->s[id].end, data, n);
+    m->s[id].end += n;
+}
+
+static size_t mux_chunk_size(size_t last_flushed, int lagging) { /* mux.rs:37-48 */
+    if (lagging) return 16;
+    if (last_flushed <= 1024) return 4096;
+    if (last_flushed <= 65536) return 16384;
+    return 65536;
+}
+
+/* mux.rs:55-78 get_code: returns header length, fills hdr, *count = payload bytes */
+static int mux_get_code(int id, size_t bytes_to_write, int lagging, uint8_t hdr[3], size_t *count) {
+    if (!lagging || bytes_to_write == 4096 || bytes_to_write == 16384 || bytes_to_write >= 65536) {
+        if (bytes_to_write < 4096) return mux_get_code(id, bytes_to_write, 1, hdr, count);
+        if (bytes_to_write < 16384) { hdr[0] = (uint8_t)(id | (1 << 4)); *count = 4096; return 1; }
+        if (bytes_to_write < 65536) { hdr[0] = (uint8_t)(id | (2 << 4)); *count = 16384; return 1; }
+        hdr[0] = (uint8_t)(id | (3 << 4)); *count = 65536; return 1;
+    }
+    hdr[0] = (uint8_t)id;
+    hdr[1] = (uint8_t)((bytes_to_write - 1) & 0xff);
+    hdr[2] = (uint8_t)(((bytes_to_write - 1) >> 8) & 0xff);
+    *count = bytes_to_write;
+    return 3;
+}
+
+static size_t mux_serialize_leftover(orc_mux *m, uint8_t *out, size_t out_len) { /* mux.rs:331-338 */
+    size_t n = m->cur_stream_bytes_avail < out_len ? m->cur_stream_bytes_avail : out_len;
+    mux_stream *b = &m->s[m->cur_stream];
+    memcpy(out, b->buf + b->start, n);
+    b->start += n;
+    m->cur_stream_bytes_avail -= (uint32_t)n;
+    return n;
+}
+
+static void mux_serialize_stream_id(orc_mux *m, int id, uint8_t *out, size_t out_len, size_t *off, int lagging) { /* mux.rs:339-382 */
+    mux_stream *b = &m->s[id];
+    uint8_t hdr[3]; size_t count;
+    int hl = mux_get_code(id, b->end - b->start, lagging, hdr, &count);
+    m->bytes_flushed += count;
+    size_t should_write = count + (size_t)hl;
+    b->start -= (size_t)hl;
+    memcpy(b->buf + b->start, hdr, (size_t)hl);
+    m->last_flush[id] = m->bytes_flushed;
+    size_t room = out_len - *off;
+    size_t to_write = should_write < room ? should_write : room;
+    memcpy(out + *off, b->buf + b->start, to_write);
+    b->start += to_write;
+    if (b->start == b->end) { b->start = MUX_MAX_HEADER_SIZE; b->end = b->start; }
+    *off += to_write;
+    if (to_write != should_write) {
+        m->cur_stream_bytes_avail = (uint32_t)(should_write - to_write);
+        m->cur_stream = (uint8_t)id;
+    }
+}
+
+static size_t mux_serialize(orc_mux *m, uint8_t *out, size_t out_len) { /* mux.rs:445-476 */
+    size_t off = 0;
+    if (m->cur_stream_bytes_avail != 0) off += mux_serialize_leftover(m, out, out_len);
+    while (off < out_len) {
+        int flushed_any = 0;
+        size_t lo = m->last_flush[0], hi = m->last_flush[0];
+        if (m->last_flush[1] < lo) lo = m->last_flush[1];
+        if (m->last_flush[1] > hi) hi = m->last_flush[1];
+        for (int i = 0; i < 2; ++i) {
+            int lagging = hi > MUX_MAX_FLUSH_VARIANCE + m->last_flush[i];
+            if (m->s[i].end - m->s[i].start >= mux_chunk_size(m->last_flush[i], lagging) &&
+                m->last_flush[i] <= lo + MUX_MAX_FLUSH_VARIANCE) {
+                flushed_any = 1;
+                mux_serialize_stream_id(m, i, out, out_len, &off, lagging);
+                if (m->cur_stream_bytes_avail != 0) break;
+            }
+        }
+        if (!flushed_any) break;
+    }
+    return off;
+}
+
+static size_t mux_flush_internal(orc_mux *m, uint8_t *out, size_t out_len) { /* mux.rs:519-561 */
+    size_t off = 0;
+    if (m->cur_stream_bytes_avail != 0) off += mux_serialize_leftover(m, out, out_len);
+    while (off < out_len) {
+        int flushed_any = 0, have_lf = 0;
+        size_t last_flush = 0;
+        for (int i = 0; i < 2; ++i) {
+            int nonempty = m->s[i].start != m->s[i].end;
+            if (!have_lf ? nonempty : (m->last_flush[i] < last_flush && nonempty)) { last_flush = m->last_flush[i]; have_lf = 1; }
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (!have_lf || m->last_flush[i] <= last_flush + MUX_MAX_FLUSH_VARIANCE) {
+                size_t written = off;
+                if (m->s[i].start != m->s[i].end) mux_serialize_stream_id(m, i, out, out_len, &written, 1);
+                if (written != off) flushed_any = 1;
+                off = written;
+                if (m->cur_stream_bytes_avail != 0) break;
+            }
+        }
+        if (!flushed_any) break;
+    }
+    return off;
+}
+
+static const uint8_t MUX_EOF_MARKER[3] = {0xff, 0xfe, 0xff}; /* mux.rs:54 */
+
+static size_t mux_serialize_close(orc_mux *m, uint8_t *out, size_t out_len) { /* mux.rs:477-518 */
+    if (m->eof == 3) return 0;
+    size_t ret = mux_flush_internal(m, out, out_len);
+    for (int st = 0; st < 3; ++st) {
+        if (ret == out_len) return ret;
+        if (m->eof == st) { out[ret++] = MUX_EOF_MARKER[st]; m->eof = st + 1; }
+    }
+    return ret;
+}
+
+/* mux.rs:384-444 deserialize (iterative; the reference recurses on the tail) */
+typedef struct { int pending_kind; /* 0 none, 1 some, 2 header0, 3 header1 */ int stream; uint32_t count; uint8_t lsb; } mux_parse;
+static size_t mux_deserialize(orc_mux *m, mux_parse *p, const uint8_t *in, size_t n) {
+    size_t pos = 0;
+    while (pos < n && m->eof != 3) {
+        uint8_t c = in[pos];
+        switch (p->pending_kind) {
+        case 2: p->lsb = c; p->pending_kind = 3; pos++; break;
+        case 3: p->count = ((uint32_t)p->lsb | ((uint32_t)c << 8)) + 1; p->pending_kind = 1; pos++; break;
+        case 1: {
+            size_t take = p->count < n - pos ? p->count : n - pos;
+            mux_push_data(m, p->stream, in + pos, take);
+            pos += take; p->count -= (uint32_t)take;
+            if (p->count == 0) p->pending_kind = 0;
+            break;
+        }
+        default:
+            if (c == 0xff || c == 0xfe) {
+                if (c == 0xff || m->eof != 0) {
+                    /* deserialize_eof :384-  consumes marker bytes in order, then returns */
+                    int progressed = 0;
+                    while (pos < n && m->eof < 3 && in[pos] == MUX_EOF_MARKER[m->eof]) { m->eof++; pos++; progressed = 1; }
+                    if (!progressed) return pos;
+                    if (m->eof == 3) return pos;
+                    if (pos < n) return pos; /* malformed marker: reference stops consuming */
+                    break;
+                }
+            }
+            p->stream = c & 1; /* STREAM_ID_MASK for NUM_STREAMS = 2 */
+            if (c < 16) { p->pending_kind = 2; pos++; }
+            else { p->count = (uint32_t)1024 << ((c >> 4) << 1); p->pending_kind = 1; pos++; }
+            break;
+        }
+    }
+    return pos;
+}
+
+/* exported for the mux KAT (src/test_mux.rs:1192-1207) */
+int orc_mux_demux(const uint8_t *in, size_t n, uint8_t *s0, size_t *n0, uint8_t *s1, size_t *n1, size_t *consumed) {
+    orc_mux m; mux_parse p;
+    memset(&m, 0, sizeof(m)); memset(&p, 0, sizeof(p));
+    size_t used = mux_deserialize(&m, &p, in, n);
+    size_t a = m.s[0].end - m.s[0].start, b = m.s[1].end - m.s[1].start;
+    if (a > *n0 || b > *n1) { mux_free(&m); return -1; }
+    if (a) memcpy(s0, m.s[0].buf + m.s[0].start, a);
+    if (b) memcpy(s1, m.s[1].buf + m.s[1].start, b);
+    *n0 = a; *n1 = b; if (consumed) *consumed = used;
+    int done = m.eof == 3;
+    mux_free(&m);
+    return done ? 0 : 1;
+}
+
+/* ------------------------------------------------------------------ output sink = the caller's buffers */
+typedef struct {
+    uint8_t *data; size_t len, cap;    /* everything emitted so far */
+    size_t call_buf;                   /* size of the output buffer the caller passes per call */
+    size_t call_used;                  /* bytes of the current call's buffer already filled */
+} sink;
+
+static void sink_reserve(sink *s, size_t extra) {
+    if (s->len + extra <= s->cap) return;
+    size_t nc = s->cap ? s->cap * 2 : 65536;
+    while (nc < s->len + extra) nc *= 2;
+    s->data = (uint8_t *)realloc(s->data, nc); s->cap = nc;
+}
+/* remaining room in the current call; a full buffer means the call returned NeedsMoreOutput and the caller came back */
+static size_t sink_room(sink *s) { if (s->call_used == s->call_buf) s->call_used = 0; return s->call_buf - s->call_used; }
+static uint8_t *sink_ptr(sink *s, size_t want) { sink_reserve(s, want); return s->data + s->len; }
+static void sink_commit(sink *s, size_t n) { s->len += n; s->call_used += n; }
+
+/* ------------------------------------------------------------------ CMD-coder side state */
+enum { SPEED_MUD_I = 0x10, SPEED_MUD_L = 0x2000 };
+static const orc_speed SP_MED = {0x30, 0x4000}, SP_FAST = {0x60, 0x4000}, SP_PLANE = {0x80, 0x4000},
+                       SP_ROCKET = {0x180, 0x4000}, SP_SLOW = {0x20, 0x1000}, SP_MUD = {0x10, 0x2000};
+
+#define CONTEXT_MAP_CACHE_SIZE 13
+typedef struct {
+    /* CrossCommandBookKeeping, codec/interface.rs:142-167, :369-404 */
+    orc_cdf16 cc_priors[16];           /* CrossCommandPriors FullSelection(16,1) (EndIndicator unused here) */
+    orc_cdf16 lit_len_priors[4 * 256 + 256 * 15]; /* CountSmall(256,16) SizeBegNib SizeLastNib SizeMantissaNib */
+    orc_cdf16 prediction_priors[31];   /* codec/priors.rs:125-133 */
+    orc_cdf16 btype_priors[10];        /* Mnemonic(3) FirstNibble(3) SecondNibble(3) StrideNibble(1) */
+    uint8_t cmap_lru[CONTEXT_MAP_CACHE_SIZE];
+    uint8_t distance_context_map[4 * 256];
+    uint8_t btype_lru[3][2], btype_max_seen[3];
+    uint8_t last_4_states;
+    /* options */
+    uint8_t desired_prior_depth, desired_context_mixing, desired_force_stride;
+    int desired_do_context_map, has_desired_adaptation;
+    orc_speed desired_literal_adaptation[4];
+    /* PredictionModeState scratch that persists across PredictionMode commands, context_map.rs:84-94 */
+    uint8_t pm_literal_context_map[ORC_MAX_LITERAL_CONTEXT_MAP_SIZE];
+    uint8_t pm_mixing[ORC_NUM_MIXING_VALUES];
+    uint8_t pm_distance_map[4 * 256];
+} cmd_state;
+
+/* prior offsets, codec/priors.rs (define_prior_struct! linearisation, priors.rs:211-259) */
+#define LL_COUNT_SMALL(ctype) (ctype)
+#define LL_SIZE_BEG(ctype) (4096 + (ctype))
+#define LL_SIZE_LAST(ctype) (4096 + 256 + (ctype))
+#define LL_SIZE_MANT(ctype) (4096 + 512 + (ctype))
+#define PM_ONLY 0
+#define PM_FIRST(t) (2 + (t))
+#define PM_SECOND(t) (4 + (t))
+#define PM_MNEMONIC(t) (6 + (t))
+#define PM_MIXING(p) (10 + (p))
+#define PM_SPEED(p) (27 + (p))
+#define PM_ALIAS_LAST 27 /* DynamicContextMixingSpeed / PriorDepth are not in the struct: fall through to the last entry */
+#define BT_MNEMONIC(i) (i)
+#define BT_FIRST(i) (3 + (i))
+#define BT_SECOND(i) (6 + (i))
+#define BT_STRIDE 9
+
+static void cmd_state_init(cmd_state *c, const orc_stream_options *o) {
+    memset(c, 0, sizeof(*c));
+    for (size_t i = 0; i < sizeof(c->cc_priors) / sizeof(orc_cdf16); ++i) orc_cdf_default(&c->cc_priors[i]);
+    for (size_t i = 0; i < sizeof(c->lit_len_priors) / sizeof(orc_cdf16); ++i) orc_cdf_default(&c->lit_len_priors[i]);
+    for (size_t i = 0; i < 31; ++i) orc_cdf_default(&c->prediction_priors[i]);
+    for (size_t i = 0; i < 10; ++i) orc_cdf_default(&c->btype_priors[i]);
+    for (int i = 0; i < 3; ++i) { c->btype_lru[i][0] = 0; c->btype_lru[i][1] = 1; }
+    c->last_4_states = 3 << 4;
+    uint8_t mixing = o->dynamic_context_mixing;
+    if (o->force_stride != 0 && mixing == 0 && o->use_context_map) mixing = 1; /* codec/interface.rs:360-365 */
+    c->desired_context_mixing = mixing;
+    c->desired_prior_depth = o->prior_depth;
+    c->desired_force_stride = o->force_stride;
+    c->desired_do_context_map = o->use_context_map;
+    c->has_desired_adaptation = o->has_literal_adaptation;
+    for (int i = 0; i < 4; ++i) c->desired_literal_adaptation[i] = o->literal_adaptation[i];
+}
+
+/* one "get_or_put_nibble + blend" on the CMD coder */
+typedef struct { orc_ans_encoder *enc; orc_ans_decoder *dec; } cmd_coder;
+static uint8_t cmd_nibble(cmd_coder *cc, uint8_t nib, orc_cdf16 *prior, orc_speed sp) {
+    if (cc->enc) orc_ans_put_nibble(cc->enc, nib, prior, NULL);
+    else nib = orc_ans_get_nibble(cc->dec, prior, NULL);
+    orc_cdf_blend(prior, nib, sp);
+    return nib;
+}
+
+/* codec/interface.rs:421-455 obs_context_map_for_lru */
+static int obs_context_map_for_lru(cmd_state *c, int type, uint32_t index, uint8_t val) {
+    int found = -1;
+    for (int i = 0; i < CONTEXT_MAP_CACHE_SIZE; ++i) if (c->cmap_lru[i] == val) { found = i; break; }
+    if (found > 0) memmove(c->cmap_lru + 1, c->cmap_lru, (size_t)found);
+    else if (found < 0) memmove(c->cmap_lru + 1, c->cmap_lru, CONTEXT_MAP_CACHE_SIZE - 1);
+    c->cmap_lru[0] = val;
+    if (type == 1) {
+        if (index >= sizeof(c->distance_context_map)) return -1;
+        c->distance_context_map[index] = val;
+    }
+    return 0;
+}
+
+static uint8_t lru_max_plus_one(const cmd_state *c) {
+    uint8_t m = 0;
+    for (int i = 0; i < CONTEXT_MAP_CACHE_SIZE; ++i) if (c->cmap_lru[i] > m) m = c->cmap_lru[i];
+    return (uint8_t)(m + 1);
+}
+
+/* PredictionModeState::encode_or_decode, codec/context_map.rs:105-428.
+ * `pm` is the encoder's input command (NULL when decoding); on return `out` holds what the codec's own
+ * PredictionModeContextMap contains, i.e. what obs_prediction_mode_context_map will copy. */
+static int code_prediction_mode(cmd_state *c, cmd_coder *cc, void (*drain)(void *), void *drain_ctx,
+                                const orc_prediction_mode *pm, orc_prediction_mode_result *out) {
+    orc_speed desired[4] = {SP_MUD, SP_MUD, SP_MUD, SP_MUD};
+    if (pm && pm->has_context_speeds) {
+        /* context_map.rs:124-145 */
+        for (int i = 0; i < 2; ++i) {
+            if (pm->context_map_speed_f8[i][0] || pm->context_map_speed_f8[i][1]) {
+                desired[2 + i].inc = orc_u8_to_speed(pm->context_map_speed_f8[i][0]);
+                desired[2 + i].lim = orc_u8_to_speed(pm->context_map_speed_f8[i][1]);
+            }
+            const uint8_t *st = c->desired_context_mixing != 0 ? pm->combined_stride_speed_f8[i] : pm->stride_speed_f8[i];
+            if (st[0] || st[1]) { desired[i].inc = orc_u8_to_speed(st[0]); desired[i].lim = orc_u8_to_speed(st[1]); }
+        }
+    }
+    if (c->has_desired_adaptation) for (int i = 0; i < 4; ++i) desired[i] = c->desired_literal_adaptation[i];
+
+    /* Begin :159-178 */
+    drain(drain_ctx);
+    for (int i = 0; i < CONTEXT_MAP_CACHE_SIZE; ++i) c->cmap_lru[i] = (uint8_t)i;
+    for (size_t i = 0; i < sizeof(c->distance_context_map); ++i) c->distance_context_map[i] = (uint8_t)(i & 3);
+    uint8_t mode = cmd_nibble(cc, pm ? pm->prediction_mode : 0, &c->prediction_priors[PM_ONLY], SP_MED);
+    if (mode > 3) return -1;
+    out->prediction_mode = mode;
+    /* DynamicContextMixing :179-198 */
+    drain(drain_ctx);
+    uint8_t is_adv = pm ? pm->is_adv_context_map : 0;
+    if (is_adv >> 1) return -1;
+    uint8_t mixnib = cmd_nibble(cc, (uint8_t)(c->desired_context_mixing | (is_adv << 3)), &c->prediction_priors[PM_ALIAS_LAST], SP_MED);
+    out->mixing_math = mixnib & 3;
+    int combine = mixnib != 0;
+    /* PriorDepth :199-211 */
+    drain(drain_ctx);
+    (void)cmd_nibble(cc, c->desired_prior_depth, &c->prediction_priors[PM_ALIAS_LAST], SP_FAST);
+    /* AdaptationSpeed :212-252 */
+    uint8_t out_f8[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (uint32_t index = 0; index < 16; ++index) {
+        drain(drain_ctx);
+        uint32_t si = index >> 2, pt = index & 3;
+        uint8_t f0 = orc_speed_to_u8(desired[si].inc), f1 = orc_speed_to_u8(desired[si].lim);
+        uint8_t nib = pt == 0 ? (uint8_t)((f0 & 0x7f) >> 3) : pt == 1 ? (uint8_t)(f0 & 7) : pt == 2 ? (uint8_t)((f1 & 0x7f) >> 3) : (uint8_t)(f1 & 7);
+        nib = cmd_nibble(cc, nib, &c->prediction_priors[PM_SPEED(pt)], SP_FAST);
+        if (pt == 0) out_f8[si][0] |= (uint8_t)(nib << 3);
+        if (pt == 1) out_f8[si][0] |= nib;
+        if (pt == 2) out_f8[si][1] |= (uint8_t)(nib << 3);
+        if (pt == 3) out_f8[si][1] |= nib;
+    }
+    /* set_stride_context_speed / set_context_map_speed store speed_to_u8(u8_to_speed(f8)); readers apply u8_to_speed */
+    for (int i = 0; i < 4; ++i) {
+        out->literal_adaptation[i].inc = orc_u8_to_speed(orc_speed_to_u8(orc_u8_to_speed(out_f8[i][0])));
+        out->literal_adaptation[i].lim = orc_u8_to_speed(orc_speed_to_u8(orc_u8_to_speed(out_f8[i][1])));
+    }
+    /* context maps :253-384 */
+    for (int type = 0; type < 2; ++type) {
+        const uint8_t *cur = NULL; size_t cur_len = 0;
+        if (pm) {
+            if (type == 0) { cur = pm->literal_context_map; cur_len = pm->n_literal_context_map; }
+            else if (pm->has_context_speeds) { cur = pm->distance_context_map; cur_len = pm->n_distance_context_map; }
+        }
+        if (!c->desired_do_context_map) cur_len = 0;
+        uint8_t *outmap = type == 0 ? c->pm_literal_context_map : c->pm_distance_map;
+        size_t outmap_len = type == 0 ? sizeof(c->pm_literal_context_map) : sizeof(c->pm_distance_map);
+        for (uint32_t index = 0;; ++index) {
+            drain(drain_ctx);
+            uint8_t mn = 14;
+            if (pm && index < cur_len) {
+                uint8_t target = cur[index];
+                mn = 15;
+                for (int i = 0; i < CONTEXT_MAP_CACHE_SIZE; ++i) if (c->cmap_lru[i] == target) mn = (uint8_t)i;
+                if (target == lru_max_plus_one(c)) mn = 13;
+            }
+            mn = cmd_nibble(cc, mn, &c->prediction_priors[PM_MNEMONIC(type)], SP_MED);
+            if (mn == 14) {
+                if (type == 0) for (int i = 0; i < CONTEXT_MAP_CACHE_SIZE; ++i) c->cmap_lru[i] = (uint8_t)i; /* :303-306 */
+                break;
+            }
+            uint8_t val;
+            if (mn == 15) {
+                drain(drain_ctx);
+                uint8_t msn = cmd_nibble(cc, (pm && index < cur_len) ? (uint8_t)(cur[index] >> 4) : 0, &c->prediction_priors[PM_FIRST(type)], SP_MED);
+                drain(drain_ctx);
+                uint8_t lsn = cmd_nibble(cc, (pm && index < cur_len) ? (uint8_t)(cur[index] & 0xf) : 0, &c->prediction_priors[PM_SECOND(type)], SP_MED);
+                val = (uint8_t)((msn << 4) | lsn);
+                if (index >= outmap_len) return -1;
+                outmap[index] = val;
+                if (obs_context_map_for_lru(c, type, index, val)) return -1;
+            } else {
+                val = mn == 13 ? lru_max_plus_one(c) : c->cmap_lru[mn];
+                if (obs_context_map_for_lru(c, type, index, val)) return -1;
+                if (index >= outmap_len) return -1;
+                outmap[index] = val;
+            }
+        }
+    }
+    /* MixingValues :385-422 */
+    for (uint32_t index = 0; index < ORC_NUM_MIXING_VALUES; ++index) {
+        drain(drain_ctx);
+        uint8_t nib = !c->desired_do_context_map ? 4 : (!combine ? 0 : ((pm && pm->has_context_speeds && pm->mixing_values) ? pm->mixing_values[index] : 0));
+        uint32_t prior = index >= 256 ? (uint32_t)(c->pm_mixing[index - 256] & 0xf) : 16; /* the codec's own pm always has_context_speeds */
+        nib = cmd_nibble(cc, nib, &c->prediction_priors[PM_MIXING(prior)], SP_PLANE);
+        c->pm_mixing[index] = nib;
+    }
+    out->literal_context_map = c->pm_literal_context_map;
+    out->mixing_values = c->pm_mixing;
+    return 0;
+}
+
+/* BlockTypeState + LiteralBlockTypeState, codec/block_type.rs:31-194 (switch index 0 = literal) */
+static int code_block_switch_literal(cmd_state *c, cmd_coder *cc, void (*drain)(void *), void *drain_ctx,
+                                     uint8_t in_btype, uint8_t in_stride, uint8_t *out_btype, uint8_t *out_stride) {
+    const int idx = 0;
+    uint8_t varint = in_btype == c->btype_lru[idx][1] ? 0 : in_btype == (uint8_t)(c->btype_max_seen[idx] + 1) ? 1 : in_btype <= 12 ? (uint8_t)(in_btype + 2) : 15;
+    drain(drain_ctx);
+    varint = cmd_nibble(cc, varint, &c->btype_priors[BT_MNEMONIC(idx)], SP_SLOW);
+    uint8_t btype;
+    if (varint == 0) btype = c->btype_lru[idx][1];
+    else if (varint == 1) btype = (uint8_t)(c->btype_max_seen[idx] + 1);
+    else if (varint == 15) {
+        drain(drain_ctx);
+        uint8_t first = cmd_nibble(cc, in_btype & 0xf, &c->btype_priors[BT_FIRST(idx)], SP_SLOW);
+        drain(drain_ctx);
+        uint8_t second = cmd_nibble(cc, in_btype >> 4, &c->btype_priors[BT_SECOND(idx)], SP_SLOW);
+        btype = (uint8_t)((second << 4) | first);
+    } else btype = (uint8_t)(varint - 2);
+    drain(drain_ctx);
+    uint8_t stride = c->desired_force_stride == 9 ? in_stride : c->desired_force_stride; /* UseBrotliRec = 9 */
+    stride = cmd_nibble(cc, stride, &c->btype_priors[BT_STRIDE], SP_SLOW);
+    /* obs_btypel, codec/interface.rs:527-537 */
+    c->last_4_states >>= 2;
+    c->btype_lru[idx][1] = c->btype_lru[idx][0]; c->btype_lru[idx][0] = btype;
+    if (btype > c->btype_max_seen[idx]) c->btype_max_seen[idx] = btype;
+    *out_btype = btype; *out_stride = stride;
+    return 0;
+}
+
+static uint8_t round_up_mod_4(uint8_t v) { return (uint8_t)((((uint8_t)(v - 1)) | 3) + 1); } /* codec/interface.rs:180-182 */
+
+/* literal length, codec/literal.rs:565-661.  Encoding passes len; decoding returns it. */
+static int code_literal_length(cmd_state *c, cmd_coder *cc, void (*drain)(void *), void *drain_ctx, uint32_t len_in, uint32_t *len_out) {
+    const uint32_t ctype = c->btype_lru[1][0];
+    const uint32_t MN = 14; /* NUM_LITERAL_LENGTH_MNEMONIC */
+    uint32_t serialized = len_in - (MN + 1);
+    uint8_t lllen = (uint8_t)(serialized ? 32 - __builtin_clz(serialized) : 0);
+    drain(drain_ctx);
+    uint32_t lm1 = len_in - 1;
+    uint8_t shortcut = cmd_nibble(cc, (uint8_t)(lm1 < MN ? lm1 : MN), &c->lit_len_priors[LL_COUNT_SMALL(ctype)], SP_MED);
+    if (shortcut == MN + 1) return -1; /* high-entropy literals are not produced by the literal-only path */
+    if (shortcut != MN) { *len_out = (uint32_t)shortcut + 1; return 0; }
+    drain(drain_ctx);
+    uint8_t beg = cmd_nibble(cc, lllen < 15 ? lllen : 15, &c->lit_len_priors[LL_SIZE_BEG(ctype)], SP_MUD);
+    uint8_t len_remaining; uint32_t decoded;
+    if (beg == 15) {
+        drain(drain_ctx);
+        uint8_t last = cmd_nibble(cc, (uint8_t)(lllen - 15), &c->lit_len_priors[LL_SIZE_LAST(ctype)], SP_MUD);
+        len_remaining = round_up_mod_4((uint8_t)(last + 14));
+        decoded = (uint32_t)1 << (last + 14);
+    } else if (beg <= 1) {
+        *len_out = MN + 1 + beg; return 0;
+    } else {
+        len_remaining = round_up_mod_4((uint8_t)(beg - 1));
+        decoded = (uint32_t)1 << (beg - 1);
+    }
+    while (1) {
+        drain(drain_ctx);
+        uint8_t next_rem = (uint8_t)(len_remaining - 4);
+        uint8_t nib = cmd_nibble(cc, (uint8_t)((serialized ^ decoded) >> next_rem), &c->lit_len_priors[LL_SIZE_MANT(ctype)], SP_MUD);
+        decoded |= (uint32_t)nib << next_rem;
+        if (next_rem == 0) { *len_out = decoded + MN + 1; return 0; }
+        len_remaining = next_rem;
+    }
+}
+
+/* command type nibble, codec/mod.rs:662-688 */
+static uint8_t code_command_type(cmd_state *c, cmd_coder *cc, void (*drain)(void *), void *drain_ctx, uint8_t code) {
+    drain(drain_ctx);
+    code = cmd_nibble(cc, code, &c->cc_priors[c->last_4_states >> 4], SP_ROCKET);
+    if (code == 3) { c->last_4_states >>= 2; c->last_4_states |= 128; } /* obs_literal_state */
+    return code;
+}
+
+/* ------------------------------------------------------------------ encoder driver */
+typedef struct {
+    orc_mux mux; sink out; uint32_t crc;
+    orc_ans_encoder cmd, lit;
+    size_t cmd_drained, lit_drained;   /* bytes of enc.out already handed to the mux */
+} enc_ctx;
+
+/* drain_or_fill_static_buffer for an encoder, codec/interface.rs:868-895 */
+static void drain_coder(enc_ctx *e, int id) {
+    orc_ans_encoder *enc = id == 0 ? &e->cmd : &e->lit;
+    size_t *drained = id == 0 ? &e->cmd_drained : &e->lit_drained;
+    while (*drained < enc->out.len) {
+        size_t room = sink_room(&e->out);
+        uint8_t *p = sink_ptr(&e->out, room);
+        size_t n = mux_serialize(&e->mux, p, room);
+        sink_commit(&e->out, n);
+        mux_prep_push(&e->mux, 0, 16); mux_prep_push(&e->mux, 1, 16);   /* write_buffer, mux.rs:184-204 */
+        mux_stream *b = &e->mux.s[id];
+        size_t space = b->cap - b->end, avail = enc->out.len - *drained;
+        size_t take = avail < space ? avail : space;
+        memcpy(b->buf + b->end, enc->out.data + *drained, take);
+        b->end += take; *drained += take;
+        /* NeedsMoreOutput with a full caller buffer returns to the caller, who comes back with a fresh one:
+         * sink_room() models that by starting a new call buffer */
+    }
+}
+static void drain_cmd_cb(void *p) { drain_coder((enc_ctx *)p, 0); }
+
+static void lit_config_from_pm(orc_lit_config *cfg, const orc_prediction_mode_result *r, uint8_t btype, uint8_t mixing) {
+    memcpy(cfg->literal_context_map, r->literal_context_map, sizeof(cfg->literal_context_map));
+    memcpy(cfg->mixing_mask, r->mixing_values, sizeof(cfg->mixing_mask));
+    cfg->prediction_mode = r->prediction_mode;
+    cfg->btype = btype;
+    cfg->context_mixing = mixing;
+    cfg->reserved = 0;
+    for (int i = 0; i < 4; ++i) cfg->literal_adaptation[i] = r->literal_adaptation[i];
+}
+
+void orc_stream_options_default(orc_stream_options *o) { /* src/interface.rs:463-483 */
+    memset(o, 0, sizeof(*o));
+    o->window_size = 22; o->dynamic_context_mixing = 1; o->use_context_map = 1; o->force_stride = 9;
+    o->call_buffer_size = 65536;
+}
+
+size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command *cmds, size_t n_cmds, uint8_t *out, size_t cap) {
+    enc_ctx e;
+    memset(&e, 0, sizeof(e));
+    orc_ans_encoder_init(&e.cmd); orc_ans_encoder_init(&e.lit);
+    e.out.call_buf = o->call_buffer_size ? o->call_buffer_size : 65536;
+    cmd_state *c = (cmd_state *)malloc(sizeof(cmd_state));
+    cmd_state_init(c, o);
+    cmd_coder cc = {&e.cmd, NULL};
+    orc_lit_config *cfg = (orc_lit_config *)calloc(1, sizeof(orc_lit_config));
+    /* LiteralBookKeeping::new, codec/interface.rs:244-262 (+ reset on construction = zeroed map) */
+    for (int i = 0; i < 4; ++i) cfg->literal_adaptation[i] = SP_MUD;
+    orc_lit_state *ls = orc_lit_state_new(cfg);
+    int bad = 0;
+    /* header, divans_compressor.rs:126-131,150-174 */
+    {
+        int w = o->window_size < 10 ? 10 : (o->window_size > 24 ? 24 : o->window_size);
+        uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        size_t written = 0;
+        while (written < 16) {
+            size_t room = sink_room(&e.out), n = 16 - written < room ? 16 - written : room;
+            memcpy(sink_ptr(&e.out, n), hdr + written, n);
+            sink_commit(&e.out, n); written += n;
+        }
+    }
+    uint8_t btype = 0; uint8_t mixing = c->desired_context_mixing;
+    for (size_t k = 0; k < n_cmds && !bad; ++k) {
+        const orc_stream_command *cm = &cmds[k];
+        if (cm->kind == ORC_CMD_PREDICTION_MODE) {
+            code_command_type(c, &cc, drain_cmd_cb, &e, 7);
+            orc_prediction_mode_result r;
+            if (code_prediction_mode(c, &cc, drain_cmd_cb, &e, &cm->pm, &r)) { bad = 1; break; }
+            mixing = r.mixing_math;
+            lit_config_from_pm(cfg, &r, btype, mixing);
+            orc_lit_state_reconfigure(ls, cfg);
+        } else if (cm->kind == ORC_CMD_BLOCK_SWITCH_LITERAL) {
+            code_command_type(c, &cc, drain_cmd_cb, &e, 4);
+            uint8_t stride;
+            code_block_switch_literal(c, &cc, drain_cmd_cb, &e, cm->btype, cm->stride, &btype, &stride);
+            cfg->btype = btype;
+            orc_lit_state_reconfigure(ls, cfg);
+        } else if (cm->kind == ORC_CMD_LITERAL) {
+            if (cm->len == 0) { bad = 1; break; }
+            code_command_type(c, &cc, drain_cmd_cb, &e, 3);
+            uint32_t len_out;
+            if (code_literal_length(c, &cc, drain_cmd_cb, &e, (uint32_t)cm->len, &len_out)) { bad = 1; break; }
+            drain_coder(&e, 1);                        /* literal.rs:426-433 */
+            for (size_t i = 0; i < cm->len; ++i) {     /* code_nibble_array drains the LIT coder after every nibble */
+                orc_lit_encode_bytes(ls, &e.lit, cm->data + i, 1);
+                drain_coder(&e, 1);
+            }
+        } else bad = 1;
+    }
+    if (!bad) {
+        /* DivansCodec::flush, codec/mod.rs:424-554 */
+        code_command_type(c, &cc, drain_cmd_cb, &e, 0xf);
+        drain_coder(&e, 0); drain_coder(&e, 1);          /* EncodedShutdownNode */
+        orc_ans_flush_chunk(&e.cmd); orc_ans_flush_chunk(&e.lit);   /* ShutdownCoder(0), (1) */
+        drain_coder(&e, 0); drain_coder(&e, 1);          /* CoderBufferDrain */
+        while (e.mux.eof != 3) {                         /* MuxDrain */
+            size_t room = sink_room(&e.out);
+            size_t n = mux_serialize_close(&e.mux, sink_ptr(&e.out, room), room);
+            sink_commit(&e.out, n);
+        }
+        uint32_t crc = orc_crc32c_update(0, e.out.data, e.out.len);   /* every emitted byte, header included */
+        uint8_t tr[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
+        memcpy(sink_ptr(&e.out, 8), tr, 8); e.out.len += 8;
+        if (e.cmd.failed || e.lit.failed) bad = 1;
+    }
+    size_t ret = (size_t)-1;
+    if (!bad && e.out.len <= cap) { memcpy(out, e.out.data, e.out.len); ret = e.out.len; }
+    free(e.out.data); mux_free(&e.mux);
+    orc_ans_encoder_free(&e.cmd); orc_ans_encoder_free(&e.lit);
+    orc_lit_state_free(ls); free(cfg); free(c);
+    return ret;
+}
+
+/* The literal-only internal compressor (use_brotli = UseInternalCommandSelection): raw_to_cmd/mod.rs:105-181
+ * emits [PredictionMode][Literal per ring-buffer span].  Input shorter than the ring arrives as one Literal. */
+size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, size_t n, uint8_t *out, size_t cap) {
+    int w = o->window_size < 10 ? 10 : (o->window_size > 24 ? 24 : o->window_size);
+    size_t ring = (size_t)1 << w;
+    size_t nlit = n ? (n + ring - 1) / ring : 0;
+    orc_stream_command *cmds = (orc_stream_command *)calloc(nlit + 1, sizeof(orc_stream_command));
+    static uint8_t cmap[64], dmap[4], mixing[ORC_NUM_MIXING_VALUES];
+    for (int i = 0; i < 64; ++i) cmap[i] = (uint8_t)(i & 0x3f);
+    for (int i = 0; i < 4; ++i) dmap[i] = (uint8_t)(i & 3);
+    memset(mixing, 4, sizeof(mixing));
+    cmds[0].kind = ORC_CMD_PREDICTION_MODE;
+    cmds[0].pm.prediction_mode = 0;
+    cmds[0].pm.literal_context_map = cmap; cmds[0].pm.n_literal_context_map = 64;
+    cmds[0].pm.distance_context_map = dmap; cmds[0].pm.n_distance_context_map = 4;
+    cmds[0].pm.mixing_values = mixing; cmds[0].pm.has_context_speeds = 1;
+    for (size_t i = 0; i < nlit; ++i) {
+        cmds[1 + i].kind = ORC_CMD_LITERAL;
+        cmds[1 + i].data = in + i * ring;
+        cmds[1 + i].len = (i + 1 < nlit) ? ring : n - i * ring;
+    }
+    /* an empty input still flushes a PredictionMode command (has_produced_header, raw_to_cmd/mod.rs:114-143) */
+    size_t r = orc_stream_compress(o, cmds, nlit + 1, out, cap);
+    free(cmds);
+    return r;
+}
+
+/* ------------------------------------------------------------------ decoder */
+static void no_drain(void *p) { (void)p; }
+
+int orc_stream_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    if (n < 16 + 3 + 8) return -1;
+    if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f) return -2;  /* divans_decompressor.rs:38-52 */
+    if (in[5] < 10 || in[5] >= 25) return -2;
+    orc_mux m; mux_parse p;
+    memset(&m, 0, sizeof(m)); memset(&p, 0, sizeof(p));
+    size_t used = mux_deserialize(&m, &p, in + 16, n - 16);
+    if (m.eof != 3 || n - 16 - used < 8) { mux_free(&m); return -3; }
+    const uint8_t *tr = in + 16 + used;
+    uint32_t crc = orc_crc32c_update(0, in, 16 + used);
+    uint8_t want[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
+    if (memcmp(tr, want, 8) != 0) { mux_free(&m); return -4; }    /* codec/mod.rs:949-1017 */
+    orc_stream_options o;
+    orc_stream_options_default(&o);
+    cmd_state *c = (cmd_state *)malloc(sizeof(cmd_state));
+    cmd_state_init(c, &o);   /* every desired_* only shapes what an ENCODER would put; the decoder takes the coded nibble */
+    orc_ans_decoder cd, ld;
+    orc_ans_decoder_init(&cd, m.s[0].buf ? m.s[0].buf + m.s[0].start : (const uint8_t *)"", m.s[0].end - m.s[0].start);
+    orc_ans_decoder_init(&ld, m.s[1].buf ? m.s[1].buf + m.s[1].start : (const uint8_t *)"", m.s[1].end - m.s[1].start);
+    cmd_coder cc = {NULL, &cd};
+    orc_lit_config *cfg = (orc_lit_config *)calloc(1, sizeof(orc_lit_config));
+    for (int i = 0; i < 4; ++i) cfg->literal_adaptation[i] = SP_MUD;
+    orc_lit_state *ls = orc_lit_state_new(cfg);
+    size_t produced = 0; int rc = 0; uint8_t btype = 0;
+    for (;;) {
+        uint8_t code = code_command_type(c, &cc, no_drain, NULL, 0);
+        if (cd.starved) { rc = -5; break; }
+        if (code == 0xf) break;
+        if (code == 7) {
+            orc_prediction_mode_result r;
+            if (code_prediction_mode(c, &cc, no_drain, NULL, NULL, &r)) { rc = -6; break; }
+            lit_config_from_pm(cfg, &r, btype, r.mixing_math);
+            orc_lit_state_reconfigure(ls, cfg);
+        } else if (code == 4) {
+            uint8_t stride;
+            code_block_switch_literal(c, &cc, no_drain, NULL, 0, 0, &btype, &stride);
+            cfg->btype = btype;
+            orc_lit_state_reconfigure(ls, cfg);
+        } else if (code == 3) {
+            uint32_t len;
+            if (code_literal_length(c, &cc, no_drain, NULL, 15, &len)) { rc = -7; break; }
+            if (produced + len > cap) { rc = -8; break; }
+            orc_lit_decode_bytes(ls, &ld, out + produced, len);
+            if (ld.starved) { rc = -9; break; }
+            produced += len;
+        } else { rc = -10; break; }   /* Copy / Dict / other block switches: outside the literal-only scope */
+    }
+    if (out_len) *out_len = produced;
+    free(cfg); orc_lit_state_free(ls); free(c); mux_free(&m);
+    return rc;
+}
