@@ -103,7 +103,7 @@ def exported_symbols():
         "divans_lit_config_simple", "divans_lit_config_context_mixing", "divans_gpu_codec_create",
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
-        "divans_gpu_lit_encode_host", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
+        "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
         "divans_gpu_codec_set_geometry", "divans_gpu_selftest_division",
     ]
 

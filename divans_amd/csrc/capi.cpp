@@ -265,9 +265,22 @@ extern "C" size_t divans_gpu_lit_encode_bound(size_t n) {
     return (bytes + 15) & ~(size_t)15;
 }
 
+static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                             const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                             uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes,
+                             uint32_t* d_chunk_bytes, uint32_t max_chunks);
+
 extern "C" int divans_gpu_lit_encode_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                                            const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                                            uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes) {
+    return encode_batch_impl(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, d_out, out_slot, d_out_offsets,
+                             d_out_sizes, nullptr, 0);
+}
+
+static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                             const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                             uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes,
+                             uint32_t* d_chunk_bytes, uint32_t max_chunks) {
     if (!c || !d_in || !d_out || !d_out_offsets || !d_out_sizes) return fail(DIVANS_GPU_EINVAL, "null argument");
     if (n_streams == 0) return 0;
     if ((d_in_offsets == nullptr) != (d_in_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
@@ -290,7 +303,7 @@ extern "C" int divans_gpu_lit_encode_batch(divans_gpu_codec* c, const uint8_t* d
     RansBatch r;
     r.sf = c->d_sf; r.n_streams = n_streams; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
     r.in_sizes = d_in_sizes; r.out = d_out; r.out_slot = out_slot; r.out_offsets = d_out_offsets; r.out_sizes = d_out_sizes;
-    r.status = c->d_status;
+    r.status = c->d_status; r.chunk_bytes = d_chunk_bytes; r.max_chunks = max_chunks;
     HIP_TRY(launch_rans_encode(r, c->stream));
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     c->timing_pending_enc = true;
@@ -372,16 +385,24 @@ extern "C" int divans_gpu_selftest_division(divans_gpu_codec* c, uint64_t* misma
 extern "C" int divans_gpu_lit_encode_host(divans_gpu_codec* c, const uint8_t* in, uint32_t stream_len, uint32_t n_streams,
                                           uint8_t* out_packed, size_t out_cap, uint64_t* out_offsets, uint32_t* out_sizes,
                                           size_t* out_total) {
+    return divans_gpu_lit_encode_host_chunks(c, in, stream_len, n_streams, out_packed, out_cap, out_offsets, out_sizes,
+                                             out_total, nullptr, 0);
+}
+
+extern "C" int divans_gpu_lit_encode_host_chunks(divans_gpu_codec* c, const uint8_t* in, uint32_t stream_len, uint32_t n_streams,
+                                                 uint8_t* out_packed, size_t out_cap, uint64_t* out_offsets, uint32_t* out_sizes,
+                                                 size_t* out_total, uint32_t* out_chunk_bytes, uint32_t max_chunks) {
     if (!c || !in || !out_packed || !out_offsets || !out_sizes || !out_total) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (out_chunk_bytes && max_chunks < (2u * stream_len + 65535u) / 65536u) return fail(DIVANS_GPU_EINVAL, "max_chunks too small");
     HIP_TRY(hipSetDevice(c->device));
     const size_t in_bytes = (size_t)stream_len * n_streams;
     const uint64_t slot = divans_gpu_lit_encode_bound(stream_len);
     uint8_t *d_in = nullptr, *d_slots = nullptr, *d_packed = nullptr;
-    uint64_t *d_off = nullptr, *d_poff = nullptr, *d_total = nullptr; uint32_t* d_sz = nullptr;
+    uint64_t *d_off = nullptr, *d_poff = nullptr, *d_total = nullptr; uint32_t* d_sz = nullptr; uint32_t* d_chunks = nullptr;
     int rc = 0;
     auto cleanup = [&]() {
         (void)hipFree(d_in); (void)hipFree(d_slots); (void)hipFree(d_packed); (void)hipFree(d_off); (void)hipFree(d_poff);
-        (void)hipFree(d_total); (void)hipFree(d_sz);
+        (void)hipFree(d_total); (void)hipFree(d_sz); (void)hipFree(d_chunks);
     };
 #define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(DIVANS_GPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     TRY_OR_CLEAN(hipMalloc(&d_in, in_bytes + 64));
@@ -391,8 +412,12 @@ extern "C" int divans_gpu_lit_encode_host(divans_gpu_codec* c, const uint8_t* in
     TRY_OR_CLEAN(hipMalloc(&d_poff, sizeof(uint64_t) * n_streams));
     TRY_OR_CLEAN(hipMalloc(&d_total, sizeof(uint64_t)));
     TRY_OR_CLEAN(hipMalloc(&d_sz, sizeof(uint32_t) * n_streams));
+    if (out_chunk_bytes) {
+        TRY_OR_CLEAN(hipMalloc(&d_chunks, sizeof(uint32_t) * (size_t)n_streams * max_chunks));
+        TRY_OR_CLEAN(hipMemsetAsync(d_chunks, 0, sizeof(uint32_t) * (size_t)n_streams * max_chunks, c->stream));
+    }
     TRY_OR_CLEAN(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
-    rc = divans_gpu_lit_encode_batch(c, d_in, nullptr, nullptr, stream_len, n_streams, d_slots, slot, d_off, d_sz);
+    rc = encode_batch_impl(c, d_in, nullptr, nullptr, stream_len, n_streams, d_slots, slot, d_off, d_sz, d_chunks, max_chunks);
     if (rc) { cleanup(); return rc; }
     rc = divans_gpu_pack_streams(c, d_slots, d_off, d_sz, n_streams, d_packed, d_poff, d_total);
     if (rc) { cleanup(); return rc; }
@@ -401,6 +426,8 @@ extern "C" int divans_gpu_lit_encode_host(divans_gpu_codec* c, const uint8_t* in
     TRY_OR_CLEAN(hipMemcpyAsync(&status, c->d_status, sizeof(status), hipMemcpyDeviceToHost, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(out_offsets, d_poff, sizeof(uint64_t) * n_streams, hipMemcpyDeviceToHost, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(out_sizes, d_sz, sizeof(uint32_t) * n_streams, hipMemcpyDeviceToHost, c->stream));
+    if (out_chunk_bytes)
+        TRY_OR_CLEAN(hipMemcpyAsync(out_chunk_bytes, d_chunks, sizeof(uint32_t) * (size_t)n_streams * max_chunks, hipMemcpyDeviceToHost, c->stream));
     TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
     if (status) { (void)hipMemset(c->d_status, 0, 64); cleanup(); return fail(DIVANS_GPU_EINVAL, "model produced an invalid (start,freq): unsupported speed/CDF state"); }
     if (total > out_cap) { cleanup(); return fail(DIVANS_GPU_ECAP, "out_cap too small for the packed streams"); }

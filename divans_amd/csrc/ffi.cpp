@@ -1,0 +1,222 @@
+// ffi.cpp -- the reference's per-stream C ABI (include/divans_ffi.h <-> c/divans/ffi.h, src/ffi/*.rs) on top of the
+// host stream layer + HIP literal coder.  Error behaviour follows src/ffi/mod.rs: NULL state/offset -> FAILURE,
+// every internal error collapses to DIVANS_FAILURE, options only before the first encode (OptionStage).
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/divans_ffi.h"
+#include "host_stream.h"
+
+using divans_host::StreamOptions;
+
+namespace {
+
+void* state_alloc(const CAllocator& a, size_t n) { return a.alloc_func ? a.alloc_func(a.opaque, n) : std::malloc(n); }
+void state_free(const CAllocator& a, void* p) { if (a.alloc_func) { if (a.free_func) a.free_func(a.opaque, p); } else std::free(p); }
+
+// ENCODER_DEFAULT_PALETTE, src/probability/interface.rs:303-320
+const divans_speed kPalette[15] = {{0, 1024}, {2, 1024}, {1, 128}, {1, 16384}, {2, 2048}, {4, 1024}, {8, 8192}, {16, 48},
+                                   {16, 8192}, {32, 4096}, {64, 16384}, {128, 256}, {128, 16384}, {512, 16384}, {1664, 16384}};
+
+}  // namespace
+
+struct DivansCompressorState {
+    CAllocator alloc;
+    StreamOptions opt;
+    bool started = false;        // CompressorState::OptionStage -> constructed compressor (ffi/compressor.rs:212-236)
+    bool failed = false;
+    int header_sent = 0;         // bytes of the 16-byte header already handed out (write_header, divans_compressor.rs:150-174)
+    std::vector<uint8_t> input;  // RawToCmdState buffers input until flush (raw_to_cmd/mod.rs:55-104)
+    bool built = false;
+    std::vector<uint8_t> stream; // complete container, produced at the first flush
+    size_t cursor = 0;
+};
+
+struct DivansDecompressorState {
+    CAllocator alloc;
+    bool skip_crc = false;
+    bool failed = false, decoded = false;
+    std::vector<uint8_t> input, output;
+    size_t cursor = 0;
+};
+
+extern "C" {
+
+struct DivansCompressorState* divans_new_compressor_with_custom_alloc(struct CAllocator alloc) {
+    void* mem = state_alloc(alloc, sizeof(DivansCompressorState));
+    if (!mem) return nullptr;
+    DivansCompressorState* s = new (mem) DivansCompressorState();
+    s->alloc = alloc;
+    return s;
+}
+struct DivansCompressorState* divans_new_compressor(void) {
+    CAllocator a = {nullptr, nullptr, nullptr};
+    return divans_new_compressor_with_custom_alloc(a);
+}
+
+// src/ffi/compressor.rs:63-166
+DivansResult divans_set_option(struct DivansCompressorState* s, DivansOptionSelect selector, uint32_t value) {
+    if (!s || s->started) return DIVANS_FAILURE;
+    StreamOptions& o = s->opt;
+    auto set_speed = [&](int index) -> DivansResult {
+        if (value >= 15) return DIVANS_FAILURE;
+        if (!o.has_literal_adaptation) { o.has_literal_adaptation = true; for (auto& sp : o.literal_adaptation) sp = kPalette[value]; }
+        else o.literal_adaptation[index] = kPalette[value];
+        return DIVANS_SUCCESS;
+    };
+    switch (selector) {
+    case DIVANS_OPTION_QUALITY: case DIVANS_OPTION_LGBLOCK: case DIVANS_OPTION_STRIDE_DETECTION_QUALITY:
+    case DIVANS_OPTION_PRIOR_BITMASK_DETECTION: case DIVANS_OPTION_SPEED_DETECTION_QUALITY:
+    case DIVANS_OPTION_BROTLI_LITERAL_BYTE_SCORE: case DIVANS_OPTION_Q9_5: case DIVANS_OPTION_FORCE_LITERAL_CONTEXT_MODE:
+    case DIVANS_OPTION_IR_OPTIMIZER:
+        return DIVANS_SUCCESS;   // brotli front-end knobs: stored by the reference, never read by the literal-only compressor
+    case DIVANS_OPTION_WINDOW_SIZE: o.window_size = (int)value; return DIVANS_SUCCESS;
+    case DIVANS_OPTION_DYNAMIC_CONTEXT_MIXING: o.dynamic_context_mixing = (uint8_t)value; return DIVANS_SUCCESS;
+    case DIVANS_OPTION_USE_BROTLI_COMMAND_SELECTION: if (value > 2) return DIVANS_FAILURE; o.use_brotli = (int)value; return DIVANS_SUCCESS;
+    case DIVANS_OPTION_USE_BROTLI_BITSTREAM: if (value != 1) return DIVANS_FAILURE; o.use_brotli = 2; return DIVANS_SUCCESS;
+    case DIVANS_OPTION_USE_CONTEXT_MAP: if (value > 1) return DIVANS_FAILURE; o.use_context_map = value == 1; return DIVANS_SUCCESS;
+    case DIVANS_OPTION_FORCE_STRIDE_VALUE: if (value > 8) return DIVANS_FAILURE; o.force_stride = (uint8_t)value; return DIVANS_SUCCESS;
+    case DIVANS_OPTION_LITERAL_ADAPTATION_STRIDE_HIGH: return set_speed(1);
+    case DIVANS_OPTION_LITERAL_ADAPTATION_CM_HIGH: return set_speed(3);
+    case DIVANS_OPTION_LITERAL_ADAPTATION_STRIDE_LOW: return set_speed(0);
+    case DIVANS_OPTION_LITERAL_ADAPTATION_CM_LOW: return set_speed(2);
+    case DIVANS_OPTION_PRIOR_DEPTH: o.has_prior_depth = true; o.prior_depth = (uint8_t)value; return DIVANS_SUCCESS;
+    default: return DIVANS_FAILURE;
+    }
+}
+
+static bool start(DivansCompressorState* s) {
+    s->started = true;
+    if (s->opt.use_brotli != 0) s->failed = true;   // brotli command selection is out of scope; no silent substitute
+    if (s->opt.dynamic_context_mixing >= 15) s->failed = true;   // codec/interface.rs:359 assert
+    return !s->failed;
+}
+
+static size_t emit_header(DivansCompressorState* s, uint8_t* out, size_t cap) {
+    const int w = s->opt.window_size < 10 ? 10 : (s->opt.window_size > 24 ? 24 : s->opt.window_size);
+    const uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t n = (size_t)(16 - s->header_sent) < cap ? (size_t)(16 - s->header_sent) : cap;
+    std::memcpy(out, hdr + s->header_sent, n);
+    s->header_sent += (int)n;
+    return n;
+}
+
+// src/ffi/mod.rs:70-91 + divans_compressor.rs:276-337
+DivansResult divans_encode(struct DivansCompressorState* s, const uint8_t* in, size_t in_size, size_t* in_off,
+                           uint8_t* out, size_t out_size, size_t* out_off) {
+    if (!s || !in_off || !out_off || *in_off > in_size || *out_off > out_size) return DIVANS_FAILURE;
+    if (!s->started && !start(s)) return DIVANS_FAILURE;
+    if (s->failed || s->built) return DIVANS_FAILURE;          // NotAllowedToEncodeAfterFlush
+    if (s->header_sent < 16) {
+        *out_off += emit_header(s, out + *out_off, out_size - *out_off);
+        if (s->header_sent < 16) return DIVANS_NEEDS_MORE_OUTPUT;
+    }
+    if (in_size > *in_off) s->input.insert(s->input.end(), in + *in_off, in + in_size);
+    *in_off = in_size;
+    return DIVANS_NEEDS_MORE_INPUT;
+}
+
+// src/ffi/mod.rs:94-108 + divans_compressor.rs:363-426
+DivansResult divans_encode_flush(struct DivansCompressorState* s, uint8_t* out, size_t out_size, size_t* out_off) {
+    if (!s || !out_off || *out_off > out_size) return DIVANS_FAILURE;
+    if (!s->started && !start(s)) return DIVANS_FAILURE;
+    if (s->failed) return DIVANS_FAILURE;
+    const bool header_in_this_call = s->header_sent < 16;
+    if (header_in_this_call) {
+        *out_off += emit_header(s, out + *out_off, out_size - *out_off);
+        if (s->header_sent < 16) return DIVANS_NEEDS_MORE_OUTPUT;
+    }
+    if (!s->built) {
+        // The Mux slicing depends on the room the caller gives each call (src/mux.rs:445-476); replay it with this
+        // call's buffer size, which callers keep constant (c/example.c: BUF_SIZE).
+        const size_t call_buffer = out_size ? out_size : 65536;
+        if (divans_host::build_container(s->opt, s->input.data(), s->input.size(), call_buffer, 0, s->stream) != 0) {
+            s->failed = true;
+            return DIVANS_FAILURE;
+        }
+        s->built = true;
+        s->cursor = 16;   // the header already went out through emit_header
+        std::vector<uint8_t>().swap(s->input);
+    }
+    const size_t room = out_size - *out_off, left = s->stream.size() - s->cursor;
+    const size_t n = left < room ? left : room;
+    std::memcpy(out + *out_off, s->stream.data() + s->cursor, n);
+    s->cursor += n; *out_off += n;
+    return s->cursor == s->stream.size() ? DIVANS_SUCCESS : DIVANS_NEEDS_MORE_OUTPUT;
+}
+
+void divans_free_compressor(struct DivansCompressorState* s) {
+    if (!s) return;
+    const CAllocator a = s->alloc;
+    s->~DivansCompressorState();
+    state_free(a, s);
+}
+
+struct DivansDecompressorState* divans_new_decompressor_with_custom_alloc(struct CAllocator alloc, uint8_t skip_crc, uint8_t multithread) {
+    (void)multithread;
+    void* mem = state_alloc(alloc, sizeof(DivansDecompressorState));
+    if (!mem) return nullptr;
+    DivansDecompressorState* s = new (mem) DivansDecompressorState();
+    s->alloc = alloc;
+    s->skip_crc = skip_crc != 0;
+    return s;
+}
+struct DivansDecompressorState* divans_new_decompressor(void) {
+    CAllocator a = {nullptr, nullptr, nullptr};
+    return divans_new_decompressor_with_custom_alloc(a, 0, 1);
+}
+struct DivansDecompressorState* divans_new_serial_decompressor(void) {
+    CAllocator a = {nullptr, nullptr, nullptr};
+    return divans_new_decompressor_with_custom_alloc(a, 0, 0);
+}
+
+// src/ffi/mod.rs:236-262 + divans_decompressor.rs:356-397
+DivansResult divans_decode(struct DivansDecompressorState* s, const uint8_t* in, size_t in_size, size_t* in_off,
+                           uint8_t* out, size_t out_size, size_t* out_off) {
+    if (!s || !in_off || !out_off || *in_off > in_size || *out_off > out_size) return DIVANS_FAILURE;
+    if (s->failed) return DIVANS_FAILURE;
+    if (!s->decoded) {
+        if (in_size > *in_off) s->input.insert(s->input.end(), in + *in_off, in + in_size);
+        *in_off = in_size;
+        // magic / window are checkable as soon as the 16-byte header is in (divans_decompressor.rs:38-52)
+        if (s->input.size() >= 6) {
+            const uint8_t* h = s->input.data();
+            if (h[0] != 0xff || h[1] != 0xe5 || h[2] != 0x8c || h[3] != 0x9f || h[5] < 10 || h[5] >= 25) { s->failed = true; return DIVANS_FAILURE; }
+        }
+        // a complete stream ends with the trailer crc32c || "ans~" (codec/mod.rs:518-554)
+        const size_t n = s->input.size();
+        if (n < 16 + 3 + 8 || std::memcmp(s->input.data() + n - 4, "ans~", 4) != 0) return DIVANS_NEEDS_MORE_INPUT;
+        size_t consumed = 0;
+        const divans_host::ParseStatus st = divans_host::parse_container(s->input.data(), n, s->skip_crc, 0, s->output, &consumed);
+        if (st == divans_host::PARSE_NEED_MORE) return DIVANS_NEEDS_MORE_INPUT;   // "ans~" occurred inside the payload
+        if (st != divans_host::PARSE_OK) { s->failed = true; return DIVANS_FAILURE; }
+        s->decoded = true;
+        std::vector<uint8_t>().swap(s->input);
+    }
+    const size_t room = out_size - *out_off, left = s->output.size() - s->cursor;
+    const size_t n = left < room ? left : room;
+    if (n) std::memcpy(out + *out_off, s->output.data() + s->cursor, n);
+    s->cursor += n; *out_off += n;
+    return s->cursor == s->output.size() ? DIVANS_SUCCESS : DIVANS_NEEDS_MORE_OUTPUT;
+}
+
+void divans_free_decompressor(struct DivansDecompressorState* s) {
+    if (!s) return;
+    const CAllocator a = s->alloc;
+    s->~DivansDecompressorState();
+    state_free(a, s);
+}
+
+// src/ffi/mod.rs:111-145,276-309
+uint8_t* divans_compressor_malloc_u8(struct DivansCompressorState* s, size_t n) { return (uint8_t*)state_alloc(s->alloc, n); }
+void divans_compressor_free_u8(struct DivansCompressorState* s, uint8_t* p, size_t) { state_free(s->alloc, p); }
+size_t* divans_compressor_malloc_usize(struct DivansCompressorState* s, size_t n) { return (size_t*)state_alloc(s->alloc, n * sizeof(size_t)); }
+void divans_compressor_free_usize(struct DivansCompressorState* s, size_t* p, size_t) { state_free(s->alloc, p); }
+uint8_t* divans_decompressor_malloc_u8(struct DivansDecompressorState* s, size_t n) { return (uint8_t*)state_alloc(s->alloc, n); }
+void divans_decompressor_free_u8(struct DivansDecompressorState* s, uint8_t* p, size_t) { state_free(s->alloc, p); }
+size_t* divans_decompressor_malloc_usize(struct DivansDecompressorState* s, size_t n) { return (size_t*)state_alloc(s->alloc, n * sizeof(size_t)); }
+void divans_decompressor_free_usize(struct DivansDecompressorState* s, size_t* p, size_t) { state_free(s->alloc, p); }
+
+}  // extern "C"

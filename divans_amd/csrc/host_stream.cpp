@@ -1,0 +1,665 @@
+// host_stream.cpp -- CMD-coder side, Mux, header and trailer of a literal-only .divans stream (host, C++).
+// Product code: it links the HIP literal coder (capi.cpp) for every literal byte and never the CPU oracle.
+//   command type nibble / flush / trailer : src/codec/mod.rs:143-158,409-560,652-792
+//   PredictionMode                         : src/codec/context_map.rs:105-428
+//   BlockSwitchLiteral                     : src/codec/block_type.rs:31-194
+//   literal length                         : src/codec/literal.rs:565-661
+//   Mux                                    : src/mux.rs
+//   header / internal compressor           : src/divans_compressor.rs:126-174,276-426, src/raw_to_cmd/mod.rs:105-181
+#include "host_stream.h"
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <functional>
+#include <memory>
+
+namespace divans_host {
+
+// ---------------------------------------------------------------- CRC-32C (Castagnoli, reflected)
+uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return ~crc;
+}
+
+// ---------------------------------------------------------------- 16-symbol CDF on the host (CMD coder only)
+struct Speed { int16_t inc, lim; };
+static const Speed kMud{0x10, 0x2000}, kSlow{0x20, 0x1000}, kMed{0x30, 0x4000}, kFast{0x60, 0x4000},
+    kPlane{0x80, 0x4000}, kRocket{0x180, 0x4000};   // probability/interface.rs:321-328
+
+static inline int16_t wrap16(int v) { return (int16_t)(uint16_t)v; }
+
+struct Cdf {
+    int16_t c[16];
+    Cdf() { for (int i = 0; i < 16; ++i) c[i] = (int16_t)(4 * (i + 1)); }        // frequentist_cdf.rs:17-23
+    void blend(int sym, Speed s) {                                               // frequentist_cdf.rs:74-85
+        for (int i = sym; i < 16; ++i) c[i] = wrap16(c[i] + s.inc);
+        if (c[15] >= s.lim)
+            for (int i = 0; i < 16; ++i) { int16_t t = wrap16(c[i] + i + 1); c[i] = wrap16(t - (t >> 2)); }
+    }
+    bool range(int sym, int& start, int& freq) const {                           // probability/interface.rs:97-108
+        const int mx = c[15];
+        if (mx == 0) return false;
+        const int hi = ((int)c[sym] << 15) / mx;
+        const int lo = sym ? ((int)c[sym - 1] << 15) / mx : 0;
+        start = wrap16(wrap16(lo) + 1);
+        freq = wrap16(wrap16(hi - lo) - 1);
+        return true;
+    }
+    int find(int offset) const {                                                 // probability/interface.rs:136-198
+        const int16_t r = wrap16(((int)(int16_t)offset * (int)c[15]) >> 15);
+        for (int i = 0; i < 15; ++i) if (r < c[i]) return i;
+        return 15;
+    }
+};
+
+// ---------------------------------------------------------------- rANS on the host (CMD coder only), src/ans.rs
+class RansEncoder {
+  public:
+    std::vector<uint8_t> out;            // finished chunks in decoder order
+    bool failed = false;
+    void put(int start, int freq) {      // ans.rs:287-301
+        pairs_.push_back(((uint32_t)(uint16_t)freq << 16) | (uint16_t)start);
+        if (pairs_.size() == 65536) flush();
+    }
+    void flush() {                       // ans.rs:331-378 + 302-329
+        if (pairs_.empty()) return;
+        std::vector<uint32_t> words;
+        uint64_t a = 1ull << 31, b = 1ull << 31;
+        for (size_t k = pairs_.size(); k-- > 0;) {
+            const int16_t start = (int16_t)(pairs_[k] & 0xffffu), freq = (int16_t)(pairs_[k] >> 16);
+            if (freq <= 0 || start < 0) { failed = true; pairs_.clear(); return; }
+            const uint64_t f = (uint64_t)freq;
+            uint64_t st = a;
+            if (st >= (f << 48)) { words.push_back((uint32_t)st); st >>= 32; }
+            const uint64_t x = ((st / f) << 15) + (st % f) + (uint64_t)start;
+            a = b; b = x;
+        }
+        std::swap(a, b);
+        for (int i = 0; i < 8; ++i) out.push_back((uint8_t)(a >> (8 * i)));
+        for (int i = 0; i < 8; ++i) out.push_back((uint8_t)(b >> (8 * i)));
+        for (size_t w = words.size(); w-- > 0;)
+            for (int i = 0; i < 4; ++i) out.push_back((uint8_t)(words[w] >> (8 * i)));
+        pairs_.clear();
+    }
+  private:
+    std::vector<uint32_t> pairs_;
+};
+
+class RansDecoder {
+  public:
+    RansDecoder(const uint8_t* p, size_t n) : p_(p), n_(n) {}
+    bool starved = false;
+    int get(const Cdf& cdf) {            // ans.rs:246-252, 230-244, refill :428-442
+        fill();
+        const int offset = (int)(a_ & 0x7fffu);
+        const int sym = cdf.find(offset);
+        int start = 1, freq = 1;
+        if (!cdf.range(sym, start, freq)) starved = true;
+        need_a_ = need_b_ | ((count_ == 65535u) ? 8u : 0u);
+        const uint64_t x = (uint64_t)(int64_t)freq * (a_ >> 15) + (a_ & 0x7fffu) - (uint64_t)(int64_t)start;
+        count_ = (uint16_t)(count_ + 1);
+        need_b_ = x < (1ull << 31) ? 1u : 0u;
+        a_ = b_; b_ = x;
+        return sym;
+    }
+  private:
+    void fill() {
+        if (need_a_ == 0) return;
+        if (need_a_ == 1) {
+            if (n_ - pos_ < 4) { starved = true; return; }
+            uint32_t w = 0;
+            for (int i = 0; i < 4; ++i) w |= (uint32_t)p_[pos_ + i] << (8 * i);
+            a_ = (a_ << 32) | w; pos_ += 4; need_a_ = 0;
+            return;
+        }
+        if (n_ - pos_ < 16) { starved = true; return; }
+        a_ = b_ = 0; count_ = 0;
+        for (int i = 0; i < 8; ++i) a_ |= (uint64_t)p_[pos_ + i] << (8 * i);
+        for (int i = 0; i < 8; ++i) b_ |= (uint64_t)p_[pos_ + 8 + i] << (8 * i);
+        pos_ += 16; need_a_ = 0;
+    }
+    const uint8_t* p_; size_t n_, pos_ = 0;
+    uint64_t a_ = 0, b_ = 0; uint16_t count_ = 0; unsigned need_a_ = 8, need_b_ = 0;
+};
+
+// get_or_put_nibble + blend for either direction
+struct NibbleCoder {
+    RansEncoder* enc = nullptr; RansDecoder* dec = nullptr;
+    std::function<void()> before;   // drain_or_fill_internal_buffer_cmd runs before every CMD nibble (e.g. codec/mod.rs:663)
+    int code(int v, Cdf& prior, Speed sp) {
+        if (before) before();
+        if (enc) { int s, f; if (!prior.range(v, s, f)) enc->failed = true; else enc->put(s, f); }
+        else v = dec->get(prior);
+        prior.blend(v, sp);
+        return v;
+    }
+};
+
+// 5.3 mini-float of the speeds, probability/interface.rs:566-585
+static uint8_t speed_to_u8(int16_t d) {
+    const uint16_t u = (uint16_t)d;
+    int length = 0; while (length < 16 && (u >> length) != 0) ++length;
+    int mant = 0;
+    if (d != 0) { const int16_t rem = (int16_t)(d - (int16_t)(1 << (length - 1))); mant = (int16_t)(rem << 3) >> (length - 1); }
+    return (uint8_t)((length << 3) | mant);
+}
+static int16_t u8_to_speed(uint8_t d) {
+    if (d < 8) return 0;
+    const int lg = (d >> 3) - 1;
+    const int16_t rem = (int16_t)(((int16_t)d & 7) << lg);
+    return (int16_t)((int16_t)(1 << lg) | (rem >> 3));
+}
+
+// ---------------------------------------------------------------- command-stream model
+struct PredictionModeIn {                 // what raw_to_cmd hands over (raw_to_cmd/mod.rs:115-143)
+    uint8_t prediction_mode = 0, is_adv = 0;
+    std::vector<uint8_t> literal_context_map, distance_context_map, mixing_values;
+    bool has_context_speeds = false;
+    uint8_t cm_speed[2][2] = {{0, 0}, {0, 0}}, stride_speed[2][2] = {{0, 0}, {0, 0}}, combined_speed[2][2] = {{0, 0}, {0, 0}};
+};
+
+class CommandModel {
+  public:
+    explicit CommandModel(const StreamOptions& o) {
+        lit_len.resize(4096 + 3 * 256);
+        last_4_states = 3 << 4;                                   // codec/interface.rs:374
+        for (auto& l : btype_lru) { l[0] = 0; l[1] = 1; }
+        mixing = o.dynamic_context_mixing;
+        if (o.force_stride != 0 && mixing == 0 && o.use_context_map) mixing = 1;   // codec/interface.rs:360-365
+        prior_depth = o.has_prior_depth ? o.prior_depth : 0;
+        do_context_map = o.use_context_map; force_stride = o.force_stride;
+        has_adaptation = o.has_literal_adaptation;
+        for (int i = 0; i < 4; ++i) adaptation[i] = Speed{o.literal_adaptation[i].inc, o.literal_adaptation[i].lim};
+        pm_cmap.assign(DIVANS_GPU_MAX_LITERAL_CONTEXT_MAP_SIZE, 0);
+        pm_mixing.assign(DIVANS_GPU_NUM_MIXING_VALUES, 0);
+        pm_dmap.assign(1024, 0);
+    }
+    // priors (layouts of codec/priors.rs, linearised as priors.rs:211-259)
+    std::array<Cdf, 16> cc;                 // CrossCommandPriors FullSelection(16,1)
+    std::vector<Cdf> lit_len;               // CountSmall(256,16) | SizeBegNib | SizeLastNib | SizeMantissaNib
+    std::array<Cdf, 31> pred;               // Only, LiteralSpeed, FirstNibble(2), SecondNibble(2), Mnemonic(4), PriorMixingValue(17), ContextMapSpeedPalette(4)
+    std::array<Cdf, 10> btype;              // Mnemonic(3) FirstNibble(3) SecondNibble(3) StrideNibble(1)
+    std::array<uint8_t, 13> lru{};          // cmap_lru
+    std::array<std::array<uint8_t, 2>, 3> btype_lru{};
+    std::array<uint8_t, 3> btype_max{};
+    uint8_t last_4_states = 0;
+    uint8_t mixing = 0, prior_depth = 0, force_stride = 9;
+    bool do_context_map = true, has_adaptation = false;
+    Speed adaptation[4];
+    std::vector<uint8_t> pm_cmap, pm_mixing, pm_dmap;     // the codec's own PredictionModeContextMap (persists, context_map.rs:84-94)
+    // result of the last PredictionMode command
+    uint8_t pm_mode = 0, pm_mixing_math = 0;
+    Speed pm_speeds[4] = {kMud, kMud, kMud, kMud};
+
+    int command_type(NibbleCoder& nc, int code) {           // codec/mod.rs:662-688
+        code = nc.code(code, cc[last_4_states >> 4], kRocket);
+        if (code == 3) { last_4_states >>= 2; last_4_states |= 128; }
+        return code;
+    }
+
+    bool prediction_mode(NibbleCoder& nc, const PredictionModeIn* in) {   // context_map.rs:105-428
+        Speed desired[4] = {kMud, kMud, kMud, kMud};
+        if (in && in->has_context_speeds) {
+            for (int i = 0; i < 2; ++i) {
+                if (in->cm_speed[i][0] || in->cm_speed[i][1]) desired[2 + i] = Speed{u8_to_speed(in->cm_speed[i][0]), u8_to_speed(in->cm_speed[i][1])};
+                const uint8_t* st = mixing != 0 ? in->combined_speed[i] : in->stride_speed[i];
+                if (st[0] || st[1]) desired[i] = Speed{u8_to_speed(st[0]), u8_to_speed(st[1])};
+            }
+        }
+        if (has_adaptation) for (int i = 0; i < 4; ++i) desired[i] = adaptation[i];
+        for (int i = 0; i < 13; ++i) lru[i] = (uint8_t)i;
+        const int mode = nc.code(in ? in->prediction_mode : 0, pred[0], kMed);
+        if (mode > 3) return false;
+        pm_mode = (uint8_t)mode;
+        const int is_adv = in ? in->is_adv : 0;
+        // DynamicContextMixingSpeed and PriorDepth are not members of PredictionModePriors: they alias the last entry (offset 27)
+        const int mixnib = nc.code(mixing | (is_adv << 3), pred[27], kMed);
+        pm_mixing_math = (uint8_t)(mixnib & 3);
+        const bool combine = mixnib != 0;
+        nc.code(prior_depth, pred[27], kFast);
+        uint8_t f8[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        for (int index = 0; index < 16; ++index) {
+            const int si = index >> 2, pt = index & 3;
+            const uint8_t f0 = speed_to_u8(desired[si].inc), f1 = speed_to_u8(desired[si].lim);
+            int nib = pt == 0 ? (f0 & 0x7f) >> 3 : pt == 1 ? (f0 & 7) : pt == 2 ? (f1 & 0x7f) >> 3 : (f1 & 7);
+            nib = nc.code(nib, pred[27 + pt], kFast);
+            if (pt == 0) f8[si][0] |= (uint8_t)(nib << 3);
+            if (pt == 1) f8[si][0] |= (uint8_t)nib;
+            if (pt == 2) f8[si][1] |= (uint8_t)(nib << 3);
+            if (pt == 3) f8[si][1] |= (uint8_t)nib;
+        }
+        for (int i = 0; i < 4; ++i)   // stored as f8 again and read back through u8_to_speed (codec/interface.rs:303-308)
+            pm_speeds[i] = Speed{u8_to_speed(speed_to_u8(u8_to_speed(f8[i][0]))), u8_to_speed(speed_to_u8(u8_to_speed(f8[i][1])))};
+        for (int type = 0; type < 2; ++type) {
+            const std::vector<uint8_t>* cur = nullptr;
+            if (in && do_context_map) { if (type == 0) cur = &in->literal_context_map; else if (in->has_context_speeds) cur = &in->distance_context_map; }
+            std::vector<uint8_t>& outmap = type == 0 ? pm_cmap : pm_dmap;
+            for (uint32_t index = 0;; ++index) {
+                int mn = 14;
+                const bool have = cur && index < cur->size();
+                if (have) {
+                    const uint8_t target = (*cur)[index];
+                    mn = 15;
+                    for (int i = 0; i < 13; ++i) if (lru[i] == target) mn = i;
+                    if (target == (uint8_t)(*std::max_element(lru.begin(), lru.end()) + 1)) mn = 13;
+                }
+                mn = nc.code(mn, pred[6 + type], kMed);
+                if (mn == 14) { if (type == 0) for (int i = 0; i < 13; ++i) lru[i] = (uint8_t)i; break; }
+                uint8_t val;
+                if (mn == 15) {
+                    const int msn = nc.code(have ? (*cur)[index] >> 4 : 0, pred[2 + type], kMed);
+                    const int lsn = nc.code(have ? (*cur)[index] & 0xf : 0, pred[4 + type], kMed);
+                    val = (uint8_t)((msn << 4) | lsn);
+                } else {
+                    val = mn == 13 ? (uint8_t)(*std::max_element(lru.begin(), lru.end()) + 1) : lru[(size_t)mn];
+                }
+                if (index >= outmap.size()) return false;
+                outmap[index] = val;
+                touch_lru(val);
+            }
+        }
+        for (uint32_t index = 0; index < DIVANS_GPU_NUM_MIXING_VALUES; ++index) {
+            int nib = !do_context_map ? 4 : (!combine ? 0 : ((in && in->has_context_speeds && !in->mixing_values.empty()) ? in->mixing_values[index] : 0));
+            const int prior = index >= 256 ? (pm_mixing[index - 256] & 0xf) : 16;
+            nib = nc.code(nib, pred[10 + prior], kPlane);
+            pm_mixing[index] = (uint8_t)nib;
+        }
+        return true;
+    }
+
+    void block_switch_literal(NibbleCoder& nc, uint8_t in_btype, uint8_t in_stride, uint8_t& out_btype) {   // block_type.rs:31-194
+        int varint = in_btype == btype_lru[0][1] ? 0 : in_btype == (uint8_t)(btype_max[0] + 1) ? 1 : in_btype <= 12 ? in_btype + 2 : 15;
+        varint = nc.code(varint, btype[0], kSlow);
+        uint8_t bt;
+        if (varint == 0) bt = btype_lru[0][1];
+        else if (varint == 1) bt = (uint8_t)(btype_max[0] + 1);
+        else if (varint == 15) {
+            const int first = nc.code(in_btype & 0xf, btype[3], kSlow);
+            const int second = nc.code(in_btype >> 4, btype[6], kSlow);
+            bt = (uint8_t)((second << 4) | first);
+        } else bt = (uint8_t)(varint - 2);
+        nc.code(force_stride == 9 ? in_stride : force_stride, btype[9], kSlow);
+        last_4_states >>= 2;                                    // obs_btypel, codec/interface.rs:527-537
+        btype_lru[0][1] = btype_lru[0][0]; btype_lru[0][0] = bt;
+        btype_max[0] = std::max(btype_max[0], bt);
+        out_btype = bt;
+    }
+
+    bool literal_length(NibbleCoder& nc, uint32_t len_in, uint32_t& len_out) {   // literal.rs:565-661
+        const uint32_t ctype = btype_lru[1][0], MN = 14;
+        const uint32_t serialized = len_in - (MN + 1);
+        int lllen = 0; while (lllen < 32 && (serialized >> lllen) != 0) ++lllen;
+        const int shortcut = nc.code((int)std::min<uint32_t>(MN, len_in - 1), lit_len[ctype], kMed);
+        if (shortcut == (int)MN + 1) return false;
+        if (shortcut != (int)MN) { len_out = (uint32_t)shortcut + 1; return true; }
+        const int beg = nc.code(std::min(15, lllen), lit_len[4096 + ctype], kMud);
+        int remaining; uint32_t decoded;
+        auto round_up_mod_4 = [](int v) { return ((v - 1) | 3) + 1; };
+        if (beg == 15) {
+            const int last = nc.code((lllen - 15) & 0xf, lit_len[4096 + 256 + ctype], kMud);
+            remaining = round_up_mod_4(last + 14); decoded = 1u << (last + 14);
+        } else if (beg <= 1) { len_out = MN + 1 + (uint32_t)beg; return true; }
+        else { remaining = round_up_mod_4(beg - 1); decoded = 1u << (beg - 1); }
+        for (;;) {
+            const int next = remaining - 4;
+            const int nib = nc.code((int)(((serialized ^ decoded) >> next) & 0xf), lit_len[4096 + 512 + ctype], kMud);
+            decoded |= (uint32_t)nib << next;
+            if (next == 0) { len_out = decoded + MN + 1; return true; }
+            remaining = next;
+        }
+    }
+
+    void fill_lit_config(divans_lit_config& cfg, uint8_t bt) const {   // obs_prediction_mode_context_map, codec/interface.rs:285-319
+        std::memcpy(cfg.literal_context_map, pm_cmap.data(), sizeof(cfg.literal_context_map));
+        std::memcpy(cfg.mixing_mask, pm_mixing.data(), sizeof(cfg.mixing_mask));
+        cfg.prediction_mode = pm_mode; cfg.btype = bt; cfg.context_mixing = pm_mixing_math; cfg.reserved = 0;
+        for (int i = 0; i < 4; ++i) cfg.literal_adaptation[i] = divans_speed{pm_speeds[i].inc, pm_speeds[i].lim};
+    }
+
+  private:
+    void touch_lru(uint8_t val) {          // obs_context_map_for_lru, codec/interface.rs:421-455
+        int found = -1;
+        for (int i = 0; i < 13; ++i) if (lru[i] == val) { found = i; break; }
+        const int shift = found < 0 ? 12 : found;
+        for (int i = shift; i > 0; --i) lru[i] = lru[i - 1];
+        lru[0] = val;
+    }
+};
+
+// ---------------------------------------------------------------- Mux, src/mux.rs
+class Mux {
+  public:
+    struct Stream { std::vector<uint8_t> buf; size_t start = 0, end = 0; size_t avail() const { return end - start; } };
+    Stream s[2];
+    uint32_t leftover = 0; int leftover_stream = 0;
+    size_t last_flush[2] = {0, 0}, bytes_flushed = 0;
+    int eof = 0;
+
+    void prep(int id, size_t len) {       // prep_push_for_n_bytes :285-329
+        Stream& b = s[id];
+        if (b.buf.size() - b.end >= len) return;
+        const size_t have = b.avail();
+        if (b.buf.size() >= have + len + 3 && (b.start == b.end || (b.start >= 16384 && b.start > have + 3))) {
+            std::memmove(b.buf.data() + 3, b.buf.data() + b.start, have);
+            b.end = 3 + have; b.start = 3;
+            return;
+        }
+        const uint64_t desired = 3 + len + have;
+        int lg = 0; while ((desired >> lg) != 0) ++lg;
+        lg = std::max(lg + 1, 9);
+        std::vector<uint8_t> nb((size_t)1 << lg, 0);
+        if (have) std::memcpy(nb.data() + 3, b.buf.data() + b.start, have);
+        b.buf.swap(nb); b.end = 3 + have; b.start = 3;
+    }
+    void push(int id, const uint8_t* p, size_t n) { prep(id, n); std::memcpy(s[id].buf.data() + s[id].end, p, n); s[id].end += n; }
+
+    size_t serialize(uint8_t* out, size_t cap) {   // :445-476
+        size_t off = 0;
+        if (leftover) off += copy_leftover(out, cap);
+        while (off < cap) {
+            bool any = false;
+            const size_t lo = std::min(last_flush[0], last_flush[1]), hi = std::max(last_flush[0], last_flush[1]);
+            for (int i = 0; i < 2; ++i) {
+                const bool lagging = hi > kVariance + last_flush[i];
+                if (s[i].avail() >= chunk_size(last_flush[i], lagging) && last_flush[i] <= lo + kVariance) {
+                    any = true;
+                    emit(i, out, cap, off, lagging);
+                    if (leftover) break;
+                }
+            }
+            if (!any) break;
+        }
+        return off;
+    }
+    size_t close(uint8_t* out, size_t cap) {       // serialize_close :477-518 + flush_internal :519-561
+        if (eof == 3) return 0;
+        size_t off = 0;
+        if (leftover) off += copy_leftover(out, cap);
+        while (off < cap) {
+            bool any = false, have = false; size_t lf = 0;
+            for (int i = 0; i < 2; ++i) {
+                const bool nonempty = s[i].avail() != 0;
+                if (!have ? nonempty : (last_flush[i] < lf && nonempty)) { lf = last_flush[i]; have = true; }
+            }
+            for (int i = 0; i < 2; ++i) {
+                if (!have || last_flush[i] <= lf + kVariance) {
+                    const size_t before = off;
+                    if (s[i].avail()) emit(i, out, cap, off, true);
+                    if (off != before) any = true;
+                    if (leftover) break;
+                }
+            }
+            if (!any) break;
+        }
+        static const uint8_t marker[3] = {0xff, 0xfe, 0xff};
+        for (int st = 0; st < 3; ++st) {
+            if (off == cap) return off;
+            if (eof == st) { out[off++] = marker[st]; eof = st + 1; }
+        }
+        return off;
+    }
+    // deserialize :384-444.  Returns bytes consumed; stops after the EOF marker.
+    size_t deserialize(const uint8_t* in, size_t n) {
+        size_t pos = 0;
+        while (pos < n && eof != 3) {
+            const uint8_t c = in[pos];
+            if (pending == 2) { lsb = c; pending = 3; ++pos; }
+            else if (pending == 3) { count = ((uint32_t)lsb | ((uint32_t)c << 8)) + 1; pending = 1; ++pos; }
+            else if (pending == 1) {
+                const size_t take = std::min<size_t>(count, n - pos);
+                push(pstream, in + pos, take); pos += take; count -= (uint32_t)take;
+                if (count == 0) pending = 0;
+            } else {
+                if (c == 0xff || (c == 0xfe && eof != 0)) {
+                    static const uint8_t marker[3] = {0xff, 0xfe, 0xff};
+                    bool progressed = false;
+                    while (pos < n && eof < 3 && in[pos] == marker[eof]) { ++eof; ++pos; progressed = true; }
+                    if (!progressed || eof == 3 || pos < n) return pos;
+                    continue;
+                }
+                pstream = c & 1;
+                if (c < 16) { pending = 2; ++pos; }
+                else { count = 1024u << ((c >> 4) << 1); pending = 1; ++pos; }
+            }
+        }
+        return pos;
+    }
+
+  private:
+    static constexpr size_t kVariance = 131073;
+    int pending = 0, pstream = 0; uint32_t count = 0; uint8_t lsb = 0;
+    static size_t chunk_size(size_t last, bool lagging) { return lagging ? 16 : last <= 1024 ? 4096 : last <= 65536 ? 16384 : 65536; }
+    size_t copy_leftover(uint8_t* out, size_t cap) {
+        const size_t n = std::min<size_t>(leftover, cap);
+        Stream& b = s[leftover_stream];
+        std::memcpy(out, b.buf.data() + b.start, n); b.start += n; leftover -= (uint32_t)n;
+        return n;
+    }
+    static int header_for(int id, size_t n, bool lagging, uint8_t hdr[3], size_t& count) {   // get_code :55-78
+        if (!lagging || n == 4096 || n == 16384 || n >= 65536) {
+            if (n < 4096) return header_for(id, n, true, hdr, count);
+            if (n < 16384) { hdr[0] = (uint8_t)(id | 0x10); count = 4096; return 1; }
+            if (n < 65536) { hdr[0] = (uint8_t)(id | 0x20); count = 16384; return 1; }
+            hdr[0] = (uint8_t)(id | 0x30); count = 65536; return 1;
+        }
+        hdr[0] = (uint8_t)id; hdr[1] = (uint8_t)((n - 1) & 0xff); hdr[2] = (uint8_t)((n - 1) >> 8); count = n;
+        return 3;
+    }
+    void emit(int id, uint8_t* out, size_t cap, size_t& off, bool lagging) {   // serialize_stream_id :339-382
+        Stream& b = s[id];
+        uint8_t hdr[3]; size_t count;
+        const int hl = header_for(id, b.avail(), lagging, hdr, count);
+        bytes_flushed += count;
+        const size_t total = count + (size_t)hl;
+        b.start -= (size_t)hl;
+        std::memcpy(b.buf.data() + b.start, hdr, (size_t)hl);
+        last_flush[id] = bytes_flushed;
+        const size_t n = std::min(total, cap - off);
+        std::memcpy(out + off, b.buf.data() + b.start, n);
+        b.start += n;
+        if (b.start == b.end) { b.start = 3; b.end = 3; }
+        off += n;
+        if (n != total) { leftover = (uint32_t)(total - n); leftover_stream = id; }
+    }
+};
+
+// ---------------------------------------------------------------- output as the caller sees it: one buffer per call
+class CallSink {
+  public:
+    CallSink(std::vector<uint8_t>& out, size_t call_buffer) : out_(out), buf_(call_buffer ? call_buffer : 65536) {}
+    size_t room() { if (used_ == buf_) used_ = 0; return buf_ - used_; }   // a full buffer = NeedsMoreOutput, the caller returns with a new one
+    uint8_t* reserve(size_t n) { out_.resize(out_.size() + n); return out_.data() + out_.size() - n; }
+    void commit(size_t reserved, size_t used) { out_.resize(out_.size() - (reserved - used)); used_ += used; }
+    void new_call() { used_ = 0; }
+  private:
+    std::vector<uint8_t>& out_; size_t buf_, used_ = 0;
+};
+
+// drain_or_fill_static_buffer for an encoder, codec/interface.rs:868-895
+static void drain(Mux& mux, CallSink& sink, int id, const std::vector<uint8_t>& coder_out, size_t avail_end, size_t& drained) {
+    while (drained < avail_end) {
+        const size_t room = sink.room();
+        uint8_t* p = sink.reserve(room);
+        const size_t n = mux.serialize(p, room);
+        sink.commit(room, n);
+        mux.prep(0, 16); mux.prep(1, 16);                                 // write_buffer :184-204
+        Mux::Stream& b = mux.s[id];
+        const size_t take = std::min(avail_end - drained, b.buf.size() - b.end);
+        std::memcpy(b.buf.data() + b.end, coder_out.data() + drained, take);
+        b.end += take; drained += take;
+    }
+}
+
+struct GpuCodecHandle {
+    divans_gpu_codec* c = nullptr;
+    ~GpuCodecHandle() { if (c) divans_gpu_codec_destroy(c); }
+};
+
+int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
+                    std::vector<uint8_t>& out) {
+    out.clear();
+    const int w = std::min(24, std::max(10, opt.window_size));
+    const size_t ring = (size_t)1 << w;
+    CommandModel model(opt);
+    RansEncoder cmd;
+    NibbleCoder nc; nc.enc = &cmd;
+    // the command list of the literal-only internal compressor, raw_to_cmd/mod.rs:105-181
+    PredictionModeIn pm;
+    pm.literal_context_map.resize(64); for (int i = 0; i < 64; ++i) pm.literal_context_map[i] = (uint8_t)(i & 0x3f);
+    pm.distance_context_map = {0, 1, 2, 3};
+    pm.mixing_values.assign(DIVANS_GPU_NUM_MIXING_VALUES, 4);
+    pm.has_context_speeds = true;
+
+    // 1. the literal stream on the GPU (all Literal commands share one LIT coder and one set of priors).
+    // Its configuration is a function of the PredictionMode command alone, so a scratch model codes that command
+    // once to learn it; the real CMD stream is produced in step 2 in event order.
+    std::vector<uint8_t> lit; std::vector<uint32_t> chunk_bytes;
+    if (n) {
+        if (n > 0x7fffffffu) return DIVANS_GPU_EINVAL;
+        CommandModel probe(opt);
+        RansEncoder scratch;
+        NibbleCoder pn; pn.enc = &scratch;
+        probe.command_type(pn, 7);
+        if (!probe.prediction_mode(pn, &pm)) return DIVANS_GPU_EINVAL;
+        auto cfg = std::make_unique<divans_lit_config>();
+        probe.fill_lit_config(*cfg, 0);
+        GpuCodecHandle h;
+        int rc = divans_gpu_codec_create(&h.c, cfg.get(), device, nullptr, (uint32_t)n);
+        if (rc) return rc;
+        (void)divans_gpu_codec_set_geometry(h.c, 1, 0xffffffffu);   // one stream: one workgroup's worth of tables is plenty
+        const uint32_t max_chunks = (uint32_t)((2 * n + 65535) / 65536);
+        lit.resize(divans_gpu_lit_encode_bound(n) + 64);
+        chunk_bytes.assign(max_chunks, 0);
+        uint64_t off = 0; uint32_t size = 0; size_t total = 0;
+        rc = divans_gpu_lit_encode_host_chunks(h.c, input, (uint32_t)n, 1, lit.data(), lit.size(), &off, &size, &total,
+                                               chunk_bytes.data(), max_chunks);
+        if (rc) return rc;
+        lit.resize(size);
+    }
+    // 2. replay the encoder's event sequence through the Mux
+    Mux mux;
+    CallSink sink(out, call_buffer);
+    {   // header in the first encode() call, divans_compressor.rs:126-131,150-174
+        uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        size_t done = 0;
+        while (done < 16) { const size_t room = sink.room(), k = std::min<size_t>(16 - done, room); std::memcpy(sink.reserve(k), hdr + done, k); sink.commit(k, k); done += k; }
+        sink.new_call();   // encode() returned NeedsMoreInput; everything below happens in flush() calls
+    }
+    size_t cmd_drained = 0, lit_drained = 0, lit_avail = 0;
+    uint64_t lit_syms = 0; size_t chunk_idx = 0;
+    auto drain_cmd = [&]() { drain(mux, sink, 0, cmd.out, cmd.out.size(), cmd_drained); };
+    auto drain_lit = [&]() { drain(mux, sink, 1, lit, lit_avail, lit_drained); };
+    nc.before = drain_cmd;
+    model.command_type(nc, 7);
+    if (!model.prediction_mode(nc, &pm)) return DIVANS_GPU_EINVAL;
+    for (size_t pos = 0; pos < n; pos += ring) {
+        const size_t len = std::min(ring, n - pos);
+        model.command_type(nc, 3);
+        uint32_t len_out;
+        if (!model.literal_length(nc, (uint32_t)len, len_out)) return DIVANS_GPU_EINVAL;
+        drain_lit();
+        // every 65 536th LIT symbol flushes a chunk, drained right after that nibble (literal.rs:309-315,368-374)
+        uint64_t end_syms = lit_syms + 2 * (uint64_t)len;
+        while ((lit_syms / 65536 + 1) * 65536 <= end_syms) {
+            lit_syms = (lit_syms / 65536 + 1) * 65536;
+            lit_avail += chunk_bytes[chunk_idx++];
+            drain_lit();
+        }
+        lit_syms = end_syms;
+    }
+    // DivansCodec::flush, codec/mod.rs:424-554
+    model.command_type(nc, 0xf);
+    drain_cmd(); drain_lit();                       // EncodedShutdownNode
+    cmd.flush();                                    // ShutdownCoder(0)
+    if (chunk_idx < chunk_bytes.size()) lit_avail += chunk_bytes[chunk_idx++];   // ShutdownCoder(1): the partial last chunk
+    drain_cmd(); drain_lit();                       // CoderBufferDrain
+    if (cmd.failed || lit_avail != lit.size()) return DIVANS_GPU_EINVAL;
+    while (mux.eof != 3) {                          // MuxDrain
+        const size_t room = sink.room();
+        uint8_t* p = sink.reserve(room);
+        const size_t k = mux.close(p, room);
+        sink.commit(room, k);
+    }
+    const uint32_t crc = crc32c(0, out.data(), out.size());
+    const uint8_t tr[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
+    out.insert(out.end(), tr, tr + 8);
+    return 0;
+}
+
+ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed) {
+    out.clear();
+    if (n < 16) return PARSE_NEED_MORE;
+    if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f) return PARSE_CORRUPT;   // divans_decompressor.rs:38-52
+    if (in[5] < 10 || in[5] >= 25) return PARSE_CORRUPT;
+    Mux mux;
+    const size_t used = mux.deserialize(in + 16, n - 16);
+    if (mux.eof != 3) return (16 + used < n) ? PARSE_CORRUPT : PARSE_NEED_MORE;
+    if (n - 16 - used < 8) return PARSE_NEED_MORE;
+    const uint8_t* tr = in + 16 + used;
+    const uint32_t crc = crc32c(0, in, 16 + used);
+    const uint8_t want[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
+    if (std::memcmp(tr + 4, want + 4, 4) != 0) return PARSE_CORRUPT;               // codec/mod.rs:949-1017
+    if (!skip_crc && std::memcmp(tr, want, 4) != 0) return PARSE_CORRUPT;
+    if (consumed) *consumed = 16 + used + 8;
+    // CMD stream on the host
+    StreamOptions o;
+    CommandModel model(o);
+    RansDecoder cd(mux.s[0].buf.data() + mux.s[0].start, mux.s[0].avail());
+    NibbleCoder nc; nc.dec = &cd;
+    uint8_t btype = 0; bool have_pm = false, seen_literal = false;
+    uint64_t total = 0;
+    auto cfg = std::make_unique<divans_lit_config>();
+    for (;;) {
+        const int code = model.command_type(nc, 0);
+        if (cd.starved) return PARSE_CORRUPT;
+        if (code == 0xf) break;
+        if (code == 7) {
+            // a second PredictionMode after literal bytes would change the literal coder's tables mid-stream:
+            // the batch kernels code one configuration per stream
+            if (seen_literal) return PARSE_UNSUPPORTED;
+            if (!model.prediction_mode(nc, nullptr)) return PARSE_CORRUPT;
+            have_pm = true;
+        } else if (code == 4) {
+            if (seen_literal) return PARSE_UNSUPPORTED;
+            model.block_switch_literal(nc, 0, 0, btype);
+        } else if (code == 3) {
+            uint32_t len;
+            if (!model.literal_length(nc, 15, len)) return PARSE_CORRUPT;
+            total += len; seen_literal = true;
+            if (total > 0x7fffffffu) return PARSE_UNSUPPORTED;
+        } else return PARSE_UNSUPPORTED;   // Copy / Dict / command- and distance- block switches
+        if (cd.starved) return PARSE_CORRUPT;
+    }
+    if (total == 0) return PARSE_OK;
+    if (have_pm) model.fill_lit_config(*cfg, btype);
+    else {   // LiteralBookKeeping::new defaults, codec/interface.rs:244-262
+        std::memset(cfg.get(), 0, sizeof(*cfg));
+        cfg->btype = btype;
+        for (auto& s : cfg->literal_adaptation) s = divans_speed{0x10, 0x2000};
+    }
+    GpuCodecHandle h;
+    if (divans_gpu_codec_create(&h.c, cfg.get(), device, nullptr, (uint32_t)total)) return PARSE_GPU_ERROR;
+    (void)divans_gpu_codec_set_geometry(h.c, 1, 0xffffffffu);
+    // the kernels read whole 32-bit words; LIT streams are 16 + 4k bytes per chunk by construction
+    std::vector<uint8_t> lit(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
+    if (lit.size() % 4) return PARSE_CORRUPT;
+    lit.resize(lit.size() + 64, 0);
+    const uint64_t off = 0; const uint32_t size = (uint32_t)(lit.size() - 64);
+    out.resize(total);
+    if (divans_gpu_lit_decode_host(h.c, lit.data(), &off, &size, 1, out.data(), (uint32_t)total)) return PARSE_GPU_ERROR;
+    return PARSE_OK;
+}
+
+}  // namespace divans_host

@@ -1,0 +1,39 @@
+// host_stream.h -- host side of a literal-only .divans stream (product code, C++; no oracle involved).
+// The command stream (CMD coder), the two-stream Mux, header and CRC-32C trailer are serial, branchy,
+// a few percent of the symbols: they stay on the host, while every literal byte
+// goes through the HIP kernels.  Citations are relative to the reference tree.
+#ifndef DIVANS_HOST_STREAM_H_
+#define DIVANS_HOST_STREAM_H_
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/divans_gpu.h"
+
+namespace divans_host {
+
+struct StreamOptions {            // DivansCompressorOptions, src/interface.rs:444-484 (fields the literal-only path reads)
+    int window_size = 22;
+    uint8_t dynamic_context_mixing = 1;
+    bool has_prior_depth = false; uint8_t prior_depth = 0;
+    bool use_context_map = true;
+    uint8_t force_stride = 9;     // StrideSelection: 0..8, 9 = UseBrotliRec
+    bool has_literal_adaptation = false; divans_speed literal_adaptation[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int use_brotli = 1;           // BrotliCompressionSetting (only 0 = internal command selection is implemented)
+};
+
+// Builds the complete container for `input` exactly as the reference's literal-only internal compressor would
+// (src/divans_compressor.rs:276-426 + src/raw_to_cmd/mod.rs:105-181), `call_buffer` = size of the output buffer
+// the caller hands to each flush call (the Mux slicing depends on it, src/mux.rs:445-476).
+// Literal bytes are coded on GPU `device`.  Returns 0 or a DIVANS_GPU_E* code.
+int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
+                    std::vector<uint8_t>& out);
+
+enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
+// Decodes a complete container (header .. "ans~").  PARSE_NEED_MORE when `n` bytes do not yet hold the whole stream.
+ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed);
+
+uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n);   // src/codec/crc32.rs
+
+}  // namespace divans_host
+#endif

@@ -46,6 +46,7 @@ struct LitBatch {
 struct RansBatch {
     const uint32_t* sf; uint32_t n_streams, stream_len, max_stream_len; const uint32_t* in_sizes;
     uint8_t* out; uint64_t out_slot; uint64_t* out_offsets; uint32_t* out_sizes; uint32_t* status;
+    uint32_t* chunk_bytes; uint32_t max_chunks;   // optional [n_streams][max_chunks] coded size of every 65 536-symbol chunk
 };
 
 uint32_t lit_lds_bytes(const LitBatch& b);

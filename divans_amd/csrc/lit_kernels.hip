@@ -394,6 +394,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
     const uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
     uint8_t* slot_end = b.out + (uint64_t)(s + 1) * b.out_slot;
     uint32_t* wp = (uint32_t*)slot_end;
+    uint32_t* chunk_top = wp;
     uint32_t bad = 0;
     // chunk k covers symbols [k*65536, min((k+1)*65536, nsym)); later chunks sit later in the stream
     uint32_t nchunks = (nsym + 65535u) >> 16;
@@ -413,6 +414,10 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
         uint64_t fa = bst, fb = a;
         *--wp = (uint32_t)(fb >> 32); *--wp = (uint32_t)fb;
         *--wp = (uint32_t)(fa >> 32); *--wp = (uint32_t)fa;
+        if (b.chunk_bytes) {   // bytes of chunk ck (the host replays the reference's per-chunk Mux drains with these)
+            b.chunk_bytes[(size_t)s * b.max_chunks + ck] = (uint32_t)((uint8_t*)chunk_top - (uint8_t*)wp);
+            chunk_top = wp;
+        }
     }
     uint64_t off = (uint64_t)((uint8_t*)wp - b.out);
     b.out_offsets[s] = off;

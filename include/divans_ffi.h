@@ -1,0 +1,93 @@
+/*
+ * divans_ffi.h -- per-stream C ABI, a drop-in for the reference's c/divans/ffi.h:6-66
+ * (Rust side: src/ffi/mod.rs, src/ffi/interface.rs, src/ffi/compressor.rs, src/ffi/decompressor.rs).
+ * Same names, argument meaning and return codes.  The literal bytes of the stream are coded by the
+ * MI355X kernels (include/divans_gpu.h); command stream, Mux, header and CRC trailer are host code.
+ *
+ * Scope: the literal-only internal compressor, i.e. what the reference does with
+ * DIVANS_OPTION_USE_BROTLI_COMMAND_SELECTION = 0 (src/ffi/compressor.rs:73-78,168-178).  Option values that
+ * select the brotli front end are accepted by divans_set_option (as in the reference) but the first
+ * divans_encode() then fails: brotli command generation is out of scope and there is no CPU fallback.
+ * The state buffers the whole input and produces the stream in the divans_encode_flush() calls; the
+ * decompressor accepts literal-only streams (one PredictionMode before the first Literal).
+ */
+#ifndef DIVANS_FFI_H_
+#define DIVANS_FFI_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint8_t DivansResult;
+#define DIVANS_SUCCESS ((uint8_t)0)
+#define DIVANS_NEEDS_MORE_INPUT ((uint8_t)1)
+#define DIVANS_NEEDS_MORE_OUTPUT ((uint8_t)2)
+#define DIVANS_FAILURE ((uint8_t)3)
+
+typedef uint8_t DivansOptionSelect;          /* src/ffi/interface.rs:16-37 */
+#define DIVANS_OPTION_QUALITY 1
+#define DIVANS_OPTION_WINDOW_SIZE 2
+#define DIVANS_OPTION_LGBLOCK 3
+#define DIVANS_OPTION_DYNAMIC_CONTEXT_MIXING 4
+#define DIVANS_OPTION_USE_BROTLI_COMMAND_SELECTION 5
+#define DIVANS_OPTION_USE_BROTLI_BITSTREAM 6
+#define DIVANS_OPTION_USE_CONTEXT_MAP 7
+#define DIVANS_OPTION_LITERAL_ADAPTATION_CM_HIGH 8
+#define DIVANS_OPTION_FORCE_STRIDE_VALUE 9
+#define DIVANS_OPTION_STRIDE_DETECTION_QUALITY 10
+#define DIVANS_OPTION_PRIOR_DEPTH 11
+#define DIVANS_OPTION_LITERAL_ADAPTATION_STRIDE_HIGH 12
+#define DIVANS_OPTION_LITERAL_ADAPTATION_CM_LOW 13
+#define DIVANS_OPTION_LITERAL_ADAPTATION_STRIDE_LOW 14
+#define DIVANS_OPTION_BROTLI_LITERAL_BYTE_SCORE 15
+#define DIVANS_OPTION_SPEED_DETECTION_QUALITY 16
+#define DIVANS_OPTION_PRIOR_BITMASK_DETECTION 17
+#define DIVANS_OPTION_Q9_5 18
+#define DIVANS_OPTION_FORCE_LITERAL_CONTEXT_MODE 19
+#define DIVANS_OPTION_IR_OPTIMIZER 20        /* present in src/ffi/interface.rs:37, missing from c/divans/ffi.h */
+
+/* src/ffi/interface.rs:40-47: all three NULL => libc malloc/free */
+struct CAllocator {
+    void *(*alloc_func)(void *opaque, size_t length);
+    void (*free_func)(void *opaque, void *mfd);
+    void *opaque;
+};
+struct DivansDecompressorState;
+struct DivansCompressorState;
+
+struct DivansCompressorState *divans_new_compressor(void);                                           /* mod.rs:18-24 */
+struct DivansCompressorState *divans_new_compressor_with_custom_alloc(struct CAllocator alloc);       /* mod.rs:27-52 */
+DivansResult divans_set_option(struct DivansCompressorState *state, DivansOptionSelect selector, uint32_t value); /* mod.rs:58-67 */
+DivansResult divans_encode(struct DivansCompressorState *state, const uint8_t *input_buf_ptr, size_t input_size,
+                           size_t *input_offset, uint8_t *output_buf_ptr, size_t output_size, size_t *output_offset); /* mod.rs:70-91 */
+DivansResult divans_encode_flush(struct DivansCompressorState *state, uint8_t *output_buf_ptr, size_t output_size,
+                                 size_t *output_offset);                                              /* mod.rs:94-108 */
+void divans_free_compressor(struct DivansCompressorState *mfd);                                       /* mod.rs:159-169 */
+
+struct DivansDecompressorState *divans_new_decompressor(void);                                        /* mod.rs:178-187 */
+struct DivansDecompressorState *divans_new_serial_decompressor(void);                                 /* mod.rs:189-198 */
+/* The Rust takes (alloc, skip_crc, multithread) (mod.rs:213-232) although c/divans/ffi.h:61 declares two
+ * arguments; c/example.c (built against that header) passes two, so the third arrives as register garbage:
+ * it is ignored here (there is no worker thread to start -- the literal stream is decoded on the GPU). */
+struct DivansDecompressorState *divans_new_decompressor_with_custom_alloc(struct CAllocator alloc, uint8_t skip_crc,
+                                                                          uint8_t multithread);
+DivansResult divans_decode(struct DivansDecompressorState *state, const uint8_t *input_buf_ptr, size_t input_size,
+                           size_t *input_offset, uint8_t *output_buf_ptr, size_t output_size, size_t *output_offset); /* mod.rs:236-262 */
+void divans_free_decompressor(struct DivansDecompressorState *mfd);                                   /* mod.rs:312-323 */
+
+/* helper allocators through the state's CAllocator, src/ffi/mod.rs:111-145,276-309 */
+uint8_t *divans_compressor_malloc_u8(struct DivansCompressorState *state, size_t size);
+void divans_compressor_free_u8(struct DivansCompressorState *state, uint8_t *data, size_t size);
+size_t *divans_compressor_malloc_usize(struct DivansCompressorState *state, size_t size);
+void divans_compressor_free_usize(struct DivansCompressorState *state, size_t *data, size_t size);
+uint8_t *divans_decompressor_malloc_u8(struct DivansDecompressorState *state, size_t size);
+void divans_decompressor_free_u8(struct DivansDecompressorState *state, uint8_t *data, size_t size);
+size_t *divans_decompressor_malloc_usize(struct DivansDecompressorState *state, size_t size);
+void divans_decompressor_free_usize(struct DivansDecompressorState *state, size_t *data, size_t size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -91,6 +91,11 @@ int divans_gpu_pack_streams(divans_gpu_codec *c, const uint8_t *d_slots, const u
 int divans_gpu_lit_encode_host(divans_gpu_codec *c, const uint8_t *in, uint32_t stream_len, uint32_t n_streams,
                                uint8_t *out_packed, size_t out_cap, uint64_t *out_offsets, uint32_t *out_sizes,
                                size_t *out_total);
+/* same, additionally returning out_chunk_bytes[i*max_chunks + k] = coded bytes of the k-th 65 536-symbol chunk of stream i
+ * (the unit ANSEncoder hands to the Mux, src/ans.rs:331-378) */
+int divans_gpu_lit_encode_host_chunks(divans_gpu_codec *c, const uint8_t *in, uint32_t stream_len, uint32_t n_streams,
+                                      uint8_t *out_packed, size_t out_cap, uint64_t *out_offsets, uint32_t *out_sizes,
+                                      size_t *out_total, uint32_t *out_chunk_bytes, uint32_t max_chunks);
 int divans_gpu_lit_decode_host(divans_gpu_codec *c, const uint8_t *in_packed, const uint64_t *in_offsets,
                                const uint32_t *in_sizes, uint32_t n_streams, uint8_t *out, uint32_t stream_len);
 

@@ -557,7 +557,7 @@ void orc_stream_options_default(orc_stream_options *o) { /* src/interface.rs:463
     o->call_buffer_size = 65536;
 }
 
-size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command *cmds, size_t n_cmds, uint8_t *out, size_t cap) {
+static size_t stream_compress_impl(const orc_stream_options *o, const orc_stream_command *cmds, size_t n_cmds, uint8_t *out, size_t cap, int header_in_own_call) {
     enc_ctx e;
     memset(&e, 0, sizeof(e));
     orc_ans_encoder_init(&e.cmd); orc_ans_encoder_init(&e.lit);
@@ -580,6 +580,9 @@ size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command
             memcpy(sink_ptr(&e.out, n), hdr + written, n);
             sink_commit(&e.out, n); written += n;
         }
+        /* divans_encode(): the header goes out in the encode() call, which returns NeedsMoreInput while the ring
+         * buffer is not full (raw_to_cmd/mod.rs:55-104); everything else is produced by the flush() calls */
+        if (header_in_own_call) e.out.call_used = 0;
     }
     uint8_t btype = 0; uint8_t mixing = c->desired_context_mixing;
     for (size_t k = 0; k < n_cmds && !bad; ++k) {
@@ -633,6 +636,10 @@ size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command
     return ret;
 }
 
+size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command *cmds, size_t n_cmds, uint8_t *out, size_t cap) {
+    return stream_compress_impl(o, cmds, n_cmds, out, cap, 0);   /* encode_commands(): header and commands share the call */
+}
+
 /* The literal-only internal compressor (use_brotli = UseInternalCommandSelection): raw_to_cmd/mod.rs:105-181
  * emits [PredictionMode][Literal per ring-buffer span].  Input shorter than the ring arrives as one Literal. */
 size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, size_t n, uint8_t *out, size_t cap) {
@@ -655,7 +662,7 @@ size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, s
         cmds[1 + i].len = (i + 1 < nlit) ? ring : n - i * ring;
     }
     /* an empty input still flushes a PredictionMode command (has_produced_header, raw_to_cmd/mod.rs:114-143) */
-    size_t r = orc_stream_compress(o, cmds, nlit + 1, out, cap);
+    size_t r = stream_compress_impl(o, cmds, nlit + 1, out, cap, 1);
     free(cmds);
     return r;
 }
