@@ -45,9 +45,9 @@ def cpu_baseline(cfg_name, workload, corpus, block_len, seconds_target=15.0):
         lib = po.lib()
     cfg = po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
     cores = os.cpu_count() or 1
-    # ~5 MB/s/core encode+decode: size the sample for roughly seconds_target of wall time
-    per_core = max(4, int(seconds_target * 5e6 / block_len))
-    n = min(cores * per_core, 8192)
+    # one stream per worker thread at a time; ~2-5 MB/s/thread encode+decode => ~10-30 s for 64 streams of 64 KiB each
+    per_core = max(4, int(64 * 65536 / max(block_len, 1)))
+    n = cores * per_core
     blocks = workload.make_blocks(corpus, 0, n, block_len=block_len)
     enc = ctypes.c_double(0); dec = ctypes.c_double(0); coded = ctypes.c_uint64(0)
     t0 = time.time()
@@ -95,17 +95,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    from divans_amd import sharding
     N, L = args.streams, args.block_len
+    first, last = sharding.shard_bounds(N * world, rank, world)   # weak scaling: every rank owns N streams of the job's N*world
+    assert last - first == N
     corpus = workload.load_corpus()
     if args.diag_data == "zeros":
         d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev)
     elif args.diag_data == "random":
         d_in = torch.randint(0, 256, (N, L), dtype=torch.uint8, device=dev)
     elif args.diag_data == "repeat1k":
-        d_in = make_device_blocks(torch, workload, corpus, rank * N, N, L, dev)
+        d_in = make_device_blocks(torch, workload, corpus, first, N, L, dev)
         d_in = d_in[:, :1024].repeat(1, L // 1024).contiguous()
     else:
-        d_in = make_device_blocks(torch, workload, corpus, rank * N, N, L, dev)   # rank r owns blocks [r*N, (r+1)*N)
+        d_in = make_device_blocks(torch, workload, corpus, first, N, L, dev)
     cfg = da.config_simple() if args.config == "simple" else da.config_context_mixing()
     codec = da.LiteralCodec(cfg, L, device=local_rank)
     if args.blocks_per_cu:
@@ -146,10 +149,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dev)
 
     sizes = outs["sizes"].to(torch.int64)
     coded_total = int(sizes.sum().item())
@@ -164,12 +164,8 @@ def main():
             ref = po.lit_encode(ocfg, d_in[i].cpu().numpy())
             got = outs["out"][int(offs[i]):int(offs[i]) + int(sz[i])].cpu().numpy()
             ok = ok and got.size == ref.size and bool((got == ref).all())
-    if world > 1:
-        t = torch.tensor([coded_total, int(ok)], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        coded_all, ok_all = int(t[0].item()), int(t[1].item()) == world
-    else:
-        coded_all, ok_all = coded_total, ok
+    coded_all, ok_count = sharding.sum_over_ranks([coded_total, int(ok)], dev)
+    ok_all = ok_count == world
 
     if rank == 0:
         K = args.steps

@@ -193,17 +193,20 @@ class LiteralCodec:
                     offsets=t.empty(n_streams, dtype=t.int64, device=dev),
                     sizes=t.empty(n_streams, dtype=t.int32, device=dev))
 
-    def encode_batch(self, d_in, n_streams, stream_len, outputs):
-        """d_in: uint8 tensor of n_streams*stream_len bytes (stream i = rows i).  Fills outputs in place."""
+    def encode_batch(self, d_in, n_streams, stream_len, outputs, in_offsets=None, in_sizes=None):
+        """d_in: uint8 tensor of n_streams*stream_len bytes (stream i = rows i), or ragged streams located by the
+        int64 `in_offsets` / int32 `in_sizes` device tensors (then stream_len = the longest).  Fills outputs in place."""
         _check(self._lib.divans_gpu_lit_encode_batch(
-            self._h, d_in.data_ptr(), None, None, int(stream_len), int(n_streams),
+            self._h, d_in.data_ptr(), in_offsets.data_ptr() if in_offsets is not None else None,
+            in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams),
             outputs["out"].data_ptr(), int(outputs["slot"]), outputs["offsets"].data_ptr(),
             outputs["sizes"].data_ptr()), "divans_gpu_lit_encode_batch")
 
-    def decode_batch(self, d_coded, d_offsets, d_sizes, n_streams, stream_len, d_out):
+    def decode_batch(self, d_coded, d_offsets, d_sizes, n_streams, stream_len, d_out, out_offsets=None, out_sizes=None):
         _check(self._lib.divans_gpu_lit_decode_batch(
             self._h, d_coded.data_ptr(), d_offsets.data_ptr(), d_sizes.data_ptr(), int(n_streams),
-            d_out.data_ptr(), None, None, int(stream_len)), "divans_gpu_lit_decode_batch")
+            d_out.data_ptr(), out_offsets.data_ptr() if out_offsets is not None else None,
+            out_sizes.data_ptr() if out_sizes is not None else None, int(stream_len)), "divans_gpu_lit_decode_batch")
 
     def pack(self, outputs, n_streams):
         t = self._torch

@@ -212,7 +212,7 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     c->cfg = *cfg;
-    c->max_stream_len = max_stream_len;
+    c->max_stream_len = (max_stream_len + 1u) & ~1u;   // even: keeps every stream's start/freq spill 16-byte aligned
     std::vector<uint8_t> blob;
     int rc = derive_geometry(*cfg, c->geom, blob);
     if (rc) { delete c; return rc; }

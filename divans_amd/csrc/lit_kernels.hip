@@ -391,7 +391,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
     if (s >= b.n_streams) return;
     const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
     const uint32_t nsym = 2u * len;
-    const uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
+    const uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;   // 16-byte aligned: max_stream_len*8 bytes per stream
     uint8_t* slot_end = b.out + (uint64_t)(s + 1) * b.out_slot;
     uint32_t* wp = (uint32_t*)slot_end;
     uint32_t* chunk_top = wp;
@@ -399,16 +399,30 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
     // chunk k covers symbols [k*65536, min((k+1)*65536, nsym)); later chunks sit later in the stream
     uint32_t nchunks = (nsym + 65535u) >> 16;
     for (uint32_t ck = nchunks; ck-- > 0;) {
-        uint32_t beg = ck << 16;
-        uint32_t end = beg + 65536u < nsym ? beg + 65536u : nsym;
+        const uint32_t beg = ck << 16;
+        const uint32_t end = beg + 65536u < nsym ? beg + 65536u : nsym;
         uint64_t a = 1ull << 31, bst = 1ull << 31;
-        for (uint32_t i = end; i-- > beg;) {
-            uint32_t p = sf[i];
-            uint32_t start = p & 0xffffu, freq = p >> 16;
+        uint32_t i = end;
+        // symbols are taken newest first; the two states alternate, so consecutive symbols are independent chains
+        auto put = [&](uint32_t p) {
+            const uint32_t start = p & 0xffffu;
+            uint32_t freq = p >> 16;
             bad |= (freq == 0u) | (freq >> 15) | (start >> 15);
             freq = freq ? freq : 1u;
-            uint64_t x = rans_put(a, start, freq, wp);
+            const uint64_t x = rans_put(a, start, freq, wp);
             a = bst; bst = x;
+        };
+        while (i > beg && (i & 3u)) put(sf[--i]);             // ragged tail (nsym is even, so 0 or 2 symbols)
+        if (i > beg) {
+            // 16-byte groups, the next group is requested before the current one is coded
+            uint4 cur = *(const uint4*)(sf + i - 4);
+            while (i > beg) {
+                i -= 4;
+                uint4 nxt = cur;
+                if (i > beg) nxt = *(const uint4*)(sf + i - 4);
+                put(cur.w); put(cur.z); put(cur.y); put(cur.x);
+                cur = nxt;
+            }
         }
         // unconditional swap (ans.rs:354-356), then [state_a][state_b] little-endian in front of the words
         uint64_t fa = bst, fb = a;

@@ -85,3 +85,59 @@ def test_row_cache_sizes_bit_exact(cfg_name, cache_rows, corpus, shuffle384):
     blocks[3] = np.resize(shuffle384, 20000)
     blocks[4] = np.random.default_rng(1).integers(0, 256, 20000, dtype=np.uint8)
     _compare(cfg_name, blocks, cache_rows=cache_rows, blocks_grid=2)
+
+
+def test_decode_only_random_then_unicode(random_then_unicode):
+    # BASELINE.json configs[3]: random_then_unicode pre-encoded under the config-3 options as ceil(291949/65536) = 5
+    # blocks (the last one ragged), replicated in device memory, decoded on the GPU, every copy checked bit-exactly
+    import torch
+    import divans_amd as da
+    data = random_then_unicode
+    assert data.size == 291949
+    L, copies = 65536, 96
+    ocfg = po.config_context_mixing()
+    pieces = [data[i:i + L] for i in range(0, data.size, L)]
+    coded = [po.lit_encode(ocfg, p) for p in pieces]
+    dev = torch.device("cuda", 0)
+    offs, sizes, blob, pos = [], [], [], 0
+    for _ in range(copies):
+        for c in coded:
+            offs.append(pos); sizes.append(c.size); blob.append(c); pos += c.size      # sizes are multiples of 4
+    d_coded = torch.from_numpy(np.concatenate(blob + [np.zeros(64, np.uint8)])).to(dev)
+    n = len(offs)
+    out_sizes = [p.size for p in pieces] * copies
+    out_offs = np.concatenate([[0], np.cumsum(out_sizes)[:-1]])
+    d_out = torch.zeros(int(sum(out_sizes)) + 64, dtype=torch.uint8, device=dev)
+    codec = da.LiteralCodec(da.config_context_mixing(), L)
+    codec.decode_batch(d_coded, torch.tensor(offs, dtype=torch.int64, device=dev), torch.tensor(sizes, dtype=torch.int32, device=dev), n, L,
+                       d_out, torch.tensor(out_offs, dtype=torch.int64, device=dev), torch.tensor(out_sizes, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()[:sum(out_sizes)].reshape(copies, data.size)
+    assert (got == data[None, :]).all()
+    codec.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_ragged_batch_device_api(cfg_name, corpus):
+    # ragged streams through the device-pointer entry points (offsets/sizes arrays), incl. an empty stream
+    import torch
+    import divans_amd as da
+    dev = torch.device("cuda", 0)
+    lens = [0, 1, 777, 65536, 40000, 3, 32768, 32770, 12345]
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    flat = corpus[1000:1000 + sum(lens)].copy()
+    d_in = torch.from_numpy(np.concatenate([flat, np.zeros(64, np.uint8)])).to(dev)
+    codec = da.LiteralCodec(da.config_simple() if cfg_name == "simple" else da.config_context_mixing(), max(lens))
+    outs = codec.alloc_encode_outputs(len(lens))
+    d_off = torch.tensor(starts, dtype=torch.int64, device=dev); d_sz = torch.tensor(lens, dtype=torch.int32, device=dev)
+    codec.encode_batch(d_in, len(lens), max(lens), outs, in_offsets=d_off, in_sizes=d_sz)
+    d_back = torch.zeros(sum(lens) + 64, dtype=torch.uint8, device=dev)
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], len(lens), max(lens), d_back, out_offsets=d_off, out_sizes=d_sz)
+    torch.cuda.synchronize()
+    assert (d_back.cpu().numpy()[:sum(lens)] == flat).all()
+    offs = outs["offsets"].cpu().numpy(); szs = outs["sizes"].cpu().numpy(); blob = outs["out"].cpu().numpy()
+    ocfg = _oracle_cfg(cfg_name)
+    for i, (s0, ln) in enumerate(zip(starts, lens)):
+        ref = po.lit_encode(ocfg, flat[s0:s0 + ln])
+        assert szs[i] == ref.size and (blob[offs[i]:offs[i] + szs[i]] == ref).all(), i
+    codec.close()
