@@ -184,6 +184,14 @@ static int derive_geometry(const divans_lit_config& cfg, LitGeometry& g, std::ve
 static uint32_t resident_groups(const divans_gpu_codec* c) { return c->blocks * (LIT_THREADS / 16); }
 
 static int ensure_tables(divans_gpu_codec* c) {
+    // big geometries (many context columns / planes) shrink the persistent grid instead of asking for hundreds of GB:
+    // at most a quarter of the device memory that is free right now, and never less than one workgroup
+    size_t free_b = 0, total_b = 0;
+    const size_t per_block = (size_t)(LIT_THREADS / 16) * c->geom.total_rows * 32u;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && c->tables_bytes == 0) {
+        const size_t budget = std::max<size_t>(free_b / 4, per_block);
+        if ((size_t)c->blocks * per_block > budget) c->blocks = (uint32_t)std::max<size_t>(1, budget / per_block);
+    }
     const size_t need = (size_t)resident_groups(c) * c->geom.total_rows * 32u;
     if (need <= c->tables_bytes) return 0;
     if (c->d_tables) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }

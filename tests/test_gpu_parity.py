@@ -141,3 +141,74 @@ def test_ragged_batch_device_api(cfg_name, corpus):
         ref = po.lit_encode(ocfg, flat[s0:s0 + ln])
         assert szs[i] == ref.size and (blob[offs[i]:offs[i] + szs[i]] == ref).all(), i
     codec.close()
+
+
+def _random_config(rng, da, mixing, modes, mm_values, speeds):
+    """A configuration a brotli-driven stream could carry: arbitrary context map, per-context mixing values
+    (stride 1/2/3/4/8, half-byte, no-prior, context-only), lossy palette speeds, any prediction mode."""
+    import ctypes
+    g = da.LitConfig()
+    o = po.LitConfig()
+    cmap = rng.integers(0, 48, size=256 * 64, dtype=np.uint8)
+    mix = rng.choice(np.array(mm_values, dtype=np.uint8), size=8192)
+    for cfg in (g, o):
+        ctypes.memmove(cfg.literal_context_map, cmap.ctypes.data, cmap.size)
+        ctypes.memmove(cfg.mixing_mask, mix.ctypes.data, mix.size)
+        cfg.prediction_mode = int(modes)
+        cfg.btype = int(rng.integers(0, 4))
+        cfg.context_mixing = mixing
+        for i in range(4):
+            cfg.literal_adaptation[i].inc = speeds[i][0]
+            cfg.literal_adaptation[i].lim = speeds[i][1]
+        rng_state = rng.bit_generator.state   # keep g and o identical: same btype
+        o.btype = g.btype
+    return g, o
+
+
+@pytest.mark.parametrize("mixing", [0, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_generic_mixing_mask_and_context_maps(mixing, mode, corpus, random_then_unicode):
+    # the MM = -1 / table-driven path: every branch of code_nibble's index math (mm_opts 0,1,2,3,4,5,6,7,8 and beyond)
+    import divans_amd as da
+    rng = np.random.default_rng(100 * mixing + mode)
+    speeds = [(16, 8192), (64, 16384), (2, 1024), (128, 16384)]
+    value_sets = [[0, 1, 2, 3, 4, 5, 6, 7, 8], [4, 5, 8, 12], [0, 3], [1, 2, 4]]
+    for vs in value_sets:
+        g, o = _random_config(rng, da, mixing, mode, vs, speeds)
+        L = 6000
+        blocks = np.stack([corpus[3000:3000 + L], random_then_unicode[100000:100000 + L], random_then_unicode[200000:200000 + L],
+                           np.resize(np.frombuffer(b"abcabcabd", dtype=np.uint8), L)])
+        codec = da.LiteralCodec(g, L)
+        packed, offs, sizes = codec.encode_host(blocks, L)
+        for i in range(blocks.shape[0]):
+            ref = po.lit_encode(o, blocks[i])
+            got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
+            assert got.size == ref.size and (got == ref).all(), (vs, i)
+        assert (codec.decode_host(packed, offs, sizes, L) == blocks).all()
+        codec.close()
+
+
+def test_uniform_mm0_specialisation(corpus):
+    # mixing value 0 everywhere (reference TestAdapt, benchmark.rs:182-193): the MM = 0 kernel instances
+    import ctypes
+    import divans_amd as da
+    g = da.config_context_mixing(); o = po.config_context_mixing()
+    for cfg in (g, o):
+        ctypes.memset(cfg.mixing_mask, 0, 8192)
+        cfg.context_mixing = 0
+        cfg.prediction_mode = 0
+    blocks = workload.make_blocks(corpus, 9, 6, block_len=9000)
+    codec = da.LiteralCodec(g, 9000)
+    packed, offs, sizes = codec.encode_host(blocks, 9000)
+    for i in range(6):
+        assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == po.lit_encode(o, blocks[i])).all()
+    assert (codec.decode_host(packed, offs, sizes, 9000) == blocks).all()
+    codec.close()
+
+
+def test_unsupported_speed_is_rejected():
+    import divans_amd as da
+    g = da.config_simple()
+    g.literal_adaptation[0].inc = 0x4000; g.literal_adaptation[0].lim = 0x4000   # inc + lim would wrap an i16 CDF total
+    with pytest.raises(da.DivansGpuError):
+        da.LiteralCodec(g, 1024)
