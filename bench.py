@@ -181,6 +181,14 @@ def main():
         # hands 4 B per nibble to the rANS pass; the rANS pass reads that spill and writes C
         alg = {"lit_decode_kernel": raw + coded, "lit_model_encode_kernel": raw + 8 * raw, "rans_encode_kernel": 8 * raw + coded}[dom]
         achieved = alg / 1e9 / (kern[dom] / 1e3)
+        # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes of this same workload, committed under profiles/
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tj.get("streams") == N and tj.get("block_bytes") == L and tj.get("config") == args.config:
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -194,7 +202,7 @@ def main():
             "encode_MBps": round(N * L / 1e6 / (avg(enc_ms) / 1e3), 2), "decode_MBps": round(N * L / 1e6 / (avg(dec_ms) / 1e3), 2),
             "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg},
         }
         if not args.no_cpu_baseline:
