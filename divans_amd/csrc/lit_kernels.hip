@@ -313,6 +313,34 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
     return packed;
 }
 
+struct FetchedRow { RowRef ref; int value; bool is_default; };
+
+template <bool HIGH, int MM, bool CACHE>
+__device__ __forceinline__ FetchedRow fetch_row(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb,
+                                                uint32_t ctx, uint64_t last8, uint32_t hi_nib) {
+    const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
+    FetchedRow f;
+    f.value = tb.load(rs.stride_row, f.ref);
+    f.is_default = (MM < 0 || MM == 2) && rs.is_default;
+    return f;
+}
+
+// (start | freq << 16) of `sym` under the fetched row, then blend + store: the non-mixing half of code_nibble
+template <bool CACHE>
+__device__ __forceinline__ uint32_t model_finish(const LitGeometry& g, const Table<CACHE>& tb, int li, int rbase,
+                                                 const FetchedRow& f, int sym) {
+    const int cv = f.is_default ? 4 * (li + 1) : f.value;
+    const int mx = row_bcast<15>(cv);
+    const uint32_t d = scaled_div(cv, mx, biased_rcp15(mx));
+    const int dprev = row_prev_or_zero((int)d);
+    const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
+    const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
+    int st = f.value;
+    if (!f.is_default) st = blend_row(st, li, sym, g.inc0, g.lim0);
+    if (CACHE || !f.is_default) tb.store(f.ref, st);
+    return packed;
+}
+
 template <int MM, bool CTXC, bool MIX, bool CACHE>
 __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -333,20 +361,45 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
         // each lane holds one literal byte of the current and of the next 16-byte window (coalesced reads)
         uint32_t mine = ((uint32_t)li < len) ? in[li] : 0u;
         uint32_t nxt = (16u + li < len) ? in[16u + li] : 0u;
+        // Non-mixing path: every symbol is known, so each row is requested one nibble ahead (right after the previous
+        // row of the SAME table has been stored) and the model math of one nibble runs under the fetch of the next.
+        uint32_t cur = (uint32_t)row_gather((int)mine, rbase, 0);
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
+        FetchedRow rowH = {}, rowL = {};
+        if (!MIX) {
+            rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
+            rowL = fetch_row<false, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, cur >> 4);
+        }
         for (uint32_t base = 0; base < len; base += 16) {
             const uint32_t cnt = len - base < 16u ? len - base : 16u;
             uint32_t pend_a = 0, pend_b = 0;  // lane k keeps the two pairs of byte base+k
             for (uint32_t k = 0; k < cnt; ++k) {
-                const uint32_t byte = (uint32_t)row_gather((int)mine, rbase, (int)k);
-                const uint32_t prev = (uint32_t)(last8 >> 56);
-                const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
-                if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
-                const uint32_t hi = byte >> 4, lo = byte & 15u;
-                const uint32_t ph = model_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, (int)hi, wh);
-                const uint32_t pl = model_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, (int)lo, wl);
-                last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-                pend_a = (uint32_t)li == k ? ph : pend_a;
-                pend_b = (uint32_t)li == k ? pl : pend_b;
+                if (MIX) {
+                    const uint32_t byte = (uint32_t)row_gather((int)mine, rbase, (int)k);
+                    const uint32_t prev = (uint32_t)(last8 >> 56);
+                    const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
+                    if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
+                    const uint32_t hi = byte >> 4, lo = byte & 15u;
+                    const uint32_t ph = model_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, (int)hi, wh);
+                    const uint32_t pl = model_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, (int)lo, wl);
+                    last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                    pend_a = (uint32_t)li == k ? ph : pend_a;
+                    pend_b = (uint32_t)li == k ? pl : pend_b;
+                } else {
+                    const uint32_t byte = cur;
+                    const uint32_t nb = (uint32_t)row_gather((int)(k + 1u < 16u ? mine : nxt), rbase, (int)((k + 1u) & 15u));
+                    const uint32_t ph = model_finish<CACHE>(g, tb, li, rbase, rowH, (int)(byte >> 4));
+                    const uint32_t prev = (uint32_t)(last8 >> 56);
+                    if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
+                    last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                    ctx_cur = context_of<CTXC>(g, lv.ctx, byte, k1);
+                    rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);           // next byte's high row
+                    const uint32_t pl = model_finish<CACHE>(g, tb, li, rbase, rowL, (int)(byte & 15u));
+                    rowL = fetch_row<false, MM, CACHE>(g, lv, tb, ctx_cur, last8, nb >> 4);     // next byte's low row
+                    cur = nb;
+                    pend_a = (uint32_t)li == k ? ph : pend_a;
+                    pend_b = (uint32_t)li == k ? pl : pend_b;
+                }
             }
             // nibble index of byte (base+li) is 2*(base+li): each lane stores its two pairs (8 B; 128 B coalesced per row)
             if ((uint32_t)li < cnt) {
@@ -499,6 +552,34 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const Ld
     return (uint32_t)sym;
 }
 
+// Non-mixing decode, software-pipelined: the symbol search needs only the row and the state's low 15 bits, and the
+// NEXT row's address needs only the symbol -- so the next row is requested right after the search, and the
+// division / (start,freq) gather / state update / blend / store of the current nibble run under that fetch.
+// Two rows are live at a time (the one being finished and the one in flight); they belong to different tables
+// (high vs low nibble), and the 2-way cache never evicts the most recently used way, so they cannot collide.
+__device__ __forceinline__ int search_symbol(int cv, uint32_t slot, int rbase) {
+    const int mx = row_bcast<15>(cv);
+    const int rescaled = (int)((uint32_t)__umul24(slot, (uint32_t)mx) >> 15);
+    const unsigned long long ge = __ballot(rescaled >= cv);
+    return __popc((uint32_t)(ge >> rbase) & 0x7fffu);
+}
+
+template <bool CACHE>
+__device__ __forceinline__ void finish_nibble(const LitGeometry& g, const Table<CACHE>& tb, int li, int rbase,
+                                              const FetchedRow& f, int cv, int sym, uint64_t& S) {
+    const uint32_t slot = (uint32_t)S & 0x7fffu;
+    const int mx = row_bcast<15>(cv);
+    const uint32_t d = scaled_div(cv, mx, biased_rcp15(mx));
+    const int dprev = row_prev_or_zero((int)d);
+    const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
+    const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
+    const uint32_t start = packed & 0xffffu, freq = packed >> 16;
+    S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;     // helper_advance_sym, ans.rs:238
+    int st = f.value;
+    if (!f.is_default) st = blend_row(st, li, sym, g.inc0, g.lim0);
+    if (CACHE || !f.is_default) tb.store(f.ref, st);
+}
+
 template <int MM, bool CTXC, bool MIX, bool CACHE>
 __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -520,6 +601,9 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
         uint64_t last8 = 0;
         uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];
         uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
+        FetchedRow rowH = {};
+        if (!MIX) rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
         for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
             // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
             {
@@ -532,17 +616,37 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                 const uint32_t cnt = cend - base < 16u ? cend - base : 16u;
                 uint32_t outb = 0;
                 for (uint32_t k = 0; k < cnt; ++k) {
-                    const uint32_t prev = (uint32_t)(last8 >> 56);
-                    const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
-                    if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
-                    // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
-                    if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
-                    const uint32_t hi = decode_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, SA, wh);
-                    if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
-                    const uint32_t lo = decode_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, SB, wl);
-                    const uint32_t byte = (hi << 4) | lo;
-                    last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-                    outb = (uint32_t)li == k ? byte : outb;
+                    if (MIX) {
+                        const uint32_t prev = (uint32_t)(last8 >> 56);
+                        const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
+                        if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
+                        // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
+                        if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
+                        const uint32_t hi = decode_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, SA, wh);
+                        if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
+                        const uint32_t lo = decode_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, SB, wl);
+                        const uint32_t byte = (hi << 4) | lo;
+                        last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                        outb = (uint32_t)li == k ? byte : outb;
+                    } else {
+                        // rowH (this byte's high-nibble row) was requested while the previous byte was being finished
+                        if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
+                        const int cvh = rowH.is_default ? 4 * (li + 1) : rowH.value;
+                        const uint32_t hi = (uint32_t)search_symbol(cvh, (uint32_t)SA & 0x7fffu, rbase);
+                        const FetchedRow rowL = fetch_row<false, MM, CACHE>(g, lv, tb, ctx_cur, last8, hi);
+                        finish_nibble<CACHE>(g, tb, li, rbase, rowH, cvh, (int)hi, SA);
+                        if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
+                        const int cvl = rowL.is_default ? 4 * (li + 1) : rowL.value;
+                        const uint32_t lo = (uint32_t)search_symbol(cvl, (uint32_t)SB & 0x7fffu, rbase);
+                        const uint32_t byte = (hi << 4) | lo;
+                        const uint32_t prev = (uint32_t)(last8 >> 56);
+                        if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
+                        last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                        ctx_cur = context_of<CTXC>(g, lv.ctx, byte, k1);
+                        rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);   // next byte's row (harmless past the end)
+                        finish_nibble<CACHE>(g, tb, li, rbase, rowL, cvl, (int)lo, SB);
+                        outb = (uint32_t)li == k ? byte : outb;
+                    }
                 }
                 if ((uint32_t)li < cnt) out[base + li] = (uint8_t)outb;
             }
