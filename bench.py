@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--config", choices=["simple", "mixing"], default="simple")
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
+    ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--diag-data", choices=["corpus", "zeros", "random", "repeat1k"], default="corpus",
@@ -116,6 +117,9 @@ def main():
         codec.set_geometry(blocks=max(1, int(cus * args.blocks_per_cu)))
     if args.cache_rows >= 0:
         codec.set_geometry(cache_rows=args.cache_rows)
+    if args.split_cache:
+        hi_rows, lo_rows = (int(x) for x in args.split_cache.split(","))
+        codec.set_split_cache(hi_rows, lo_rows)
     outs = codec.alloc_encode_outputs(N, L)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
 

@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-function", "-o", LIB] + os.environ.get("DIVANS_EXTRA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)

@@ -99,7 +99,8 @@ struct divans_gpu_codec {
     uint32_t max_stream_len = 0;
     uint32_t num_cus = 256;
     uint32_t blocks = 0;          // persistent grid of the model/decode kernels
-    uint32_t cache_rows = 0;      // per-stream LDS row cache (0 = tables accessed in HBM/L2 directly)
+    uint32_t cache_high = 0, cache_low = 0;   // per-stream LDS row caches (rows; 0 = that table is accessed in HBM/L2 directly)
+    bool cache_unified = false;
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
@@ -181,6 +182,15 @@ static int derive_geometry(const divans_lit_config& cfg, LitGeometry& g, std::ve
     return 0;
 }
 
+static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
+    // 0 none, 1 unified, 2 high-nibble rows only, 3 separate high / low caches
+    if (c->cache_high == 0) { b.cache_mode = 0; b.cache_rows_high = b.cache_rows_low = 0; }   // (a low-only cache is not offered)
+    else if (c->cache_unified) { b.cache_mode = 1; b.cache_rows_high = c->cache_high; b.cache_rows_low = 0; }
+    else if (c->cache_low == 0) { b.cache_mode = 2; b.cache_rows_high = c->cache_high; b.cache_rows_low = 0; }
+    else { b.cache_mode = 3; b.cache_rows_high = c->cache_high; b.cache_rows_low = c->cache_low; }
+    b.cache_bytes_per_wg = (LIT_THREADS / 16) * (b.cache_rows_high + b.cache_rows_low) * 34u;
+}
+
 static uint32_t resident_groups(const divans_gpu_codec* c) { return c->blocks * (LIT_THREADS / 16); }
 
 static int ensure_tables(divans_gpu_codec* c) {
@@ -227,8 +237,9 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->mix = cfg->context_mixing > 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
-    c->blocks = c->num_cus * 8u;  // 32 waves = 128 streams per CU, 32-row LDS cache each (tuned on MI355X)
-    c->cache_rows = c->geom.total_rows < 0x7fffu ? 32u : 0u;
+    c->blocks = c->num_cus * 4u;  // 16 waves = 64 streams per CU (tuned on MI355X)
+    // high-nibble rows only: few and hot (32 ways ~ 90 % of their accesses); mixing configurations keep one unified cache
+    if (c->geom.total_rows < 0x7fffu) { c->cache_high = 64u; c->cache_low = 0u; c->cache_unified = c->mix; }
     if (hipMalloc(&c->d_blob, LIT_BLOB_BYTES) != hipSuccess || hipMalloc(&c->d_status, 64) != hipSuccess) {
         delete c; return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed");
     }
@@ -251,15 +262,25 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     delete c;
 }
 
+static bool valid_cache_rows(uint32_t r) { return r == 0 || (r >= 16 && r <= 256 && (r & (r - 1)) == 0); }
+
 extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t cache_rows) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (cache_rows != 0xffffffffu) {
-        if (cache_rows != 0 && (cache_rows < 32 || (cache_rows & (cache_rows - 1)) != 0 || cache_rows > 256))
-            return fail(DIVANS_GPU_EINVAL, "cache_rows must be 0 or a power of two in [32, 256]");
+        if (!valid_cache_rows(cache_rows)) return fail(DIVANS_GPU_EINVAL, "cache_rows must be 0 or a power of two in [16, 256]");
         if (cache_rows && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
-        c->cache_rows = cache_rows;
+        c->cache_high = cache_rows; c->cache_low = 0; c->cache_unified = cache_rows != 0;
     }
     if (blocks) c->blocks = blocks;
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_set_split_cache(divans_gpu_codec* c, uint32_t high_rows, uint32_t low_rows) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (!valid_cache_rows(high_rows) || !valid_cache_rows(low_rows)) return fail(DIVANS_GPU_EINVAL, "cache rows must be 0 or a power of two in [16, 256]");
+    if (high_rows == 0 && low_rows != 0) return fail(DIVANS_GPU_EINVAL, "a low-nibble cache needs a high-nibble cache");
+    if ((high_rows || low_rows) && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
+    c->cache_high = high_rows; c->cache_low = low_rows; c->cache_unified = false;
     return 0;
 }
 
@@ -304,7 +325,7 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
     b.sf = c->d_sf;
-    b.cache_rows = c->cache_rows; b.cache_bytes_per_wg = (LIT_THREADS / 16) * c->cache_rows * 34u;
+    set_cache_fields(c, b);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -333,7 +354,7 @@ extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes;
-    b.cache_rows = c->cache_rows; b.cache_bytes_per_wg = (LIT_THREADS / 16) * c->cache_rows * 34u;
+    set_cache_fields(c, b);
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));

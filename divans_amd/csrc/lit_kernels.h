@@ -39,8 +39,10 @@ struct LitBatch {
     const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
     uint8_t* out; const uint64_t* out_offsets; const uint32_t* out_sizes;
     uint32_t* sf;               // encode only: [n_streams][2*max_stream_len]
-    uint32_t cache_rows;        // rows of the per-stream LDS row cache (power of two >= 32, or 0 = no cache)
-    uint32_t cache_bytes_per_wg;  // 16 * cache_rows * (32 + 2)
+    uint32_t cache_rows_high;   // rows of the per-stream LDS cache for high-nibble rows (power of two >= 16, or 0)
+    uint32_t cache_rows_low;    // same for low-nibble rows (ignored when cache_unified)
+    uint32_t cache_mode;        // 0 none, 1 unified (cache_rows_high rows serve both tables), 2 high-nibble rows only, 3 separate high / low
+    uint32_t cache_bytes_per_wg;  // 16 * (rows_high + rows_low) * (32 + 2)
 };
 
 struct RansBatch {

@@ -71,36 +71,45 @@ __device__ __forceinline__ uint32_t scaled_div(int c, int d, float rcp_lo) {
 }
 
 // Per-row view of the stream's CDF table: SRD of the workgroup's table slab + this lane's byte offset,
-// fronted (CACHE) by a private 2-way set-associative write-back row cache in LDS:
+// fronted (CACHE) by private 2-way set-associative write-back row caches in LDS, one for the rows of the
+// high-nibble table and one for the low-nibble table (they may alias = one unified cache, or the low one may be
+// absent: high-nibble rows are few and hot -- 32 ways hold ~90 % of their accesses -- while low-nibble rows are many):
 //   tag word per set = way0 row id (15 bits) | way1 row id << 15 | MRU way << 31, 0x7fff = empty way.
 // Every table access of the coder is a read-modify-write of one whole row, so a cached row is always dirty;
 // a miss writes the victim row back to HBM and fetches the new one.
 struct RowRef { uint32_t row; uint32_t slot_addr; };
+constexpr uint32_t kNoSlot = 0xffffffffu;
 
-template <bool CACHE>
+struct CacheDesc {
+    uint32_t data_off;   // LDS byte offset of this stream's cached rows + 2 * lane-in-row
+    uint32_t tag_off;    // LDS byte offset of this stream's tag words
+    uint32_t set_mask;   // sets - 1, or 0xffffffff when this table is not cached
+};
+
+template <int CACHE>   // 0: no LDS cache, 1: one unified cache, 2: high-nibble rows only, 3: separate high / low caches
 struct Table {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t lane_off;   // row-of-lanes slab offset + 2 * lane-in-row
     uint8_t* lds;        // workgroup LDS base
-    uint32_t data_off;   // LDS byte offset of this stream's cached rows + 2 * lane-in-row
-    uint32_t tag_off;    // LDS byte offset of this stream's tag words
-    uint32_t set_mask;   // sets - 1
+    CacheDesc ch, cl;    // high-nibble / low-nibble table
     __device__ __forceinline__ int gload(uint32_t row) const {
         return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, 0);
     }
     __device__ __forceinline__ void gstore(uint32_t row, int v) const {
         __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, rsrc, lane_off + (row << 5), 0, 0);
     }
-    __device__ __forceinline__ int load(uint32_t row, RowRef& ref) const {
+    __device__ __forceinline__ int load(uint32_t row, RowRef& ref, bool high) const {
         ref.row = row;
-        if (!CACHE) return gload(row);
-        const uint32_t set = (row ^ (row >> 4) ^ (row >> 9)) & set_mask;
-        uint32_t* tagp = (uint32_t*)(lds + tag_off + (set << 2));
+        ref.slot_addr = kNoSlot;
+        if (CACHE == 0 || (CACHE == 2 && !high)) return gload(row);
+        const CacheDesc& d = (CACHE == 1 || high) ? ch : cl;
+        const uint32_t set = (row ^ (row >> 4) ^ (row >> 9)) & d.set_mask;
+        uint32_t* tagp = (uint32_t*)(lds + d.tag_off + (set << 2));
         uint32_t tp = *tagp;
         const uint32_t t0 = tp & 0x7fffu, t1 = (tp >> 15) & 0x7fffu;
         const bool h0 = t0 == row, h1 = t1 == row;
         const uint32_t way = h0 ? 0u : (h1 ? 1u : ((tp >> 31) ^ 1u));
-        ref.slot_addr = data_off + (((set << 1) + way) << 5);
+        ref.slot_addr = d.data_off + (((set << 1) + way) << 5);
         int v = (int)*(uint16_t*)(lds + ref.slot_addr);
         if (!(h0 || h1)) {
             const uint32_t victim = way ? t1 : t0;
@@ -112,13 +121,17 @@ struct Table {
         return v;
     }
     __device__ __forceinline__ void store(const RowRef& ref, int v) const {
-        if (CACHE) *(uint16_t*)(lds + ref.slot_addr) = (uint16_t)v;
+        if (CACHE == 0) gstore(ref.row, v);
+        else if (CACHE == 1 || CACHE == 3) *(uint16_t*)(lds + ref.slot_addr) = (uint16_t)v;
+        else if (ref.slot_addr != kNoSlot) *(uint16_t*)(lds + ref.slot_addr) = (uint16_t)v;   // CACHE == 2: slot_addr is compile-time known per call site
         else gstore(ref.row, v);
     }
     // start of a stream: every way empty
     __device__ __forceinline__ void reset_cache(int li) const {
-        if (!CACHE) return;
-        for (uint32_t s = (uint32_t)li; s <= set_mask; s += 16u) *(uint32_t*)(lds + tag_off + (s << 2)) = 0x3fffffffu;
+        if (CACHE == 0) return;
+        for (uint32_t s = (uint32_t)li; s <= ch.set_mask; s += 16u) *(uint32_t*)(lds + ch.tag_off + (s << 2)) = 0x3fffffffu;
+        if (CACHE == 3)
+            for (uint32_t s = (uint32_t)li; s <= cl.set_mask; s += 16u) *(uint32_t*)(lds + cl.tag_off + (s << 2)) = 0x3fffffffu;
     }
 };
 
@@ -236,7 +249,7 @@ __device__ __forceinline__ LdsView load_config_to_lds(uint8_t* lds, const LitBat
 }
 
 // Fill this stream's table with default rows (ffi/alloc_util.rs:77-79: allocations are default-initialised).
-template <bool CACHE>
+template <int CACHE>
 __device__ __forceinline__ void init_table(const Table<CACHE>& t, uint32_t rows, int li) {
     // row = 16 x i16 = two 16-byte halves; even lanes write the first half, odd lanes the second
     u32x4 lo = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
@@ -259,7 +272,7 @@ __device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8
     return lds_ctx[LIT_BLOB_CTXF + (prev << 3) + k1];
 }
 
-template <bool CACHE>
+template <int CACHE>
 __device__ __forceinline__ Table<CACHE> make_table(const LitBatch& b, uint8_t* lds, int li) {
     const uint32_t slab = b.geom.total_rows * 32u;           // bytes of one stream's table
     Table<CACHE> t;
@@ -267,25 +280,30 @@ __device__ __forceinline__ Table<CACHE> make_table(const LitBatch& b, uint8_t* l
                                                0, (LIT_THREADS / 16) * slab, 0x00020000);
     t.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
     t.lds = lds;
-    const uint32_t per_stream = b.cache_rows * 32u + b.cache_rows * 2u;   // rows + one tag word per 2-way set
-    t.data_off = (threadIdx.x >> 4) * per_stream + 2u * (uint32_t)li;
-    t.tag_off = (threadIdx.x >> 4) * per_stream + b.cache_rows * 32u;
-    t.set_mask = (b.cache_rows >> 1) - 1u;
+    // per-stream LDS region: [high rows][high tags][low rows][low tags]; a unified cache aliases low onto high
+    const uint32_t hi_bytes = b.cache_rows_high * 34u, lo_bytes = CACHE == 3 ? b.cache_rows_low * 34u : 0u;
+    const uint32_t base = (threadIdx.x >> 4) * (hi_bytes + lo_bytes);
+    t.ch.data_off = base + 2u * (uint32_t)li;
+    t.ch.tag_off = base + b.cache_rows_high * 32u;
+    t.ch.set_mask = (b.cache_rows_high >> 1) - 1u;
+    t.cl.data_off = base + hi_bytes + 2u * (uint32_t)li;
+    t.cl.tag_off = base + hi_bytes + b.cache_rows_low * 32u;
+    t.cl.set_mask = (b.cache_rows_low >> 1) - 1u;
     return t;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Encode, pass 1: adaptive model.  bytes -> (start | freq << 16) per nibble.
 // ---------------------------------------------------------------------------------------------
-template <bool HIGH, int MM, bool MIX, bool CACHE>
+template <bool HIGH, int MM, bool MIX, int CACHE>
 __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb, int li, int rbase,
                                                  uint32_t ctx, uint64_t last8, uint32_t hi_nib, int sym, Weights& w) {
     const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
     RowRef sref, cref;
-    int st = tb.load(rs.stride_row, sref);
+    int st = tb.load(rs.stride_row, sref, HIGH);
     uint32_t packed;
     if (MIX) {
-        int cm = tb.load(rs.cm_row, cref);
+        int cm = tb.load(rs.cm_row, cref, HIGH);
         int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
         int p = average_rows(cm, st, cmax, smax, w.norm);
         int pmax = row_bcast<15>(p);
@@ -309,24 +327,24 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
         packed = (uint32_t)row_gather((int)sf, rbase, sym);
     }
     if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0);   // literal_adaptation[0] for both nibbles, literal.rs:320,354
-    if (CACHE || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);   // a cached way must hold its row even when it is not blended
+    if (CACHE != 0 || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);   // a cached way must hold its row even when it is not blended
     return packed;
 }
 
 struct FetchedRow { RowRef ref; int value; bool is_default; };
 
-template <bool HIGH, int MM, bool CACHE>
+template <bool HIGH, int MM, int CACHE>
 __device__ __forceinline__ FetchedRow fetch_row(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb,
                                                 uint32_t ctx, uint64_t last8, uint32_t hi_nib) {
     const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
     FetchedRow f;
-    f.value = tb.load(rs.stride_row, f.ref);
+    f.value = tb.load(rs.stride_row, f.ref, HIGH);
     f.is_default = (MM < 0 || MM == 2) && rs.is_default;
     return f;
 }
 
 // (start | freq << 16) of `sym` under the fetched row, then blend + store: the non-mixing half of code_nibble
-template <bool CACHE>
+template <int CACHE>
 __device__ __forceinline__ uint32_t model_finish(const LitGeometry& g, const Table<CACHE>& tb, int li, int rbase,
                                                  const FetchedRow& f, int sym) {
     const int cv = f.is_default ? 4 * (li + 1) : f.value;
@@ -337,11 +355,11 @@ __device__ __forceinline__ uint32_t model_finish(const LitGeometry& g, const Tab
     const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
     int st = f.value;
     if (!f.is_default) st = blend_row(st, li, sym, g.inc0, g.lim0);
-    if (CACHE || !f.is_default) tb.store(f.ref, st);
+    if (CACHE != 0 || !f.is_default) tb.store(f.ref, st);
     return packed;
 }
 
-template <int MM, bool CTXC, bool MIX, bool CACHE>
+template <int MM, bool CTXC, bool MIX, int CACHE>
 __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
@@ -509,16 +527,16 @@ struct WordWindow {
     }
 };
 
-template <bool HIGH, int MM, bool MIX, bool CACHE>
+template <bool HIGH, int MM, bool MIX, int CACHE>
 __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb, int li, int rbase,
                                                   uint32_t ctx, uint64_t last8, uint32_t hi_nib, uint64_t& S, Weights& w) {
     const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
     RowRef sref, cref;
-    int st = tb.load(rs.stride_row, sref);
+    int st = tb.load(rs.stride_row, sref, HIGH);
     int cm = 0, cmax = 0, smax = 0;
     int cv;
     if (MIX) {
-        cm = tb.load(rs.cm_row, cref);
+        cm = tb.load(rs.cm_row, cref, HIGH);
         cmax = row_bcast<15>(cm); smax = row_bcast<15>(st);
         cv = average_rows(cm, st, cmax, smax, w.norm);
     } else {
@@ -548,7 +566,7 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const Ld
         tb.store(cref, cm);
     }
     if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0);
-    if (CACHE || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);
+    if (CACHE != 0 || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);
     return (uint32_t)sym;
 }
 
@@ -564,7 +582,7 @@ __device__ __forceinline__ int search_symbol(int cv, uint32_t slot, int rbase) {
     return __popc((uint32_t)(ge >> rbase) & 0x7fffu);
 }
 
-template <bool CACHE>
+template <int CACHE>
 __device__ __forceinline__ void finish_nibble(const LitGeometry& g, const Table<CACHE>& tb, int li, int rbase,
                                               const FetchedRow& f, int cv, int sym, uint64_t& S) {
     const uint32_t slot = (uint32_t)S & 0x7fffu;
@@ -577,10 +595,10 @@ __device__ __forceinline__ void finish_nibble(const LitGeometry& g, const Table<
     S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;     // helper_advance_sym, ans.rs:238
     int st = f.value;
     if (!f.is_default) st = blend_row(st, li, sym, g.inc0, g.lim0);
-    if (CACHE || !f.is_default) tb.store(f.ref, st);
+    if (CACHE != 0 || !f.is_default) tb.store(f.ref, st);
 }
 
-template <int MM, bool CTXC, bool MIX, bool CACHE>
+template <int MM, bool CTXC, bool MIX, int CACHE>
 __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
@@ -717,7 +735,7 @@ __global__ void selftest_division_kernel(unsigned long long* mismatches) {
 typedef void (*LitKernel)(const LitBatch);
 
 #define LIT_PICK(KERNEL)                                                                                     \
-    template <bool CACHE>                                                                                    \
+    template <int CACHE>                                                                                     \
     static LitKernel pick_##KERNEL(int mm, bool ctxc, bool mix) {                                            \
         const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 4 + (ctxc ? 2 : 0) + (mix ? 1 : 0);              \
         switch (key) {                                                                                       \
@@ -727,6 +745,14 @@ typedef void (*LitKernel)(const LitBatch);
         case 6: return KERNEL<0, true, false, CACHE>;   case 7: return KERNEL<0, true, true, CACHE>;         \
         case 8: return KERNEL<4, false, false, CACHE>;  case 9: return KERNEL<4, false, true, CACHE>;        \
         case 10: return KERNEL<4, true, false, CACHE>;  default: return KERNEL<4, true, true, CACHE>;        \
+        }                                                                                                    \
+    }                                                                                                        \
+    static LitKernel pick_mode_##KERNEL(int cache_mode, int mm, bool ctxc, bool mix) {                       \
+        switch (cache_mode) {                                                                                \
+        case 1: return pick_##KERNEL<1>(mm, ctxc, mix);                                                      \
+        case 2: return pick_##KERNEL<2>(mm, ctxc, mix);                                                      \
+        case 3: return pick_##KERNEL<3>(mm, ctxc, mix);                                                      \
+        default: return pick_##KERNEL<0>(mm, ctxc, mix);                                                     \
         }                                                                                                    \
     }
 LIT_PICK(lit_model_encode_kernel)
@@ -745,8 +771,7 @@ uint32_t lit_lds_bytes(const LitBatch& b) {
 hipError_t launch_model_encode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
     const LitBatch& b = b_in;
     const int mm = effective_mm(b.geom.mm_uniform);
-    LitKernel k = b.cache_rows ? pick_lit_model_encode_kernel<true>(mm, b.geom.ctx_const >= 0, mix)
-                               : pick_lit_model_encode_kernel<false>(mm, b.geom.ctx_const >= 0, mix);
+    LitKernel k = pick_mode_lit_model_encode_kernel((int)b.cache_mode, mm, b.geom.ctx_const >= 0, mix);
     const uint32_t lds = lit_lds_bytes(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);
@@ -760,8 +785,7 @@ hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
 hipError_t launch_decode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
     const LitBatch& b = b_in;
     const int mm = effective_mm(b.geom.mm_uniform);
-    LitKernel k = b.cache_rows ? pick_lit_decode_kernel<true>(mm, b.geom.ctx_const >= 0, mix)
-                               : pick_lit_decode_kernel<false>(mm, b.geom.ctx_const >= 0, mix);
+    LitKernel k = pick_mode_lit_decode_kernel((int)b.cache_mode, mm, b.geom.ctx_const >= 0, mix);
     const uint32_t lds = lit_lds_bytes(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);

@@ -110,8 +110,10 @@ typedef struct divans_gpu_info {
 } divans_gpu_info;
 int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);
 /* tuning knobs: `blocks` = persistent grid of 256-thread workgroups (0 keeps the current value);
- * `cache_rows` = rows of the per-stream LDS row cache (0 = off, power of two in [32,256], 0xffffffff keeps). */
+ * `cache_rows` = rows of one unified per-stream LDS row cache (0 = off, power of two in [16,256], 0xffffffff keeps). */
 int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t cache_rows);
+/* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */
+int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, uint32_t low_rows);
 
 /* Exhaustive self-check of the reciprocal division used by the kernels against integer '/':
  * returns the number of mismatches over every (cdf<<15)/max with 1<=max<32768, 0<=cdf<=max. */

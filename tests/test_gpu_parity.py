@@ -18,11 +18,13 @@ def _oracle_cfg(cfg_name):
     return po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
 
 
-def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0):
+def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0, split=None):
     n, L = blocks.shape
     da, codec = _codec(cfg_name, max(L, 1))
     if cache_rows is not None or blocks_grid:
         codec.set_geometry(blocks=blocks_grid, cache_rows=cache_rows)
+    if split is not None:
+        codec.set_split_cache(*split)
     packed, offs, sizes = codec.encode_host(blocks, L)
     ocfg = _oracle_cfg(cfg_name)
     for i in range(n):
@@ -85,6 +87,15 @@ def test_row_cache_sizes_bit_exact(cfg_name, cache_rows, corpus, shuffle384):
     blocks[3] = np.resize(shuffle384, 20000)
     blocks[4] = np.random.default_rng(1).integers(0, 256, 20000, dtype=np.uint8)
     _compare(cfg_name, blocks, cache_rows=cache_rows, blocks_grid=2)
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+@pytest.mark.parametrize("split", [(16, 0), (32, 0), (32, 64), (128, 16), (0, 0)])
+def test_split_row_caches_bit_exact(cfg_name, split, corpus, shuffle384):
+    blocks = workload.make_blocks(corpus, 300, 70, block_len=20000)
+    blocks[5] = np.resize(shuffle384, 20000)
+    blocks[6] = np.random.default_rng(2).integers(0, 256, 20000, dtype=np.uint8)
+    _compare(cfg_name, blocks, blocks_grid=2, split=split)
 
 
 def test_decode_only_random_then_unicode(random_then_unicode):
