@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--config", choices=["simple", "mixing"], default="simple")
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per stream, 8 or 16 (tuning)")
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -117,6 +118,8 @@ def main():
         codec.set_geometry(blocks=max(1, int(cus * args.blocks_per_cu)))
     if args.cache_rows >= 0:
         codec.set_geometry(cache_rows=args.cache_rows)
+    if args.lanes:
+        codec.set_lane_layout(args.lanes)
     if args.split_cache:
         hi_rows, lo_rows = (int(x) for x in args.split_cache.split(","))
         codec.set_split_cache(hi_rows, lo_rows)

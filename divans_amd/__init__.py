@@ -93,6 +93,7 @@ def load_library():
     L.divans_gpu_codec_info.argtypes = [vp, ctypes.POINTER(GpuInfo)]
     L.divans_gpu_codec_set_geometry.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
+    L.divans_gpu_codec_set_lane_layout.argtypes = [vp, u32]
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
     _LIB = L
     return L
@@ -105,7 +106,8 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_selftest_division",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout",
+        "divans_gpu_selftest_division",
     ]
 
 
@@ -173,6 +175,9 @@ class LiteralCodec:
     def set_geometry(self, blocks=0, cache_rows=None):
         cr = 0xFFFFFFFF if cache_rows is None else int(cache_rows)
         _check(self._lib.divans_gpu_codec_set_geometry(self._h, int(blocks), cr), "set_geometry")
+
+    def set_lane_layout(self, lanes_per_stream):
+        _check(self._lib.divans_gpu_codec_set_lane_layout(self._h, int(lanes_per_stream)), "set_lane_layout")
 
     def set_split_cache(self, high_rows, low_rows):
         _check(self._lib.divans_gpu_codec_set_split_cache(self._h, int(high_rows), int(low_rows)), "set_split_cache")

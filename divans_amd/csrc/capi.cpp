@@ -101,6 +101,7 @@ struct divans_gpu_codec {
     uint32_t blocks = 0;          // persistent grid of the model/decode kernels
     uint32_t cache_high = 0, cache_low = 0;   // per-stream LDS row caches (rows; 0 = that table is accessed in HBM/L2 directly)
     bool cache_unified = false;
+    bool packed8 = false;         // non-mixing configurations: 8 lanes per stream, two CDF entries per lane (lit_kernels_p8.hip)
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
@@ -191,13 +192,14 @@ static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
     b.cache_bytes_per_wg = (LIT_THREADS / 16) * (b.cache_rows_high + b.cache_rows_low) * 34u;
 }
 
-static uint32_t resident_groups(const divans_gpu_codec* c) { return c->blocks * (LIT_THREADS / 16); }
+static uint32_t groups_per_block(const divans_gpu_codec* c) { return c->packed8 ? LIT_THREADS / 8 : LIT_THREADS / 16; }
+static uint32_t resident_groups(const divans_gpu_codec* c) { return c->blocks * groups_per_block(c); }
 
 static int ensure_tables(divans_gpu_codec* c) {
     // big geometries (many context columns / planes) shrink the persistent grid instead of asking for hundreds of GB:
     // at most a quarter of the device memory that is free right now, and never less than one workgroup
     size_t free_b = 0, total_b = 0;
-    const size_t per_block = (size_t)(LIT_THREADS / 16) * c->geom.total_rows * 32u;
+    const size_t per_block = (size_t)groups_per_block(c) * c->geom.total_rows * 32u;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && c->tables_bytes == 0) {
         const size_t budget = std::max<size_t>(free_b / 4, per_block);
         if ((size_t)c->blocks * per_block > budget) c->blocks = (uint32_t)std::max<size_t>(1, budget / per_block);
@@ -240,6 +242,7 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->blocks = c->num_cus * 4u;  // 16 waves = 64 streams per CU (tuned on MI355X)
     // high-nibble rows only: few and hot (32 ways ~ 90 % of their accesses); mixing configurations keep one unified cache
     if (c->geom.total_rows < 0x7fffu) { c->cache_high = 64u; c->cache_low = 0u; c->cache_unified = c->mix; }
+    c->packed8 = false;   // the packed 8-lane kernels (set_lane_layout(8)) are bit-identical; on MI355X the 16-lane ones are faster
     if (hipMalloc(&c->d_blob, LIT_BLOB_BYTES) != hipSuccess || hipMalloc(&c->d_status, 64) != hipSuccess) {
         delete c; return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed");
     }
@@ -260,6 +263,17 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
+}
+
+extern "C" int divans_gpu_codec_set_lane_layout(divans_gpu_codec* c, uint32_t lanes_per_stream) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (lanes_per_stream != 8 && lanes_per_stream != 16) return fail(DIVANS_GPU_EINVAL, "lanes_per_stream must be 8 or 16");
+    if (lanes_per_stream == 8 && c->mix) return fail(DIVANS_GPU_EINVAL, "the packed 8-lane kernels do not implement prior mixing");
+    if ((lanes_per_stream == 8) != c->packed8) {   // the table slab per workgroup changes: reallocate lazily
+        if (c->d_tables) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }
+        c->packed8 = lanes_per_stream == 8;
+    }
+    return 0;
 }
 
 static bool valid_cache_rows(uint32_t r) { return r == 0 || (r >= 16 && r <= 256 && (r & (r - 1)) == 0); }
@@ -327,7 +341,8 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.sf = c->d_sf;
     set_cache_fields(c, b);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
+    if (c->packed8) HIP_TRY(launch_model_encode_p8(b, c->blocks, c->stream));
+    else HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     RansBatch r;
     r.sf = c->d_sf; r.n_streams = n_streams; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
@@ -356,7 +371,8 @@ extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes;
     set_cache_fields(c, b);
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
+    if (c->packed8) HIP_TRY(launch_decode_p8(b, c->blocks, c->stream));
+    else HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     c->timing_pending_dec = true;
     return 0;

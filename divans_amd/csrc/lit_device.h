@@ -1,0 +1,115 @@
+// lit_device.h -- device helpers shared by the 16-lane (lit_kernels.hip) and packed 8-lane (lit_kernels_p8.hip) kernels.
+#ifndef DIVANS_LIT_DEVICE_H_
+#define DIVANS_LIT_DEVICE_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lit_kernels.h"
+
+namespace divans_hip {
+
+#define DPP_ROW_SHR1 0x111
+#define DPP_ROW_BCAST(n) (0x150 + (n))
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// value of lane `n` of this 16-lane row, broadcast to the whole row (v_mov_b32_dpp row_newbcast)
+template <int N>
+__device__ __forceinline__ int row_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST(N), 0xf, 0xf, false);
+}
+// value of the previous lane in the row, 0 for the first lane
+__device__ __forceinline__ int row_prev_or_zero(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR1, 0xf, 0xf, true);
+}
+// value of lane (row_base + idx) -- idx is row-uniform but not compile-time
+__device__ __forceinline__ int row_gather(int v, int row_base_lane, int idx) {
+    return __builtin_amdgcn_ds_bpermute((row_base_lane + idx) << 2, v);
+}
+
+// floor(n / d) for 0 <= n < 2^31, 1 <= d < 2^15, given rcp ~= 1/d (v_rcp_f32, 1 ulp).
+// The float estimate is within 2^-6 of the true quotient, so one step of correction makes it exact.
+__device__ __forceinline__ uint32_t exact_div(uint32_t n, uint32_t d, float rcp) {
+    uint32_t q = (uint32_t)((float)n * rcp);
+    int32_t r = (int32_t)(n - q * d);
+    q = r < 0 ? q - 1u : q;
+    q = r >= (int32_t)d ? q + 1u : q;
+    return q;
+}
+
+// floor((c << 15) / d) for 0 <= c <= d < 2^15 with a reciprocal biased low: `rcp_lo` = rcp(d) * 2^15 * (1 - 2^-20).
+// (float)c is exact, the product's relative error is < 2^-22, so the truncated estimate is q or q-1 (never above)
+// and a single compare finishes it.  Checked exhaustively on the GPU (selftest_division_kernel).
+__device__ __forceinline__ float biased_rcp15(int d) {
+    return __builtin_amdgcn_rcpf((float)d) * (32768.0f * (1.0f - 9.5367431640625e-07f));
+}
+__device__ __forceinline__ uint32_t scaled_div(int c, int d, float rcp_lo) {
+    uint32_t q = (uint32_t)((float)c * rcp_lo);
+    int32_t r = (c << 15) - __mul24((int)q, d);      // q < 2^16, d < 2^15: 24-bit multiply is exact
+    return r >= d ? q + 1u : q;
+}
+
+struct RowSel {
+    uint32_t stride_row;   // row index inside the stream's table
+    uint32_t cm_row;       // context-map row (mixing only)
+    bool is_default;       // mm_opts == 2: code with a fresh default CDF / never blend the stride row
+};
+
+// codec/literal.rs:176-208.  All inputs are row-uniform.
+template <bool HIGH, int MM>
+__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* lds_mix, uint32_t ctx, uint64_t last8, uint32_t hi_nib) {
+    const uint32_t prev_byte = (uint32_t)(last8 >> 56);
+    uint32_t mm_opts;
+    if (MM >= 0) mm_opts = (uint32_t)MM;
+    else mm_opts = lds_mix[ctx | (HIGH ? ((prev_byte >> 4) << 8) : ((hi_nib << 8) | 4096u))];
+    const uint32_t fast_cm = (mm_opts != 3) ? 0xffu : 0u;
+    const uint32_t mm = (mm_opts != 0 && mm_opts != 3) ? 0xffu : 0u;
+    const uint32_t opt1 = (mm_opts == 1) ? 0xfu : 0u;
+    uint32_t stride_offset = 0;
+    if (mm_opts >= 4) { uint32_t x = mm_opts ^ 4u; stride_offset = (x < 7u ? x : 7u) << 3; }
+    const uint32_t sb = (uint32_t)(last8 >> (56 - stride_offset)) & 0xffu;
+    uint32_t b, c, width;
+    if (HIGH) { b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx; }
+    else { b = ((mm & sb) | (~mm & ctx)) & 0xffu; c = (hi_nib & fast_cm) | ((ctx & opt1) << 4); width = g.low_width; }
+    const uint32_t t = (mm >> 7) ^ (opt1 >> 2);
+    const uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);
+    RowSel r;
+    r.stride_row = (HIGH ? 0u : g.low_base) + (plane * 256u + b) * width + c;
+    r.cm_row = g.cm_base + (HIGH ? ctx : g.nctx + hi_nib + 16u * ctx);
+    r.is_default = mm_opts == 2;
+    return r;
+}
+
+// LDS layout of a workgroup: [16 x row cache (data, then tags)] [context tables unless CTXC] [mixing_mask if MM < 0]
+struct LdsView { uint8_t* base; const uint8_t* ctx; const uint8_t* mix; };
+
+template <int MM, bool CTXC>
+__device__ __forceinline__ LdsView load_config_to_lds(uint8_t* lds, const LitBatch& b) {
+    LdsView v;
+    v.base = lds;
+    uint8_t* p = lds + b.cache_bytes_per_wg;
+    v.ctx = p;
+    if (!CTXC) {
+        const uint32_t* src = (const uint32_t*)(b.blob + LIT_BLOB_LUT1CLASS);
+        for (uint32_t i = threadIdx.x; i < LIT_BLOB_CTX_BYTES / 4; i += blockDim.x) ((uint32_t*)p)[i] = src[i];
+        p += LIT_BLOB_CTX_BYTES;
+    }
+    v.mix = p;
+    if (MM < 0) {
+        const uint32_t* src = (const uint32_t*)(b.blob + LIT_BLOB_MIX);
+        for (uint32_t i = threadIdx.x; i < 8192 / 4; i += blockDim.x) ((uint32_t*)p)[i] = src[i];
+    }
+    __syncthreads();
+    return v;
+}
+
+// Context of the next byte: literal.rs:87-117 with lut0 / lut1 / context map fused on the host into
+// LIT_BLOB_CTXF[prev][lut1 class of prev_prev]; `k1` (that class) is carried over from the previous byte.
+template <bool CTXC>
+__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds_ctx, uint32_t prev, uint32_t k1) {
+    if (CTXC) return (uint32_t)g.ctx_const;
+    return lds_ctx[LIT_BLOB_CTXF + (prev << 3) + k1];
+}
+
+}  // namespace divans_hip
+#endif

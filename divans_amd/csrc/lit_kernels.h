@@ -55,6 +55,8 @@ uint32_t lit_lds_bytes(const LitBatch& b);
 hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st);
 hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
+hipError_t launch_model_encode_p8(const LitBatch& b, uint32_t blocks, hipStream_t st);
+hipError_t launch_decode_p8(const LitBatch& b, uint32_t blocks, hipStream_t st);
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
                        uint64_t* dst_off, uint64_t* total, hipStream_t st);
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);

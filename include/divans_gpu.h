@@ -112,6 +112,9 @@ int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);
 /* tuning knobs: `blocks` = persistent grid of 256-thread workgroups (0 keeps the current value);
  * `cache_rows` = rows of one unified per-stream LDS row cache (0 = off, power of two in [16,256], 0xffffffff keeps). */
 int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t cache_rows);
+/* lanes of a wavefront that own one stream: 16 (one CDF entry per lane; the only layout with prior mixing) or
+ * 8 (two entries per lane; non-mixing configurations only) */
+int divans_gpu_codec_set_lane_layout(divans_gpu_codec *c, uint32_t lanes_per_stream);
 /* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */
 int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, uint32_t low_rows);
 
