@@ -12,6 +12,7 @@ namespace divans_hip {
 #define DPP_ROW_BCAST(n) (0x150 + (n))
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // value of lane `n` of this 16-lane row, broadcast to the whole row (v_mov_b32_dpp row_newbcast)
 template <int N>
@@ -74,7 +75,10 @@ __device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_
     const uint32_t t = (mm >> 7) ^ (opt1 >> 2);
     const uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);
     RowSel r;
-    r.stride_row = (HIGH ? 0u : g.low_base) + (plane * 256u + b) * width + c;
+    // rows are ordered [plane][c][b]: the byte-valued index is innermost, so the four rows of a 128-byte L2 line
+    // belong to neighbouring byte values with the same nibble / context (neighbouring letters are hot together
+    // in text), and the address needs no per-lane multiply
+    r.stride_row = (HIGH ? 0u : g.low_base) + ((plane * width + c) << 8) + b;
     r.cm_row = g.cm_base + (HIGH ? ctx : g.nctx + hi_nib + 16u * ctx);
     r.is_default = mm_opts == 2;
     return r;

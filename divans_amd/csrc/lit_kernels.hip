@@ -318,8 +318,8 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
             }
             // nibble index of byte (base+li) is 2*(base+li): each lane stores its two pairs (8 B; 128 B coalesced per row)
             if ((uint32_t)li < cnt) {
-                uint2 v; v.x = pend_a; v.y = pend_b;
-                *(uint2*)(sf + 2u * (size_t)(base + li)) = v;
+                u32x2 v = {pend_a, pend_b};   // written once, read once by the rANS kernel: keep it out of the L2's way
+                __builtin_nontemporal_store(v, (u32x2*)(sf + 2u * (size_t)(base + li)));
             }
             mine = nxt;
             nxt = (base + 32u + li < len) ? in[base + 32u + li] : 0u;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                         outb = (uint32_t)li == k ? byte : outb;
                     }
                 }
-                if ((uint32_t)li < cnt) out[base + li] = (uint8_t)outb;
+                if ((uint32_t)li < cnt) __builtin_nontemporal_store((uint8_t)outb, out + base + li);
             }
         }
     }

@@ -200,8 +200,8 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_p8_kernel(const 
                 pend_b = (uint32_t)j == k ? pl : pend_b;
             }
             if ((uint32_t)j < cnt) {
-                uint2 v; v.x = pend_a; v.y = pend_b;
-                *(uint2*)(sf + 2u * (size_t)(base + j)) = v;
+                u32x2 v = {pend_a, pend_b};
+                __builtin_nontemporal_store(v, (u32x2*)(sf + 2u * (size_t)(base + j)));
             }
             mine = nxt;
             nxt = (base + 16u + j < len) ? in[base + 16u + j] : 0u;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_p8_kernel(const LitBat
                     p8_finish_nibble<false, CACHE>(g, tb, j, sbase, rowL, cvl, mxl, (int)lo, SB);
                     outb = (uint32_t)j == k ? byte : outb;
                 }
-                if ((uint32_t)j < cnt) out[base + j] = (uint8_t)outb;
+                if ((uint32_t)j < cnt) __builtin_nontemporal_store((uint8_t)outb, out + base + j);
             }
         }
     }
