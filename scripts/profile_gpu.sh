@@ -17,11 +17,13 @@ pmc_pass () {
   rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py $BENCH_ARGS > /dev/null 2> $OUT/pmc_$name.log
   find $OUT/pmc_$name -name '*counter_collection*' -exec cp {} $OUT/pmc_$name.csv \;
 }
+if [ "${PMC:-1}" = "1" ]; then
 pmc_pass fetch FETCH_SIZE
 pmc_pass write WRITE_SIZE
 pmc_pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pmc_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM
 pmc_pass sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+fi
 python - "$OUT" <<'PY'
 import csv, sys, collections, os
 out = sys.argv[1]
