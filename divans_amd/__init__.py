@@ -94,6 +94,8 @@ def load_library():
     L.divans_gpu_codec_set_geometry.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_lane_layout.argtypes = [vp, u32]
+    L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
+    L.divans_gpu_lit_model_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
     _LIB = L
     return L
@@ -106,7 +108,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division",
     ]
 
@@ -176,6 +178,10 @@ class LiteralCodec:
         cr = 0xFFFFFFFF if cache_rows is None else int(cache_rows)
         _check(self._lib.divans_gpu_codec_set_geometry(self._h, int(blocks), cr), "set_geometry")
 
+    def set_encode_path(self, path):
+        """0 automatic, 1 streaming model kernel, 2 bucketed model pass (order-1 configurations only)."""
+        _check(self._lib.divans_gpu_codec_set_encode_path(self._h, int(path)), "set_encode_path")
+
     def set_lane_layout(self, lanes_per_stream):
         _check(self._lib.divans_gpu_codec_set_lane_layout(self._h, int(lanes_per_stream)), "set_lane_layout")
 
@@ -210,6 +216,17 @@ class LiteralCodec:
             in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams),
             outputs["out"].data_ptr(), int(outputs["slot"]), outputs["offsets"].data_ptr(),
             outputs["sizes"].data_ptr()), "divans_gpu_lit_encode_batch")
+
+    def model_batch(self, d_in, n_streams, stream_len, in_offsets=None, in_sizes=None):
+        """Model pass only: int32 device tensor [n_streams, 2 * M] of start | freq << 16 per nibble (M = max_stream_len, even)."""
+        t = self._torch
+        m = (self.max_stream_len + 1) & ~1
+        pairs = t.zeros((n_streams, 2 * m), dtype=t.int32, device=d_in.device)
+        _check(self._lib.divans_gpu_lit_model_batch(
+            self._h, d_in.data_ptr(), in_offsets.data_ptr() if in_offsets is not None else None,
+            in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams), pairs.data_ptr()),
+            "divans_gpu_lit_model_batch")
+        return pairs
 
     def decode_batch(self, d_coded, d_offsets, d_sizes, n_streams, stream_len, d_out, out_offsets=None, out_sizes=None):
         _check(self._lib.divans_gpu_lit_decode_batch(

@@ -106,6 +106,10 @@ struct divans_gpu_codec {
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
     uint32_t* d_status = nullptr;
+    // bucketed encoder model pass (lit_bucket.hip)
+    bool bucket_ok = false;       // the configuration allows it: order-1, no context map, no mixing, streams <= 64 KiB
+    uint32_t encode_path = 0;     // 0 automatic (bucketed when bucket_ok), 1 streaming kernels, 2 bucketed
+    uint8_t* d_bk = nullptr;      size_t bk_bytes = 0; uint32_t bk_streams = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
     bool timing_pending_enc = false, timing_pending_dec = false;
@@ -242,6 +246,7 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->blocks = c->num_cus * 4u;  // 16 waves = 64 streams per CU (tuned on MI355X)
     // high-nibble rows only: few and hot (32 ways ~ 90 % of their accesses); mixing configurations keep one unified cache
     if (c->geom.total_rows < 0x7fffu) { c->cache_high = 64u; c->cache_low = 0u; c->cache_unified = c->mix; }
+    c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && c->geom.ctx_const >= 0 && c->max_stream_len <= 65536u;
     c->packed8 = false;   // the packed 8-lane kernels (set_lane_layout(8)) are bit-identical; on MI355X the 16-lane ones are faster
     if (hipMalloc(&c->d_blob, LIT_BLOB_BYTES) != hipSuccess || hipMalloc(&c->d_status, 64) != hipSuccess) {
         delete c; return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed");
@@ -260,9 +265,43 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     if (c->d_blob) (void)hipFree(c->d_blob);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_sf) (void)hipFree(c->d_sf);
+    if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
+}
+
+static uint32_t bucket_pieces(const divans_gpu_codec* c) { return (c->max_stream_len + 8191u) / 8192u; }
+static bool use_bucket(const divans_gpu_codec* c) { return c->bucket_ok && c->encode_path != 1u; }
+
+// one allocation carved into the five work arrays of BucketBatch
+static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b) {
+    const size_t pl = (size_t)bucket_pieces(c) * 8192u;
+    const size_t n = n_streams;
+    const size_t sz_sfs = n * pl * 8u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 3u * 4u, sz_inv = n * pl * 2u, sz_sorted = n * pl;
+    const size_t need = sz_sfs + sz_desc + sz_tasks + sz_inv + sz_sorted + 256u;
+    if (need > c->bk_bytes) {
+        if (c->d_bk) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_bk)); c->d_bk = nullptr; c->bk_bytes = 0; }
+        if (hipMalloc(&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed encoder work arrays) failed");
+        c->bk_bytes = need;
+    }
+    uint8_t* p = c->d_bk;
+    b.counters = (uint32_t*)p; p += 256;
+    b.sfs = (bk_u32x2*)p; p += sz_sfs;
+    b.desc = (uint32_t*)p; p += sz_desc;
+    b.tasks = (uint32_t*)p; p += sz_tasks;
+    b.inv = (uint16_t*)p; p += sz_inv;
+    b.sorted = p;
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_set_encode_path(divans_gpu_codec* c, uint32_t path) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (path > 2u) return fail(DIVANS_GPU_EINVAL, "path must be 0 (automatic), 1 (streaming) or 2 (bucketed)");
+    if (path == 2u && !c->bucket_ok)
+        return fail(DIVANS_GPU_EINVAL, "the bucketed encoder needs an order-1 configuration without context map or mixing and streams of at most 65536 bytes");
+    c->encode_path = path;
+    return 0;
 }
 
 extern "C" int divans_gpu_codec_set_lane_layout(divans_gpu_codec* c, uint32_t lanes_per_stream) {
@@ -308,6 +347,38 @@ extern "C" size_t divans_gpu_lit_encode_bound(size_t n) {
     return (bytes + 15) & ~(size_t)15;
 }
 
+// Encoder pass 1: fills c->d_sf with (start | freq << 16) per nibble, position order.  Records ev[0], ev[1] around it.
+static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes,
+                      uint32_t stream_len, uint32_t n_streams) {
+    int rc = ensure_sf(c, n_streams); if (rc) return rc;
+    if (use_bucket(c)) {
+        BucketBatch k;
+        std::memset(&k, 0, sizeof(k));
+        rc = ensure_bucket(c, n_streams, k); if (rc) return rc;
+        k.in = d_in; k.in_offsets = d_in_offsets; k.in_sizes = d_in_sizes;
+        k.n_streams = n_streams; k.stream_len = stream_len; k.max_stream_len = c->max_stream_len;
+        k.pieces = bucket_pieces(c);
+        k.sf = c->d_sf; k.inc = c->geom.inc0; k.lim = c->geom.lim0;
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(launch_bucket_model(k, c->num_cus * 4u, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        return 0;
+    }
+    rc = ensure_tables(c); if (rc) return rc;
+    LitBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
+    b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
+    b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
+    b.sf = c->d_sf;
+    set_cache_fields(c, b);
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (c->packed8) HIP_TRY(launch_model_encode_p8(b, c->blocks, c->stream));
+    else HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    return 0;
+}
+
 static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                              const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                              uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes,
@@ -331,19 +402,7 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     if (out_slot % 16 != 0 || out_slot < divans_gpu_lit_encode_bound(d_in_sizes ? c->max_stream_len : stream_len))
         return fail(DIVANS_GPU_ECAP, "out_slot must be a multiple of 16 and >= divans_gpu_lit_encode_bound()");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_tables(c); if (rc) return rc;
-    rc = ensure_sf(c, n_streams); if (rc) return rc;
-    LitBatch b;
-    std::memset(&b, 0, sizeof(b));
-    b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
-    b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
-    b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
-    b.sf = c->d_sf;
-    set_cache_fields(c, b);
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (c->packed8) HIP_TRY(launch_model_encode_p8(b, c->blocks, c->stream));
-    else HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams); if (rc) return rc;
     RansBatch r;
     r.sf = c->d_sf; r.n_streams = n_streams; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
     r.in_sizes = d_in_sizes; r.out = d_out; r.out_slot = out_slot; r.out_offsets = d_out_offsets; r.out_sizes = d_out_sizes;
@@ -351,6 +410,20 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     HIP_TRY(launch_rans_encode(r, c->stream));
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     c->timing_pending_enc = true;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_model_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                                          const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams, uint32_t* d_pairs) {
+    if (!c || !d_in || !d_pairs) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (n_streams == 0) return 0;
+    if ((d_in_offsets == nullptr) != (d_in_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
+    if (stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "stream_len exceeds the codec's max_stream_len");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams); if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    c->timing_pending_enc = true;
+    HIP_TRY(hipMemcpyAsync(d_pairs, c->d_sf, (size_t)n_streams * 2u * c->max_stream_len * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 

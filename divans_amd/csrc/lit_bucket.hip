@@ -1,0 +1,287 @@
+// lit_bucket.hip -- bucketed model pass of the ENCODER for the order-1, context-map-off configuration
+// (mixing value 4 everywhere, constant context: BASELINE configs[1], reference TestSimple, bin/benchmark.rs:195-206).
+//
+// In that configuration the high nibble of byte i is coded with row [prev] and its low nibble with row [prev][hi]
+// (codec/literal.rs:176-208 with mm_opts == 4), both blended with literal_adaptation[0] (literal.rs:320,354).  A row's
+// CDF therefore only depends on the earlier positions that share its `prev` byte.  The encoder knows every byte
+// up front, so instead of walking the stream serially against a 139 KB table in HBM (lit_model_encode_kernel) it
+//   1. bucket_sort_kernel    stable counting sort of every 8 KiB piece of a stream by prev byte (LDS),
+//   2. bucket_tasks_kernel   turns the non-empty (stream, prev) buckets into a task list, longest first,
+//   3. bucket_chain_kernel   ONE LANE per bucket walks its positions in order with the bucket's 17 rows
+//                            (1 high + 16 low) in LDS -- no table in HBM, no row cache, no cross-lane traffic,
+//   4. bucket_unsort_kernel  puts the (start,freq) pairs back into position order for the rANS pass.
+// The arithmetic per nibble is the same as everywhere else (probability/interface.rs:97-108, frequentist_cdf.rs:74-85).
+// The decoder cannot do this (it learns the bytes one at a time) and keeps the streaming kernels.
+#include "lit_device.h"
+
+namespace divans_hip {
+
+constexpr uint32_t BK_PIECE = 8192;          // positions sorted together
+constexpr uint32_t BK_SORT_THREADS = 256;
+constexpr uint32_t BK_LANE_DWORDS = 148;     // 17 rows x 8 dwords + 8 descriptors, padded: 16-byte aligned and the
+                                             // 64 lanes' b128 accesses at equal offsets cover all 32 banks
+constexpr uint32_t BK_DESC_DW = 136;
+constexpr uint32_t BK_TAB_DW = 64 * BK_LANE_DWORDS;
+constexpr uint32_t BK_VALID = 1u << 31;
+constexpr uint32_t BK_WINDOW = 256;          // tasks a wave reserves per atomic
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. per (stream, piece): sorted[slot] = byte, inv[pos] = slot, desc[stream][prev][piece] = start | count << 16
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const BucketBatch b) {
+    __shared__ __attribute__((aligned(16))) uint8_t staging[BK_PIECE];
+    __shared__ uint32_t hist[4][256];
+    __shared__ uint32_t scan[256];
+    const uint32_t s = blockIdx.x / b.pieces, piece = blockIdx.x % b.pieces;
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
+    const uint8_t* in = b.in + (b.in_offsets ? b.in_offsets[s] : (uint64_t)s * b.stream_len);
+    uint32_t* desc = b.desc + ((size_t)s * 256u + tid) * 8u + piece;
+    const uint32_t base = piece * BK_PIECE;
+    if (base >= len) { *desc = 0u; return; }
+    const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
+    const size_t pl = (size_t)b.pieces * BK_PIECE;
+    for (uint32_t i = tid; i < 1024u; i += BK_SORT_THREADS) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    // wave w owns positions [2048 w, 2048 w + 2048) of the piece and visits them in order, 64 at a time
+    for (uint32_t bt = 0; bt < 32u; ++bt) {
+        const uint32_t p = w * 2048u + bt * 64u + lane;
+        if (p < n) {
+            const uint32_t key = (base + p) ? in[base + p - 1u] : 0u;
+            atomicAdd(&hist[w][key], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t c0 = hist[0][tid], c1 = hist[1][tid], c2 = hist[2][tid], c3 = hist[3][tid];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    scan[tid] = tot;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const uint32_t v = tid >= d ? scan[tid - d] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t start = scan[tid] - tot;
+    hist[0][tid] = start; hist[1][tid] = start + c0; hist[2][tid] = start + c0 + c1; hist[3][tid] = start + c0 + c1 + c2;
+    *desc = start | (tot << 16);
+    __syncthreads();
+    uint16_t* inv = b.inv + (size_t)s * pl + base;
+    for (uint32_t bt = 0; bt < 32u; ++bt) {
+        const uint32_t p = w * 2048u + bt * 64u + lane;
+        const bool valid = p < n;
+        const uint32_t key = valid ? ((base + p) ? in[base + p - 1u] : 0u) : 0u;
+        const uint32_t byte = valid ? in[base + p] : 0u;
+        unsigned long long same = __ballot(valid);
+        for (uint32_t bit = 0; bit < 8u; ++bit) {
+            const bool set = (key >> bit) & 1u;
+            const unsigned long long bb = __ballot(set);
+            same &= set ? bb : ~bb;
+        }
+        const uint32_t rank = lanes_below(same), cnt = (uint32_t)__popcll(same);
+        if (valid) {
+            const uint32_t off = hist[w][key];
+            staging[off + rank] = (uint8_t)byte;
+            inv[p] = (uint16_t)(off + rank);
+            if (rank == cnt - 1u) hist[w][key] = off + cnt;   // the wave's LDS accesses stay in program order
+        }
+    }
+    __syncthreads();
+    uint8_t* sorted = b.sorted + (size_t)s * pl + base;
+    for (uint32_t i = tid * 4u; i < n; i += BK_SORT_THREADS * 4u) {
+        if (i + 4u <= n) *(uint32_t*)(sorted + i) = *(const uint32_t*)(staging + i);
+        else for (uint32_t k = i; k < n; ++k) sorted[k] = staging[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. task lists by bucket size class, so that the long chains start first
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bucket_tasks_kernel(const BucketBatch b) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;       // stream * 256 + prev
+    const uint32_t cap = b.n_streams * 256u;
+    uint32_t tot = 0;
+    if (t < cap) {
+        const u32x4* d = (const u32x4*)(b.desc + (size_t)t * 8u);
+        const u32x4 d0 = d[0], d1 = d[1];
+        tot = (d0.x >> 16) + (d0.y >> 16) + (d0.z >> 16) + (d0.w >> 16) + (d1.x >> 16) + (d1.y >> 16) + (d1.z >> 16) + (d1.w >> 16);
+    }
+    const int cls = tot == 0u ? -1 : (tot >= 2048u ? 0 : (tot >= 64u ? 1 : 2));
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (m == 0ull) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t basev = 0;
+        if ((int)(threadIdx.x & 63u) == leader) basev = atomicAdd(&b.counters[c], (uint32_t)__popcll(m));
+        basev = (uint32_t)__builtin_amdgcn_readlane((int)basev, leader);
+        if (cls == c) b.tasks[(size_t)c * cap + basev + lanes_below(m)] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. chains
+// ---------------------------------------------------------------------------------------------
+// one nibble against the row at `row` (8 dwords = 16 x u16 in LDS): returns start | freq << 16 and blends
+__device__ __forceinline__ uint32_t bk_nibble(uint32_t* row, const uint32_t* tab, uint32_t sym, int lim) {
+    u32x4 w0 = *(const u32x4*)row, w1 = *(const u32x4*)(row + 4);
+    const uint16_t* r16 = (const uint16_t*)row;
+    const int mx = (int)(w1.w >> 16);
+    const int chi = r16[sym];
+    const int cprev = r16[sym ? sym - 1u : 0u];
+    const int clo = sym ? cprev : 0;
+    const float rcp = biased_rcp15(mx);
+    const uint32_t dhi = scaled_div(chi, mx, rcp), dlo = scaled_div(clo, mx, rcp);
+    const uint32_t packed = (dlo + 1u) | ((dhi - dlo - 1u) << 16);       // probability/interface.rs:97-108
+    const u32x4 a0 = *(const u32x4*)(tab + sym * 8u), a1 = *(const u32x4*)(tab + sym * 8u + 4u);
+    w0 += a0; w1 += a1;                                                  // frequentist_cdf.rs:74-85, both halves at once
+    if ((int)(w1.w >> 16) >= lim) {
+        const u32x4 b0 = {1u | (2u << 16), 3u | (4u << 16), 5u | (6u << 16), 7u | (8u << 16)};
+        const u32x4 b1 = {9u | (10u << 16), 11u | (12u << 16), 13u | (14u << 16), 15u | (16u << 16)};
+        const u32x4 t0 = w0 + b0, t1 = w1 + b1;
+        w0 = t0 - ((t0 >> 2) & 0x3fff3fffu);
+        w1 = t1 - ((t1 >> 2) & 0x3fff3fffu);
+    }
+    *(u32x4*)row = w0; *(u32x4*)(row + 4) = w1;
+    return packed;
+}
+
+__global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t* my = lds32 + lane * BK_LANE_DWORDS;
+    uint32_t* mydesc = my + BK_DESC_DW;
+    uint32_t* tab = lds32 + BK_TAB_DW;
+    const uint32_t inc = (uint32_t)b.inc; const int lim = b.lim;
+    for (uint32_t i = lane; i < 128u; i += 64u) {
+        const uint32_t sym = i >> 3, k = i & 7u;
+        tab[i] = (2u * k >= sym ? inc : 0u) | (2u * k + 1u >= sym ? inc << 16 : 0u);
+    }
+    __syncthreads();
+    const size_t pl = (size_t)b.pieces * BK_PIECE;
+    const uint32_t cap = b.n_streams * 256u;
+    const uint32_t n0 = b.counters[0], n1 = b.counters[1], n2 = b.counters[2];
+    const uint32_t total = n0 + n1 + n2;
+    const u32x4 def0 = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
+    const u32x4 def1 = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
+
+    // per-lane chain state
+    bool has_task = false, fresh_finish = false, exhausted = false;
+    uint32_t cur_s = 0, piece = 0, left = 0, idx = 0;
+    uint32_t nt_stage = 0, nt_tid = 0;
+    u32x4 nd0 = {0u, 0u, 0u, 0u}, nd1 = {0u, 0u, 0u, 0u};
+    // wave-uniform task window
+    uint32_t win_cur = 0, win_end = 0, nxt_val = 0;
+    bool nxt_pending = false, drained = false;
+    // four bytes in flight per lane: requested one loop iteration before they are coded
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+
+#define BK_STEP(E, A)                                                                                   \
+    {                                                                                                   \
+        if (A & BK_VALID) {                                                                             \
+            const uint32_t hi = (E >> 4) & 15u, lo = E & 15u;                                           \
+            const uint32_t ph = bk_nibble(my, tab, hi, lim);                                            \
+            const uint32_t pl_ = bk_nibble(my + 8u * (1u + hi), tab, lo, lim);                          \
+            u32x2 v = {ph, pl_};                                                                        \
+            b.sfs[(size_t)cur_s * pl + (A & 0xffffu)] = v;                                              \
+        }                                                                                               \
+        A = 0u;                                                                                         \
+        if (has_task) {                                                                                 \
+            while (left == 0u && piece < b.pieces) {                                                    \
+                const uint32_t d = mydesc[piece];                                                       \
+                left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece;                        \
+            }                                                                                           \
+            if (left) { E = b.sorted[(size_t)cur_s * pl + idx]; A = idx | BK_VALID; ++idx; --left; }    \
+            else { has_task = false; fresh_finish = true; }                                             \
+        }                                                                                               \
+    }
+
+    for (;;) {
+        BK_STEP(e0, a0) BK_STEP(e1, a1) BK_STEP(e2, a2) BK_STEP(e3, a3)
+        // a lane whose bucket ended at least one full iteration ago (all its bytes coded) takes its prefetched task
+        const bool bytes_in_flight = fresh_finish;   // bytes requested in this iteration are coded in the next one
+        if (!has_task) {
+            if (fresh_finish) fresh_finish = false;
+            else if (nt_stage == 3u) {
+                *(u32x4*)mydesc = nd0; *(u32x4*)(mydesc + 4) = nd1;
+                for (uint32_t r = 0; r < 17u; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
+                cur_s = nt_tid >> 8; piece = 0u; left = 0u; has_task = true; nt_stage = 0u;
+            }
+        }
+        // task prefetch pipeline, one stage per iteration so that no load is waited for in the iteration that issued it
+        const bool want = nt_stage == 0u && !exhausted;
+        if (nt_stage == 2u) nt_stage = 3u;
+        else if (nt_stage == 1u) {
+            const u32x4* dp = (const u32x4*)(b.desc + (size_t)nt_tid * 8u);
+            nd0 = dp[0]; nd1 = dp[1];
+            nt_stage = 2u;
+        }
+        const unsigned long long wm = __ballot(want);
+        if (wm) {
+            if (win_cur == win_end && nxt_pending) {
+                const uint32_t basev = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_val);
+                nxt_pending = false;
+                if (basev >= total) { drained = true; win_cur = win_end = total; }
+                else { win_cur = basev; win_end = basev + BK_WINDOW < total ? basev + BK_WINDOW : total; }
+            }
+            const uint32_t avail = win_end - win_cur, asked = (uint32_t)__popcll(wm);
+            const uint32_t rank = lanes_below(wm);
+            if (want) {
+                if (rank < avail) {
+                    const uint32_t t = win_cur + rank;
+                    const uint32_t* src = t < n0 ? b.tasks + t : (t < n0 + n1 ? b.tasks + cap + (t - n0) : b.tasks + 2u * (size_t)cap + (t - n0 - n1));
+                    nt_tid = *src;
+                    nt_stage = 1u;
+                } else if (drained) exhausted = true;
+            }
+            win_cur += asked < avail ? asked : avail;
+        }
+        if (!nxt_pending && !drained && win_end - win_cur < BK_WINDOW / 2u) {
+            if (lane == 0u) nxt_val = atomicAdd(&b.counters[3], BK_WINDOW);
+            nxt_pending = true;
+        }
+        const bool done = !has_task && !bytes_in_flight && nt_stage == 0u && exhausted;
+        if (__ballot(!done) == 0ull) break;
+    }
+#undef BK_STEP
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. back to position order: sf[stream][pos] = sfs[stream][piece][inv[pos]]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bucket_unsort_kernel(const BucketBatch b) {
+    __shared__ u32x2 buf[BK_PIECE];
+    const uint32_t s = blockIdx.x / b.pieces, piece = blockIdx.x % b.pieces;
+    const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
+    const uint32_t base = piece * BK_PIECE;
+    if (base >= len) return;
+    const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
+    const size_t pl = (size_t)b.pieces * BK_PIECE;
+    const u32x2* src = b.sfs + (size_t)s * pl + base;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) buf[i] = __builtin_nontemporal_load(src + i);
+    __syncthreads();
+    const uint16_t* inv = b.inv + (size_t)s * pl + base;
+    u32x2* dst = (u32x2*)(b.sf + (size_t)s * 2u * b.max_stream_len) + base;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) dst[i] = buf[inv[i]];
+}
+
+uint32_t bucket_chain_lds_bytes() { return (64u * BK_LANE_DWORDS + 128u) * 4u; }
+
+hipError_t launch_bucket_model(const BucketBatch& b, uint32_t chain_blocks, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(b.counters, 0, 16, st);
+    if (e != hipSuccess) return e;
+    if (b.pieces < 8u) {
+        e = hipMemsetAsync(b.desc, 0, (size_t)b.n_streams * 256u * 8u * sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(b.n_streams * b.pieces), dim3(BK_SORT_THREADS), 0, st, b);
+    hipLaunchKernelGGL(bucket_tasks_kernel, dim3(b.n_streams), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(bucket_chain_kernel, dim3(chain_blocks), dim3(64), bucket_chain_lds_bytes(), st, b);
+    hipLaunchKernelGGL(bucket_unsort_kernel, dim3(b.n_streams * b.pieces), dim3(256), 0, st, b);
+    return hipGetLastError();
+}
+
+}  // namespace divans_hip

@@ -51,6 +51,23 @@ struct RansBatch {
     uint32_t* chunk_bytes; uint32_t max_chunks;   // optional [n_streams][max_chunks] coded size of every 65 536-symbol chunk
 };
 
+typedef unsigned int bk_u32x2 __attribute__((ext_vector_type(2)));
+// Bucketed encoder model pass (lit_bucket.hip): order-1 configurations without context map or mixing only.
+struct BucketBatch {
+    const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
+    uint32_t n_streams, stream_len, max_stream_len;
+    uint32_t pieces;            // 8 KiB pieces per stream slot = ceil(max_stream_len / 8192), at most 8
+    uint8_t* sorted;            // [n_streams][pieces * 8192] literal bytes, every piece ordered by (previous byte, position)
+    uint16_t* inv;              // [n_streams][pieces * 8192] slot of a position inside its sorted piece
+    uint32_t* desc;             // [n_streams][256 previous-byte values][8 pieces] first slot | count << 16
+    bk_u32x2* sfs;              // [n_streams][pieces * 8192] (high, low) start|freq<<16 pairs in sorted order
+    uint32_t* sf;               // [n_streams][2 * max_stream_len] the same pairs in position order (what rans_encode_kernel reads)
+    uint32_t* tasks;            // [3 size classes][n_streams * 256] stream * 256 + previous byte
+    uint32_t* counters;         // [0..2] tasks per class, [3] next unclaimed task
+    int32_t inc, lim;           // literal_adaptation[0]
+};
+hipError_t launch_bucket_model(const BucketBatch& b, uint32_t chain_blocks, hipStream_t st);
+
 uint32_t lit_lds_bytes(const LitBatch& b);
 hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st);

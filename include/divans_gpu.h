@@ -75,6 +75,13 @@ int divans_gpu_lit_encode_batch(divans_gpu_codec *c, const uint8_t *d_in, const 
                                 const uint32_t *d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                                 uint8_t *d_out, uint64_t out_slot, uint64_t *d_out_offsets, uint32_t *d_out_sizes);
 
+/* Encoder pass 1 only: the adaptive model's output before entropy coding.  d_pairs receives, for stream i at
+ * [i * 2 * M, i * 2 * M + 2 * len_i) with M = the codec's max_stream_len rounded up to even, one word
+ * (start | freq << 16) per nibble in coding order (high nibble first) -- what ANSEncoder::put_start_freq is handed,
+ * ans.rs:287-301.  Same input conventions as divans_gpu_lit_encode_batch.  For tests and diagnostics. */
+int divans_gpu_lit_model_batch(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
+                               const uint32_t *d_in_sizes, uint32_t stream_len, uint32_t n_streams, uint32_t *d_pairs);
+
 /* Decode n_streams streams: coded bytes at d_in + d_in_offsets[i] (4-byte aligned), d_in_sizes[i] long;
  * stream i decodes to d_out + (d_out_offsets ? d_out_offsets[i] : i*stream_len), d_out_sizes[i] (or stream_len) bytes. */
 int divans_gpu_lit_decode_batch(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
@@ -115,6 +122,13 @@ int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t
 /* lanes of a wavefront that own one stream: 16 (one CDF entry per lane; the only layout with prior mixing) or
  * 8 (two entries per lane; non-mixing configurations only) */
 int divans_gpu_codec_set_lane_layout(divans_gpu_codec *c, uint32_t lanes_per_stream);
+/* Encoder model pass: 0 = automatic, 1 = streaming kernels (one walk per stream against its CDF table in HBM),
+ * 2 = bucketed (positions grouped by previous byte, one lane per bucket, rows in LDS; lit_bucket.hip).  The bucketed
+ * pass exists for order-1 configurations without context map or mixing (divans_lit_config_simple) and streams of at
+ * most 65536 bytes, where it is what "automatic" picks; asking for it elsewhere is DIVANS_GPU_EINVAL.  Both produce
+ * the same bytes. */
+int divans_gpu_codec_set_encode_path(divans_gpu_codec *c, uint32_t path);
+
 /* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */
 int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, uint32_t low_rows);
 

@@ -18,9 +18,11 @@ def _oracle_cfg(cfg_name):
     return po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
 
 
-def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0, split=None, lanes=None):
+def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0, split=None, lanes=None, encode_path=None):
     n, L = blocks.shape
     da, codec = _codec(cfg_name, max(L, 1))
+    if encode_path is not None:
+        codec.set_encode_path(encode_path)
     if lanes is not None:
         codec.set_lane_layout(lanes)
     if cache_rows is not None or blocks_grid:
@@ -227,6 +229,71 @@ def test_unsupported_speed_is_rejected():
         da.LiteralCodec(g, 1024)
 
 
+@pytest.mark.parametrize("encode_path", [1, 2])
+@pytest.mark.parametrize("length", [1, 2, 63, 64, 65, 8191, 8192, 8193, 16385, 40000, 65535, 65536])
+def test_encode_paths_bit_exact(encode_path, length, corpus, shuffle384):
+    # streaming model kernel (1) and bucketed model pass (2, what "automatic" picks for this configuration)
+    # must both reproduce the oracle's bytes; lengths straddle the 8 KiB sort pieces and the 32 KiB ANS chunks
+    blocks = workload.make_blocks(corpus, 40, 70, block_len=length, perturb_per_block=length // 100)
+    if length >= 64:
+        blocks[3] = np.resize(shuffle384, length)
+        blocks[4] = np.random.default_rng(length).integers(0, 256, length, dtype=np.uint8)
+        blocks[5] = 0
+        blocks[6] = np.resize(np.frombuffer(b"ab", dtype=np.uint8), length)   # two buckets own every position
+    _compare("simple", blocks, encode_path=encode_path)
+
+
+@pytest.mark.parametrize("cfg_name,encode_path", [("simple", 1), ("simple", 2), ("mixing", 1)])
+def test_model_pass_matches_oracle_trace(cfg_name, encode_path, corpus, shuffle384):
+    # the (start, freq) pair of every nibble, straight out of the model pass on a fresh codec (nothing stale to hide
+    # behind), against the oracle's put_start_freq trace
+    import torch
+    L = 20011
+    blocks = workload.make_blocks(corpus, 77, 40, block_len=L, perturb_per_block=200)
+    blocks[1] = np.resize(shuffle384, L)
+    blocks[2] = 0
+    da, codec = _codec(cfg_name, L)
+    codec.set_encode_path(encode_path)
+    pairs = codec.model_batch(torch.from_numpy(blocks).to("cuda:0"), blocks.shape[0], L)
+    torch.cuda.synchronize()
+    pairs = pairs.cpu().numpy().view(np.uint32)[:, :2 * L]
+    ocfg = _oracle_cfg(cfg_name)
+    for i in range(blocks.shape[0]):
+        _, tr = po.lit_encode(ocfg, blocks[i], trace=True)
+        want = tr[:, 1].astype(np.uint32) | (tr[:, 2].astype(np.uint32) << 16)
+        assert (pairs[i] == want).all(), (i, int(np.argmax(pairs[i] != want)))
+    codec.close()
+
+
+def test_bucketed_encoder_many_streams(corpus):
+    # enough buckets that every wave of the chain kernel recycles its lanes many times and reserves several task windows
+    blocks = workload.make_blocks(corpus, 9, 3000, block_len=9000)
+    da, codec = _codec("simple", 9000)
+    codec.set_encode_path(2)
+    packed, offs, sizes = codec.encode_host(blocks, 9000)
+    codec.set_encode_path(1)
+    packed1, offs1, sizes1 = codec.encode_host(blocks, 9000)
+    assert (sizes == sizes1).all() and (offs == offs1).all() and (packed == packed1).all()
+    ocfg = _oracle_cfg("simple")
+    for i in range(0, 3000, 101):
+        ref = po.lit_encode(ocfg, blocks[i])
+        assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == ref).all(), i
+    assert (codec.decode_host(packed, offs, sizes, 9000) == blocks).all()
+    codec.close()
+
+
+def test_bucketed_encoder_only_where_it_applies():
+    import divans_amd as da
+    codec = da.LiteralCodec(da.config_context_mixing(), 4096)
+    with pytest.raises(da.DivansGpuError):
+        codec.set_encode_path(2)
+    codec.close()
+    codec = da.LiteralCodec(da.config_simple(), 100000)     # streams longer than 8 pieces: streaming kernels only
+    with pytest.raises(da.DivansGpuError):
+        codec.set_encode_path(2)
+    codec.close()
+
+
 @pytest.mark.parametrize("lanes", [8, 16])
 @pytest.mark.parametrize("split", [(0, 0), (16, 0), (64, 0)])
 def test_lane_layouts_bit_exact(lanes, split, corpus, shuffle384):
@@ -235,4 +302,4 @@ def test_lane_layouts_bit_exact(lanes, split, corpus, shuffle384):
     blocks[7] = np.resize(shuffle384, 33000)
     blocks[8] = np.random.default_rng(3).integers(0, 256, 33000, dtype=np.uint8)
     blocks[9] = 0
-    _compare("simple", blocks, blocks_grid=2, split=split, lanes=lanes)
+    _compare("simple", blocks, blocks_grid=2, split=split, lanes=lanes, encode_path=1)
