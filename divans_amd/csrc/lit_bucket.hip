@@ -101,9 +101,12 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const Buck
 // ---------------------------------------------------------------------------------------------
 // 2. task lists by bucket size class, so that the long chains start first
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bucket_tasks_kernel(const BucketBatch b) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;       // stream * 256 + prev
+__global__ __launch_bounds__(1024) void bucket_tasks_kernel(const BucketBatch b) {
+    __shared__ uint32_t cnt[3], basev[3];
+    const uint32_t t = blockIdx.x * 1024u + threadIdx.x;      // stream * 256 + prev
     const uint32_t cap = b.n_streams * 256u;
+    if (threadIdx.x < 3u) cnt[threadIdx.x] = 0u;
+    __syncthreads();
     uint32_t tot = 0;
     if (t < cap) {
         const u32x4* d = (const u32x4*)(b.desc + (size_t)t * 8u);
@@ -111,42 +114,56 @@ __global__ __launch_bounds__(256) void bucket_tasks_kernel(const BucketBatch b) 
         tot = (d0.x >> 16) + (d0.y >> 16) + (d0.z >> 16) + (d0.w >> 16) + (d1.x >> 16) + (d1.y >> 16) + (d1.z >> 16) + (d1.w >> 16);
     }
     const int cls = tot == 0u ? -1 : (tot >= 2048u ? 0 : (tot >= 64u ? 1 : 2));
+    // slot inside the block: one LDS atomic per wave and class, then one global atomic per block and class
+    uint32_t local = 0;
     for (int c = 0; c < 3; ++c) {
         const unsigned long long m = __ballot(cls == c);
         if (m == 0ull) continue;
         const int leader = __ffsll((long long)m) - 1;
-        uint32_t basev = 0;
-        if ((int)(threadIdx.x & 63u) == leader) basev = atomicAdd(&b.counters[c], (uint32_t)__popcll(m));
-        basev = (uint32_t)__builtin_amdgcn_readlane((int)basev, leader);
-        if (cls == c) b.tasks[(size_t)c * cap + basev + lanes_below(m)] = t;
+        uint32_t wbase = 0;
+        if ((int)(threadIdx.x & 63u) == leader) wbase = atomicAdd(&cnt[c], (uint32_t)__popcll(m));
+        wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
+        if (cls == c) local = wbase + lanes_below(m);
     }
+    __syncthreads();
+    if (threadIdx.x < 3u) basev[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&b.counters[threadIdx.x], cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (cls >= 0) b.tasks[(size_t)cls * cap + basev[cls] + local] = t;
 }
 
 // ---------------------------------------------------------------------------------------------
 // 3. chains
 // ---------------------------------------------------------------------------------------------
-// one nibble against the row at `row` (8 dwords = 16 x u16 in LDS): returns start | freq << 16 and blends
-__device__ __forceinline__ uint32_t bk_nibble(uint32_t* row, const uint32_t* tab, uint32_t sym, int lim) {
-    u32x4 w0 = *(const u32x4*)row, w1 = *(const u32x4*)(row + 4);
+// One nibble against a row of 8 dwords (16 x u16) in LDS, split into phases so that the two nibbles of a byte
+// (different rows) can be in flight together: read, pack (start | freq << 16), blend, write.
+struct BkRow { u32x4 w0, w1, a0, a1; int chi, cprev; };
+
+__device__ __forceinline__ BkRow bk_read(const uint32_t* row, const uint32_t* tab, uint32_t sym) {
+    BkRow r;
+    r.w0 = *(const u32x4*)row; r.w1 = *(const u32x4*)(row + 4);
     const uint16_t* r16 = (const uint16_t*)row;
-    const int mx = (int)(w1.w >> 16);
-    const int chi = r16[sym];
-    const int cprev = r16[sym ? sym - 1u : 0u];
-    const int clo = sym ? cprev : 0;
+    r.chi = r16[sym];
+    r.cprev = r16[sym ? sym - 1u : 0u];
+    r.a0 = *(const u32x4*)(tab + sym * 8u); r.a1 = *(const u32x4*)(tab + sym * 8u + 4u);
+    return r;
+}
+__device__ __forceinline__ uint32_t bk_pack(const BkRow& r, uint32_t sym) {     // probability/interface.rs:97-108
+    const int mx = (int)(r.w1.w >> 16);
+    const int clo = sym ? r.cprev : 0;
     const float rcp = biased_rcp15(mx);
-    const uint32_t dhi = scaled_div(chi, mx, rcp), dlo = scaled_div(clo, mx, rcp);
-    const uint32_t packed = (dlo + 1u) | ((dhi - dlo - 1u) << 16);       // probability/interface.rs:97-108
-    const u32x4 a0 = *(const u32x4*)(tab + sym * 8u), a1 = *(const u32x4*)(tab + sym * 8u + 4u);
-    w0 += a0; w1 += a1;                                                  // frequentist_cdf.rs:74-85, both halves at once
-    if ((int)(w1.w >> 16) >= lim) {
-        const u32x4 b0 = {1u | (2u << 16), 3u | (4u << 16), 5u | (6u << 16), 7u | (8u << 16)};
-        const u32x4 b1 = {9u | (10u << 16), 11u | (12u << 16), 13u | (14u << 16), 15u | (16u << 16)};
-        const u32x4 t0 = w0 + b0, t1 = w1 + b1;
-        w0 = t0 - ((t0 >> 2) & 0x3fff3fffu);
-        w1 = t1 - ((t1 >> 2) & 0x3fff3fffu);
-    }
-    *(u32x4*)row = w0; *(u32x4*)(row + 4) = w1;
-    return packed;
+    const uint32_t dhi = scaled_div(r.chi, mx, rcp), dlo = scaled_div(clo, mx, rcp);
+    return (dlo + 1u) | ((dhi - dlo - 1u) << 16);
+}
+__device__ __forceinline__ void bk_renorm(BkRow& r) {                           // frequentist_cdf.rs:79-84, both halves at once
+    const u32x4 b0 = {1u | (2u << 16), 3u | (4u << 16), 5u | (6u << 16), 7u | (8u << 16)};
+    const u32x4 b1 = {9u | (10u << 16), 11u | (12u << 16), 13u | (14u << 16), 15u | (16u << 16)};
+    const u32x4 t0 = r.w0 + b0, t1 = r.w1 + b1;
+    r.w0 = t0 - ((t0 >> 2) & 0x3fff3fffu);
+    r.w1 = t1 - ((t1 >> 2) & 0x3fff3fffu);
+}
+
+__device__ __forceinline__ void bk_store_pair(u32x2* p, u32x2 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 
 __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
@@ -170,7 +187,8 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
 
     // per-lane chain state
     bool has_task = false, fresh_finish = false, exhausted = false;
-    uint32_t cur_s = 0, piece = 0, left = 0, idx = 0;
+    uint32_t piece = 0, left = 0, idx = 0;
+    u32x2* cur_sfs = b.sfs; const uint8_t* cur_sorted = b.sorted;   // the current bucket's stream slot
     uint32_t nt_stage = 0, nt_tid = 0;
     u32x4 nd0 = {0u, 0u, 0u, 0u}, nd1 = {0u, 0u, 0u, 0u};
     // wave-uniform task window
@@ -179,24 +197,39 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     // four bytes in flight per lane: requested one loop iteration before they are coded
     uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 
+    // Every step issues exactly one byte load (from a harmless address when the lane has nothing to fetch) and the
+    // pair store goes out through inline asm: the compiler then sees only in-order loads on vmcnt and waits with
+    // vmcnt(3) for a byte requested four steps earlier instead of draining the queue (a visible store next to the
+    // loads makes it fall back to vmcnt(0) on this target).  The hidden stores can only make that wait stricter.
+#define BK_OPAQUE(X) asm volatile("" : "+v"(X))
 #define BK_STEP(E, A)                                                                                   \
     {                                                                                                   \
+        BK_OPAQUE(E);  /* keeps the compiler from touching the byte (and waiting for it) before this point */ \
         if (A & BK_VALID) {                                                                             \
-            const uint32_t hi = (E >> 4) & 15u, lo = E & 15u;                                           \
-            const uint32_t ph = bk_nibble(my, tab, hi, lim);                                            \
-            const uint32_t pl_ = bk_nibble(my + 8u * (1u + hi), tab, lo, lim);                          \
-            u32x2 v = {ph, pl_};                                                                        \
-            b.sfs[(size_t)cur_s * pl + (A & 0xffffu)] = v;                                              \
+            const uint32_t byte_ = E >> ((A >> 13) & 24u);   /* A bits 16-17: which byte of the aligned word */ \
+            const uint32_t hi = (byte_ >> 4) & 15u, lo = byte_ & 15u;                                   \
+            uint32_t* rowl = my + 8u * (1u + hi);                                                       \
+            BkRow H = bk_read(my, tab, hi), L = bk_read(rowl, tab, lo);                                 \
+            const u32x2 v = {bk_pack(H, hi), bk_pack(L, lo)};                                           \
+            H.w0 += H.a0; H.w1 += H.a1; L.w0 += L.a0; L.w1 += L.a1;   /* frequentist_cdf.rs:75-78 */    \
+            if ((int)(H.w1.w >> 16) >= lim) bk_renorm(H);                                               \
+            if ((int)(L.w1.w >> 16) >= lim) bk_renorm(L);                                               \
+            *(u32x4*)my = H.w0; *(u32x4*)(my + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
+            bk_store_pair(cur_sfs + (A & 0xffffu), v);                                                  \
         }                                                                                               \
-        A = 0u;                                                                                         \
-        if (has_task) {                                                                                 \
-            while (left == 0u && piece < b.pieces) {                                                    \
-                const uint32_t d = mydesc[piece];                                                       \
-                left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece;                        \
-            }                                                                                           \
-            if (left) { E = b.sorted[(size_t)cur_s * pl + idx]; A = idx | BK_VALID; ++idx; --left; }    \
-            else { has_task = false; fresh_finish = true; }                                             \
+        /* fetch side, branch-free: next piece of the bucket when the current one is used up (an empty piece costs \
+           the lane this step), then one more byte */                                                   \
+        {                                                                                               \
+            const bool adv = has_task && left == 0u, more = piece < b.pieces;                           \
+            const uint32_t d = mydesc[piece & 7u];                                                      \
+            if (adv && more) { left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece; }       \
+            if (adv && !more) { has_task = false; fresh_finish = true; }                                \
         }                                                                                               \
+        const bool fetch_ = has_task && left != 0u;                                                     \
+        const uint8_t* lp = fetch_ ? cur_sorted + (idx & ~3u) : b.sorted;                               \
+        const uint32_t nxt_a = fetch_ ? (idx | ((idx & 3u) << 16) | BK_VALID) : 0u;                     \
+        idx += fetch_ ? 1u : 0u; left -= fetch_ ? 1u : 0u;                                              \
+        E = *(const uint32_t*)lp; A = nxt_a;   /* whole aligned word: no extension op on the loaded register */ \
     }
 
     for (;;) {
@@ -206,15 +239,18 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
         if (!has_task) {
             if (fresh_finish) fresh_finish = false;
             else if (nt_stage == 3u) {
+                BK_OPAQUE(nd0); BK_OPAQUE(nd1);
                 *(u32x4*)mydesc = nd0; *(u32x4*)(mydesc + 4) = nd1;
                 for (uint32_t r = 0; r < 17u; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
-                cur_s = nt_tid >> 8; piece = 0u; left = 0u; has_task = true; nt_stage = 0u;
+                cur_sfs = b.sfs + (size_t)(nt_tid >> 8) * pl; cur_sorted = b.sorted + (size_t)(nt_tid >> 8) * pl;
+                piece = 0u; left = 0u; has_task = true; nt_stage = 0u;
             }
         }
         // task prefetch pipeline, one stage per iteration so that no load is waited for in the iteration that issued it
         const bool want = nt_stage == 0u && !exhausted;
         if (nt_stage == 2u) nt_stage = 3u;
         else if (nt_stage == 1u) {
+            BK_OPAQUE(nt_tid);
             const u32x4* dp = (const u32x4*)(b.desc + (size_t)nt_tid * 8u);
             nd0 = dp[0]; nd1 = dp[1];
             nt_stage = 2u;
@@ -222,6 +258,7 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
         const unsigned long long wm = __ballot(want);
         if (wm) {
             if (win_cur == win_end && nxt_pending) {
+                BK_OPAQUE(nxt_val);
                 const uint32_t basev = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_val);
                 nxt_pending = false;
                 if (basev >= total) { drained = true; win_cur = win_end = total; }
@@ -247,12 +284,13 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
         if (__ballot(!done) == 0ull) break;
     }
 #undef BK_STEP
+#undef BK_OPAQUE
 }
 
 // ---------------------------------------------------------------------------------------------
 // 4. back to position order: sf[stream][pos] = sfs[stream][piece][inv[pos]]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bucket_unsort_kernel(const BucketBatch b) {
+__global__ __launch_bounds__(1024) void bucket_unsort_kernel(const BucketBatch b) {
     __shared__ u32x2 buf[BK_PIECE];
     const uint32_t s = blockIdx.x / b.pieces, piece = blockIdx.x % b.pieces;
     const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
@@ -261,11 +299,11 @@ __global__ __launch_bounds__(256) void bucket_unsort_kernel(const BucketBatch b)
     const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
     const size_t pl = (size_t)b.pieces * BK_PIECE;
     const u32x2* src = b.sfs + (size_t)s * pl + base;
-    for (uint32_t i = threadIdx.x; i < n; i += 256u) buf[i] = __builtin_nontemporal_load(src + i);
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) buf[i] = __builtin_nontemporal_load(src + i);
     __syncthreads();
     const uint16_t* inv = b.inv + (size_t)s * pl + base;
     u32x2* dst = (u32x2*)(b.sf + (size_t)s * 2u * b.max_stream_len) + base;
-    for (uint32_t i = threadIdx.x; i < n; i += 256u) dst[i] = buf[inv[i]];
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) dst[i] = buf[inv[i]];
 }
 
 uint32_t bucket_chain_lds_bytes() { return (64u * BK_LANE_DWORDS + 128u) * 4u; }
@@ -278,9 +316,9 @@ hipError_t launch_bucket_model(const BucketBatch& b, uint32_t chain_blocks, hipS
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(b.n_streams * b.pieces), dim3(BK_SORT_THREADS), 0, st, b);
-    hipLaunchKernelGGL(bucket_tasks_kernel, dim3(b.n_streams), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(bucket_tasks_kernel, dim3((b.n_streams + 3u) / 4u), dim3(1024), 0, st, b);
     hipLaunchKernelGGL(bucket_chain_kernel, dim3(chain_blocks), dim3(64), bucket_chain_lds_bytes(), st, b);
-    hipLaunchKernelGGL(bucket_unsort_kernel, dim3(b.n_streams * b.pieces), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(bucket_unsort_kernel, dim3(b.n_streams * b.pieces), dim3(1024), 0, st, b);
     return hipGetLastError();
 }
 

@@ -1,7 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_ffi.py -x -q -m gpu 2>&1 | tail -5
-for ep in 2 1; do timeout 200 python bench.py --streams 32768 --steps 2 --warmup 1 --no-cpu-baseline --encode-path $ep 2>&1 | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('path $ep', round(d['value'],1), d.get('kernel_ms'), d.get('bit_exact'))
-"; done
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "encode_paths or bucketed or model_pass" 2>&1 | tail -3
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -o trace -- python $GRAFT_REPO_ROOT/bench.py --streams 32768 --steps 2 --warmup 1 --no-cpu-baseline > /tmp/bench.json 2>/dev/null
+grep -o '"value": [0-9.]*\|"kernel_ms": {[^}]*}\|"bit_exact": [a-z]*' /tmp/bench.json
+find /tmp/tr -name '*kernel_stats*' -exec head -8 {} \; | cut -c1-120
