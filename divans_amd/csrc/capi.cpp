@@ -110,6 +110,7 @@ struct divans_gpu_codec {
     bool bucket_ok = false;       // the configuration allows it: order-1, no context map, no mixing, streams <= 64 KiB
     uint32_t encode_path = 0;     // 0 automatic (bucketed when bucket_ok), 1 streaming kernels, 2 bucketed
     uint8_t* d_bk = nullptr;      size_t bk_bytes = 0; uint32_t bk_streams = 0;
+    uint8_t* d_rs = nullptr;      size_t rs_bytes = 0;   // chunk-parallel rANS scratch when the bucket arrays are not there to reuse
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
     bool timing_pending_enc = false, timing_pending_dec = false;
@@ -266,6 +267,7 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->d_bk) (void)hipFree(c->d_bk);
+    if (c->d_rs) (void)hipFree(c->d_rs);
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
@@ -292,6 +294,30 @@ static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b
     b.tasks = (uint32_t*)p; p += sz_tasks;
     b.inv = (uint16_t*)p; p += sz_inv;
     b.sorted = p;
+    return 0;
+}
+
+// Scratch of the chunk-parallel rANS pass: one chunk bound per stream plus a size word.  After the bucketed model pass
+// its sorted-order pair array is dead (bucket_unsort_kernel has read it) and is reused; otherwise a separate allocation.
+static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, RansBatch& r) {
+    const uint64_t stride = divans_gpu_lit_encode_bound(32768);
+    const size_t need = (size_t)n_streams * stride + (size_t)n_streams * 4u + 64u;
+    uint8_t* base = nullptr;
+    if (use_bucket(c) && c->d_bk) {
+        const size_t pl = (size_t)bucket_pieces(c) * 8192u;
+        if ((size_t)n_streams * pl * 8u >= need) base = c->d_bk + 256;   // BucketBatch::sfs, see ensure_bucket
+    }
+    if (!base) {
+        if (need > c->rs_bytes) {
+            if (c->d_rs) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_rs)); c->d_rs = nullptr; c->rs_bytes = 0; }
+            if (hipMalloc(&c->d_rs, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(rANS chunk scratch) failed");
+            c->rs_bytes = need;
+        }
+        base = c->d_rs;
+    }
+    r.chunk0_sizes = (uint32_t*)base;
+    r.scratch = base + (((size_t)n_streams * 4u + 63u) & ~(size_t)63u);
+    r.scratch_stride = stride;
     return 0;
 }
 
@@ -407,6 +433,10 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     r.sf = c->d_sf; r.n_streams = n_streams; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
     r.in_sizes = d_in_sizes; r.out = d_out; r.out_slot = out_slot; r.out_offsets = d_out_offsets; r.out_sizes = d_out_sizes;
     r.status = c->d_status; r.chunk_bytes = d_chunk_bytes; r.max_chunks = max_chunks;
+    r.scratch = nullptr; r.scratch_stride = 0; r.chunk0_sizes = nullptr;
+    if (c->max_stream_len > 32768u && c->max_stream_len <= 65536u) {   // two chunks per stream slot: one lane per chunk
+        rc = ensure_rans_scratch(c, n_streams, r); if (rc) return rc;
+    }
     HIP_TRY(launch_rans_encode(r, c->stream));
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     c->timing_pending_enc = true;

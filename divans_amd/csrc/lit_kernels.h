@@ -49,6 +49,9 @@ struct RansBatch {
     const uint32_t* sf; uint32_t n_streams, stream_len, max_stream_len; const uint32_t* in_sizes;
     uint8_t* out; uint64_t out_slot; uint64_t* out_offsets; uint32_t* out_sizes; uint32_t* status;
     uint32_t* chunk_bytes; uint32_t max_chunks;   // optional [n_streams][max_chunks] coded size of every 65 536-symbol chunk
+    // chunk-parallel variant (streams of at most two chunks): chunk 0 is coded into scratch + (s + 1) * scratch_stride
+    // (right-aligned) and then moved in front of chunk 1; null scratch selects the one-lane-per-stream kernel
+    uint8_t* scratch; uint64_t scratch_stride; uint32_t* chunk0_sizes;
 };
 
 typedef unsigned int bk_u32x2 __attribute__((ext_vector_type(2)));

@@ -340,9 +340,15 @@ __device__ __forceinline__ uint32_t div31(uint32_t n, uint32_t d, float rcp, uin
     return q;
 }
 
+// The coded words leave through inline asm so that the compiler only sees in-order loads on vmcnt: with a visible
+// store next to them it waits with vmcnt(0) for every prefetched group, i.e. for the newest request as well.
+__device__ __forceinline__ void rans_store_word(uint32_t* p, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ uint64_t rans_put(uint64_t state, uint32_t start, uint32_t freq, uint32_t*& wp) {
     // rescale_lim = ((2^31 >> 15) << 32) * freq = freq << 48
-    if (state >= ((uint64_t)freq << 48)) { *--wp = (uint32_t)state; state >>= 32; }
+    if (state >= ((uint64_t)freq << 48)) { rans_store_word(--wp, (uint32_t)state); state >>= 32; }
     // state < freq * 2^48: long division by the 15-bit freq in three <2^31 / freq steps
     float rcp = __builtin_amdgcn_rcpf((float)freq);
     uint32_t hi = (uint32_t)(state >> 32), lo = (uint32_t)state;
@@ -352,6 +358,56 @@ __device__ __forceinline__ uint64_t rans_put(uint64_t state, uint32_t start, uin
     uint32_t q3 = div31((r2 << 16) | (lo & 0xffffu), freq, rcp, r3);
     uint64_t q = ((uint64_t)q1 << 32) | ((uint64_t)q2 << 16) | (uint64_t)q3;
     return (q << 15) + (uint64_t)r3 + (uint64_t)start;
+}
+
+// one 65 536-symbol chunk [beg, end) of a stream's (start,freq) pairs, newest symbol first; words grow downwards from wp
+__device__ __forceinline__ uint32_t* rans_encode_chunk(const uint32_t* sf, uint32_t beg, uint32_t end, uint32_t* wp, uint32_t& bad) {
+    uint64_t a = 1ull << 31, bst = 1ull << 31;
+    uint32_t i = end;
+    // the two states alternate, so consecutive symbols are independent chains
+    auto put = [&](uint32_t p) {
+        const uint32_t start = p & 0xffffu;
+        uint32_t freq = p >> 16;
+        bad |= (freq == 0u) | (freq >> 15) | (start >> 15);
+        freq = freq ? freq : 1u;
+        const uint64_t x = rans_put(a, start, freq, wp);
+        a = bst; bst = x;
+    };
+    while (i > beg && (i & 3u)) put(sf[--i]);             // ragged tail (nsym is even, so 0 or 2 symbols)
+    // The pairs arrive in 16-byte groups through a ring of four register quads (4 x 4 groups = 64 symbols), each quad
+    // requested three steps before it is coded.  Loads and their waits are inline asm: loads complete in order and
+    // every step issues exactly four (from the chunk's first group once nothing is left to request), so "at most 12
+    // operations outstanding" proves the quad requested three steps ago has arrived whatever the word stores in
+    // between are doing -- and with a step this long those stores are old enough not to be waited for either.
+    // The wait takes the registers as read-write operands, which keeps every use of the quad behind it.
+    struct Quad { u32x4 a, b, c, d; };
+    auto sat = [](uint32_t x, uint32_t k) { return x >= k ? x - k : 0u; };
+    auto request1 = [&](u32x4& q, uint32_t top) {
+        const uint32_t* p = sf + (top >= beg + 4u ? top - 4u : beg);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q) : "v"(p) : "memory");
+    };
+    auto request = [&](Quad& q, uint32_t top) {
+        request1(q.a, top); request1(q.b, sat(top, 4u)); request1(q.c, sat(top, 8u)); request1(q.d, sat(top, 12u));
+    };
+    auto code = [&](const u32x4& g) { if (i > beg) { put(g.w); put(g.z); put(g.y); put(g.x); i -= 4u; } };
+    Quad q0, q1, q2, q3;
+    request(q0, i); request(q1, sat(i, 16u)); request(q2, sat(i, 32u)); request(q3, sat(i, 48u));
+#define RANS_STEP(Q)   /* code the quad, then reuse its registers for the request 64 symbols on */ \
+    {                                                                                   \
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(Q.a), "+v"(Q.b), "+v"(Q.c), "+v"(Q.d) : : "memory"); \
+        const uint32_t top = i;                                                         \
+        code(Q.a); code(Q.b); code(Q.c); code(Q.d);                                     \
+        request(Q, sat(top, 64u));                                                      \
+    }
+    while (i > beg) { RANS_STEP(q0) RANS_STEP(q1) RANS_STEP(q2) RANS_STEP(q3) }
+#undef RANS_STEP
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.a), "+v"(q0.b), "+v"(q0.c), "+v"(q0.d), "+v"(q1.a), "+v"(q1.b), "+v"(q1.c), "+v"(q1.d) : : "memory");
+    asm volatile("" : "+v"(q2.a), "+v"(q2.b), "+v"(q2.c), "+v"(q2.d), "+v"(q3.a), "+v"(q3.b), "+v"(q3.c), "+v"(q3.d) : : "memory");
+    // unconditional swap (ans.rs:354-356), then [state_a][state_b] little-endian in front of the words
+    const uint64_t fa = bst, fb = a;
+    rans_store_word(--wp, (uint32_t)(fb >> 32)); rans_store_word(--wp, (uint32_t)fb);
+    rans_store_word(--wp, (uint32_t)(fa >> 32)); rans_store_word(--wp, (uint32_t)fa);
+    return wp;
 }
 
 __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBatch b) {
@@ -369,33 +425,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
     for (uint32_t ck = nchunks; ck-- > 0;) {
         const uint32_t beg = ck << 16;
         const uint32_t end = beg + 65536u < nsym ? beg + 65536u : nsym;
-        uint64_t a = 1ull << 31, bst = 1ull << 31;
-        uint32_t i = end;
-        // symbols are taken newest first; the two states alternate, so consecutive symbols are independent chains
-        auto put = [&](uint32_t p) {
-            const uint32_t start = p & 0xffffu;
-            uint32_t freq = p >> 16;
-            bad |= (freq == 0u) | (freq >> 15) | (start >> 15);
-            freq = freq ? freq : 1u;
-            const uint64_t x = rans_put(a, start, freq, wp);
-            a = bst; bst = x;
-        };
-        while (i > beg && (i & 3u)) put(sf[--i]);             // ragged tail (nsym is even, so 0 or 2 symbols)
-        if (i > beg) {
-            // 16-byte groups, the next group is requested before the current one is coded
-            uint4 cur = *(const uint4*)(sf + i - 4);
-            while (i > beg) {
-                i -= 4;
-                uint4 nxt = cur;
-                if (i > beg) nxt = *(const uint4*)(sf + i - 4);
-                put(cur.w); put(cur.z); put(cur.y); put(cur.x);
-                cur = nxt;
-            }
-        }
-        // unconditional swap (ans.rs:354-356), then [state_a][state_b] little-endian in front of the words
-        uint64_t fa = bst, fb = a;
-        *--wp = (uint32_t)(fb >> 32); *--wp = (uint32_t)fb;
-        *--wp = (uint32_t)(fa >> 32); *--wp = (uint32_t)fa;
+        wp = rans_encode_chunk(sf, beg, end, wp, bad);
         if (b.chunk_bytes) {   // bytes of chunk ck (the host replays the reference's per-chunk Mux drains with these)
             b.chunk_bytes[(size_t)s * b.max_chunks + ck] = (uint32_t)((uint8_t*)chunk_top - (uint8_t*)wp);
             chunk_top = wp;
@@ -405,6 +435,47 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
     b.out_offsets[s] = off;
     b.out_sizes[s] = (uint32_t)(slot_end - (uint8_t*)wp);
     if (bad) atomicOr(b.status, 1u);
+}
+
+// Streams of one or two chunks (at most 65 536 bytes): the chunks are independent rANS runs (states restart at 2^31,
+// ans.rs:331-378), so each gets its own lane.  Lane pair (2k, 2k+1) = chunks (0, 1) of stream k; chunk 1 lands
+// right-aligned in the stream's slot as before, chunk 0 in a scratch area, and rans_stitch_kernel puts it in front.
+__global__ __launch_bounds__(RANS_THREADS) void rans_encode2_kernel(const RansBatch b) {
+    const uint32_t g = blockIdx.x * RANS_THREADS + threadIdx.x;
+    const uint32_t s = g >> 1, ck = g & 1u;
+    const bool live = s < b.n_streams;
+    const uint32_t len = live ? (b.in_sizes ? b.in_sizes[s] : b.stream_len) : 0u;
+    const uint32_t nsym = 2u * len, beg = ck << 16;
+    uint8_t* slot_end = b.out + (uint64_t)(s + 1) * b.out_slot;
+    uint32_t size = 0, bad = 0;
+    if (live && beg < nsym) {
+        const uint32_t end = beg + 65536u < nsym ? beg + 65536u : nsym;
+        const uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
+        uint8_t* top = ck ? slot_end : b.scratch + (uint64_t)(s + 1) * b.scratch_stride;
+        uint32_t* wp = rans_encode_chunk(sf, beg, end, (uint32_t*)top, bad);
+        size = (uint32_t)(top - (uint8_t*)wp);
+        if (b.chunk_bytes) b.chunk_bytes[(size_t)s * b.max_chunks + ck] = size;
+    }
+    const uint32_t other = (uint32_t)__shfl_xor((int)size, 1);
+    if (live && ck == 0u) {
+        const uint32_t total = size + other;
+        b.out_sizes[s] = total;
+        b.out_offsets[s] = (uint64_t)(slot_end - b.out) - total;
+        b.chunk0_sizes[s] = size;
+    }
+    if (bad) atomicOr(b.status, 1u);
+}
+
+__global__ __launch_bounds__(256) void rans_stitch_kernel(const RansBatch b) {
+    // one wave per stream: chunk 0 from the scratch area to just below chunk 1
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const uint32_t nw = (gridDim.x * 256u) >> 6;
+    for (uint32_t s = wave; s < b.n_streams; s += nw) {
+        const uint32_t words = b.chunk0_sizes[s] >> 2;
+        const uint32_t* src = (const uint32_t*)(b.scratch + (uint64_t)(s + 1) * b.scratch_stride) - words;
+        uint32_t* dst = (uint32_t*)(b.out + b.out_offsets[s]);
+        for (uint32_t i = lane; i < words; i += 64u) dst[i] = __builtin_nontemporal_load(src + i);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -675,6 +746,13 @@ hipError_t launch_model_encode(const LitBatch& b_in, bool mix, uint32_t blocks, 
     return hipGetLastError();
 }
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
+    if (b.scratch) {   // one lane per chunk (streams of at most two chunks), then move chunk 0 in front of chunk 1
+        const uint32_t blocks = (2u * b.n_streams + RANS_THREADS - 1) / RANS_THREADS;
+        hipLaunchKernelGGL(rans_encode2_kernel, dim3(blocks), dim3(RANS_THREADS), 0, st, b);
+        const uint32_t sblocks = (b.n_streams + 3u) / 4u < 8192u ? (b.n_streams + 3u) / 4u : 8192u;
+        hipLaunchKernelGGL(rans_stitch_kernel, dim3(sblocks), dim3(256), 0, st, b);
+        return hipGetLastError();
+    }
     uint32_t blocks = (b.n_streams + RANS_THREADS - 1) / RANS_THREADS;
     hipLaunchKernelGGL(rans_encode_kernel, dim3(blocks), dim3(RANS_THREADS), 0, st, b);
     return hipGetLastError();
