@@ -14,13 +14,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 find $OUT/trace -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats.csv \;
 pmc_pass () {
   local name=$1; shift
-  rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py $BENCH_ARGS > /dev/null 2> $OUT/pmc_$name.log
+  timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py $BENCH_ARGS > /dev/null 2> $OUT/pmc_$name.log
   find $OUT/pmc_$name -name '*counter_collection*' -exec cp {} $OUT/pmc_$name.csv \;
 }
 if [ "${PMC:-1}" = "1" ]; then
 pmc_pass fetch FETCH_SIZE
 pmc_pass write WRITE_SIZE
 pmc_pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pmc_pass ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 pmc_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM
 pmc_pass sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 fi
@@ -32,7 +33,7 @@ ks = os.path.join(out, "kernel_stats.csv")
 if os.path.exists(ks):
     summary.append("== kernel stats (rocprofv3 --kernel-trace --stats)")
     summary.extend(open(ks).read().splitlines()[:12])
-for name in ("fetch", "write", "tcc", "sq", "sq2"):
+for name in ("fetch", "write", "tcc", "ea", "sq", "sq2"):
     p = os.path.join(out, f"pmc_{name}.csv")
     if not os.path.exists(p):
         summary.append(f"== pmc {name}: missing"); continue
@@ -47,4 +48,4 @@ for name in ("fetch", "write", "tcc", "sq", "sq2"):
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(summary) + "\n")
 print("\n".join(summary))
 PY
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_tcc $OUT/pmc_sq $OUT/pmc_sq2
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_tcc $OUT/pmc_ea $OUT/pmc_sq $OUT/pmc_sq2
