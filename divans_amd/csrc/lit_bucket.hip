@@ -162,6 +162,9 @@ __device__ __forceinline__ void bk_renorm(BkRow& r) {                           
     r.w1 = t1 - ((t1 >> 2) & 0x3fff3fffu);
 }
 
+__device__ __forceinline__ void bk_store_quad(u32x4* p, u32x4 v) {     // 8-byte aligned is enough for a global store
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void bk_store_pair(u32x2* p, u32x2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
@@ -202,9 +205,10 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     // vmcnt(3) for a byte requested four steps earlier instead of draining the queue (a visible store next to the
     // loads makes it fall back to vmcnt(0) on this target).  The hidden stores can only make that wait stricter.
 #define BK_OPAQUE(X) asm volatile("" : "+v"(X))
-#define BK_STEP(E, A)                                                                                   \
+#define BK_STEP(E, A, PV, PA)                                                                                   \
     {                                                                                                   \
         BK_OPAQUE(E);  /* keeps the compiler from touching the byte (and waiting for it) before this point */ \
+        PA = A;                                                                                         \
         if (A & BK_VALID) {                                                                             \
             const uint32_t byte_ = E >> ((A >> 13) & 24u);   /* A bits 16-17: which byte of the aligned word */ \
             const uint32_t hi = (byte_ >> 4) & 15u, lo = byte_ & 15u;                                   \
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
             if ((int)(H.w1.w >> 16) >= lim) bk_renorm(H);                                               \
             if ((int)(L.w1.w >> 16) >= lim) bk_renorm(L);                                               \
             *(u32x4*)my = H.w0; *(u32x4*)(my + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
-            bk_store_pair(cur_sfs + (A & 0xffffu), v);                                                  \
+            PV = v;                                                                                     \
         }                                                                                               \
         /* fetch side, branch-free: next piece of the bucket when the current one is used up (an empty piece costs \
            the lane this step), then one more byte */                                                   \
@@ -233,7 +237,22 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     }
 
     for (;;) {
-        BK_STEP(e0, a0) BK_STEP(e1, a1) BK_STEP(e2, a2) BK_STEP(e3, a3)
+        u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0; uint32_t pa0, pa1, pa2, pa3;
+        BK_STEP(e0, a0, pv0, pa0) BK_STEP(e1, a1, pv1, pa1) BK_STEP(e2, a2, pv2, pa2) BK_STEP(e3, a3, pv3, pa3)
+        {   // the four pairs of this iteration: one 32-byte run when they are neighbours in the sorted order (the usual
+            // case inside a bucket), single pairs otherwise -- a quarter of the write requests
+            const uint32_t i0 = pa0 & 0xffffu;
+            const bool run4 = (pa0 & pa1 & pa2 & pa3 & BK_VALID) && (pa1 & 0xffffu) == i0 + 1u && (pa2 & 0xffffu) == i0 + 2u && (pa3 & 0xffffu) == i0 + 3u;
+            if (run4) {
+                const u32x4 lo = {pv0.x, pv0.y, pv1.x, pv1.y}, hi = {pv2.x, pv2.y, pv3.x, pv3.y};
+                bk_store_quad((u32x4*)(cur_sfs + i0), lo); bk_store_quad((u32x4*)(cur_sfs + i0 + 2u), hi);
+            } else {
+                if (pa0 & BK_VALID) bk_store_pair(cur_sfs + i0, pv0);
+                if (pa1 & BK_VALID) bk_store_pair(cur_sfs + (pa1 & 0xffffu), pv1);
+                if (pa2 & BK_VALID) bk_store_pair(cur_sfs + (pa2 & 0xffffu), pv2);
+                if (pa3 & BK_VALID) bk_store_pair(cur_sfs + (pa3 & 0xffffu), pv3);
+            }
+        }
         // a lane whose bucket ended at least one full iteration ago (all its bytes coded) takes its prefetched task
         const bool bytes_in_flight = fresh_finish;   // bytes requested in this iteration are coded in the next one
         if (!has_task) {

@@ -1,2 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_ffi.py -x -q -m gpu 2>&1 | tail -3
-timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"kernel_ms": {[^}]*}\|"bit_exact": [a-z]*'
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "encode_paths or bucketed or model_pass or ragged" 2>&1 | tail -3
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /tmp/bench.json 2>/dev/null
+grep -o '"value": [0-9.]*\|"kernel_ms": {[^}]*}\|"bit_exact": [a-z]*' /tmp/bench.json
+find /tmp/tr -name '*kernel_stats*' -exec head -9 {} \; | cut -c1-120
