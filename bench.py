@@ -191,12 +191,14 @@ def main():
         value = total_bytes / 1e6 / (elapsed / K)
         avg = lambda xs: sum(xs) / max(len(xs), 1)
         # dominant kernel: the one with the largest average launch duration
-        kern = {"lit_decode_kernel": avg(dkern_ms), "lit_model_encode_kernel": avg(model_ms), "rans_encode_kernel": avg(rans_ms)}
+        # hipEvent spans taken inside the C ABI: the decode kernel; the encoder's model pass (bucket_sort/tasks/chain/unsort
+        # kernels, or lit_model_encode_kernel on the streaming path); its rANS pass (rans_encode2 + rans_stitch kernels)
+        kern = {"lit_decode_kernel": avg(dkern_ms), "encode_model_pass": avg(model_ms), "encode_rans_pass": avg(rans_ms)}
         dom = max(kern, key=kern.get)
         raw, coded = N * L, coded_total
         # algorithmic bytes per launch: decode reads C + writes raw; the model pass reads raw and
         # hands 4 B per nibble to the rANS pass; the rANS pass reads that spill and writes C
-        alg = {"lit_decode_kernel": raw + coded, "lit_model_encode_kernel": raw + 8 * raw, "rans_encode_kernel": 8 * raw + coded}[dom]
+        alg = {"lit_decode_kernel": raw + coded, "encode_model_pass": raw + 8 * raw, "encode_rans_pass": 8 * raw + coded}[dom]
         achieved = alg / 1e9 / (kern[dom] / 1e3)
         # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes of this same workload, committed under profiles/
         traffic = None
