@@ -87,6 +87,16 @@ def main():
     rtu = open(f"{REF}/testdata/random_then_unicode", "rb").read()
     with lzma.open(f"{OUT}/random_then_unicode.xz", "wb", preset=9) as f:
         f.write(rtu)
+    # 6. a brotli-derived PredictionMode: the `prediction` line of testdata/alice29-priors.ir (text IR of a brotli -q11 run
+    #    with context-map clustering and per-context mixing values, parsed like src/bin/divans.rs:205-318):
+    #    128 literal-context-map entries (2 block types x 64) then 8192 mixing values; mode utf8, all speeds 0 (= default)
+    pred = [l for l in open(f"{REF}/testdata/alice29-priors.ir") if l.startswith("prediction")][0].split()
+    assert pred[1] == "utf8"
+    i, j, k, m = (pred.index(t) for t in ("lcontextmap", "dcontextmap", "mixingvalues", "cmspeedinc"))
+    lmap = [int(x) for x in pred[i + 1:j]]
+    mix = [int(x) for x in pred[k + 1:m]]
+    assert len(lmap) == 128 and len(mix) == 8192 and all(x == "0" for x in pred[m:] if x.isdigit())
+    np.array(lmap + mix, dtype=np.uint8).tofile(f"{OUT}/alice29_priors_prediction.bin")
     print("golden fixtures written to", OUT)
 
 

@@ -221,6 +221,23 @@ def test_uniform_mm0_specialisation(corpus):
     codec.close()
 
 
+@pytest.mark.parametrize("btype", [0, 1])
+@pytest.mark.parametrize("context_mixing", [0, 2])
+def test_brotli_derived_prediction_mode(btype, context_mixing, corpus):
+    # configuration a real brotli -q11 run produced (reference testdata/alice29-priors.ir): clustered context map,
+    # per-context mixing values 0/1/2/3, both literal block types; with and without dynamic mixing
+    import divans_amd as da
+    g = workload.brotli_derived_config(da.LitConfig(), btype, context_mixing)
+    o = workload.brotli_derived_config(po.LitConfig(), btype, context_mixing)
+    blocks = np.stack([corpus[k * 30011:k * 30011 + 30000] for k in range(8)])
+    codec = da.LiteralCodec(g, 30000)
+    packed, offs, sizes = codec.encode_host(blocks, 30000)
+    for i in range(blocks.shape[0]):
+        assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == po.lit_encode(o, blocks[i])).all(), i
+    assert (codec.decode_host(packed, offs, sizes, 30000) == blocks).all()
+    codec.close()
+
+
 def test_unsupported_speed_is_rejected():
     import divans_amd as da
     g = da.config_simple()

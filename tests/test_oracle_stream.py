@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+import workload
+
 import pyoracle as po
 from conftest import GOLDEN
 
@@ -98,3 +100,19 @@ def test_stream_lit_bytes_equal_literal_coder(corpus):
     assert L.orc_mux_demux(body.ctypes.data, body.size, s0.ctypes.data, ctypes.byref(n0), s1.ctypes.data, ctypes.byref(n1), ctypes.byref(used)) == 0
     ref = po.lit_encode(po.config_simple(), blk)
     assert n1.value == ref.size and (s1[:n1.value] == ref).all()
+
+
+def test_brotli_derived_prediction_mode_round_trips(corpus):
+    # the PredictionMode of reference testdata/alice29-priors.ir (golden fixture) through the oracle's literal coder:
+    # round trip; dynamic mixing of the stride prior with the context-map prior must beat either map alone.  (The map
+    # was clustered for the literals brotli leaves after its copies, so on the whole text it is no match for order 1.)
+    data = corpus[:152089]
+    sizes = {}
+    for btype in (0, 1):
+        for mixing in (0, 2):
+            cfg = workload.brotli_derived_config(po.LitConfig(), btype, mixing)
+            coded = po.lit_encode(cfg, data)
+            assert (po.lit_decode(cfg, coded, data.size) == data).all()
+            sizes[(btype, mixing)] = coded.size
+    for btype in (0, 1):
+        assert sizes[(btype, 2)] < sizes[(btype, 0)] < 0.55 * data.size

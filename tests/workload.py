@@ -49,3 +49,22 @@ def make_blocks(corpus, first, count, block_len=65536, perturb_per_block=None):
             val[val == 0] = 1
             blocks[rows, pos.astype(np.int64)] ^= val
     return blocks
+
+
+def brotli_derived_config(cfg, btype, context_mixing):
+    """Fill a LitConfig (oracle or product layout: same fields) with the PredictionMode brotli -q11 produced for
+    alice29 (tests/golden/alice29_priors_prediction.bin <- reference testdata/alice29-priors.ir): clustered literal
+    context map for 2 block types, per-context mixing values (0 context-map only, 1 half-byte + context, 2 no prior,
+    3 context only without the nibble), utf8 context lookups, default speeds (the IR carries none)."""
+    import ctypes
+    raw = np.fromfile(os.path.join(GOLDEN, "alice29_priors_prediction.bin"), dtype=np.uint8)
+    cmap = np.zeros(256 * 64, dtype=np.uint8); cmap[:128] = raw[:128]
+    mix = np.ascontiguousarray(raw[128:128 + 8192])
+    ctypes.memmove(cfg.literal_context_map, cmap.ctypes.data, cmap.size)
+    ctypes.memmove(cfg.mixing_mask, mix.ctypes.data, mix.size)
+    cfg.prediction_mode = 2
+    cfg.btype = btype
+    cfg.context_mixing = context_mixing
+    for i in range(4):
+        cfg.literal_adaptation[i].inc = 0x10; cfg.literal_adaptation[i].lim = 0x2000   # Speed::MUD, probability/interface.rs:323
+    return cfg
