@@ -224,7 +224,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the host-core baseline is a single-GPU-run item
             line["cpu_baseline"] = cpu_baseline(args.config, workload, corpus, L)
         print(json.dumps(line))
         if not ok_all:
