@@ -34,6 +34,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const BucketBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t staging[BK_PIECE];
+    __shared__ __attribute__((aligned(16))) uint8_t piece_in[16 + BK_PIECE];   // piece_in[15] = the byte before the piece
     __shared__ uint32_t hist[4][256];
     __shared__ uint32_t scan[256];
     const uint32_t s = blockIdx.x / b.pieces, piece = blockIdx.x % b.pieces;
@@ -46,14 +47,25 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const Buck
     const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
     const size_t pl = (size_t)b.pieces * BK_PIECE;
     for (uint32_t i = tid; i < 1024u; i += BK_SORT_THREADS) (&hist[0][0])[i] = 0u;
+    // the piece (and the byte before it: the first key) once into LDS, 16 bytes per lane where alignment allows
+    {
+        const uint8_t* src = in + base;
+        if ((((uintptr_t)src) & 15u) == 0u) {
+            for (uint32_t i = tid * 16u; i < n; i += BK_SORT_THREADS * 16u) {
+                if (i + 16u <= n) *(u32x4*)(piece_in + 16u + i) = *(const u32x4*)(src + i);
+                else for (uint32_t k = i; k < n; ++k) piece_in[16u + k] = src[k];
+            }
+        } else {
+            for (uint32_t i = tid; i < n; i += BK_SORT_THREADS) piece_in[16u + i] = src[i];
+        }
+        if (tid == 0u) piece_in[15] = base ? in[base - 1u] : 0u;
+    }
     __syncthreads();
+    const uint8_t* key_of = piece_in + 15;      // key_of[p] = previous byte of position p, key_of[p + 1] = its own byte
     // wave w owns positions [2048 w, 2048 w + 2048) of the piece and visits them in order, 64 at a time
     for (uint32_t bt = 0; bt < 32u; ++bt) {
         const uint32_t p = w * 2048u + bt * 64u + lane;
-        if (p < n) {
-            const uint32_t key = (base + p) ? in[base + p - 1u] : 0u;
-            atomicAdd(&hist[w][key], 1u);
-        }
+        if (p < n) atomicAdd(&hist[w][key_of[p]], 1u);
     }
     __syncthreads();
     const uint32_t c0 = hist[0][tid], c1 = hist[1][tid], c2 = hist[2][tid], c3 = hist[3][tid];
@@ -74,8 +86,8 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const Buck
     for (uint32_t bt = 0; bt < 32u; ++bt) {
         const uint32_t p = w * 2048u + bt * 64u + lane;
         const bool valid = p < n;
-        const uint32_t key = valid ? ((base + p) ? in[base + p - 1u] : 0u) : 0u;
-        const uint32_t byte = valid ? in[base + p] : 0u;
+        const uint32_t key = valid ? key_of[p] : 0u;
+        const uint32_t byte = valid ? key_of[p + 1u] : 0u;
         unsigned long long same = __ballot(valid);
         for (uint32_t bit = 0; bit < 8u; ++bit) {
             const bool set = (key >> bit) & 1u;
@@ -92,8 +104,8 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const Buck
     }
     __syncthreads();
     uint8_t* sorted = b.sorted + (size_t)s * pl + base;
-    for (uint32_t i = tid * 4u; i < n; i += BK_SORT_THREADS * 4u) {
-        if (i + 4u <= n) *(uint32_t*)(sorted + i) = *(const uint32_t*)(staging + i);
+    for (uint32_t i = tid * 16u; i < n; i += BK_SORT_THREADS * 16u) {
+        if (i + 16u <= n) *(u32x4*)(sorted + i) = *(const u32x4*)(staging + i);
         else for (uint32_t k = i; k < n; ++k) sorted[k] = staging[k];
     }
 }
