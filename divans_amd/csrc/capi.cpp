@@ -246,7 +246,7 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
     c->blocks = c->num_cus * 4u;  // 16 waves = 64 streams per CU (tuned on MI355X)
     // high-nibble rows only: few and hot (32 ways ~ 90 % of their accesses); mixing configurations keep one unified cache
-    if (c->geom.total_rows < 0x7fffu) { c->cache_high = 64u; c->cache_low = 0u; c->cache_unified = c->mix; }
+    if (c->geom.total_rows < 0x7fffu) { c->cache_high = 64u; c->cache_low = 0u; c->cache_unified = false; }
     c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && c->geom.ctx_const >= 0 && c->max_stream_len <= 65536u;
     c->packed8 = false;   // the packed 8-lane kernels (set_lane_layout(8)) are bit-identical; on MI355X the 16-lane ones are faster
     if (hipMalloc(&c->d_blob, LIT_BLOB_BYTES) != hipSuccess || hipMalloc(&c->d_status, 64) != hipSuccess) {
