@@ -274,7 +274,7 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
 }
 
 static uint32_t bucket_pieces(const divans_gpu_codec* c) { return (c->max_stream_len + 8191u) / 8192u; }
-static bool use_bucket(const divans_gpu_codec* c) { return c->bucket_ok && c->encode_path != 1u; }
+static bool use_bucket(const divans_gpu_codec* c) { return c->bucket_ok && c->encode_path != 1u; }   // task ids are stream * 256 + byte in 32 bits: callers keep n_streams < 2^24
 
 // one allocation carved into the five work arrays of BucketBatch
 static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b) {
@@ -305,7 +305,7 @@ static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, RansBatc
     uint8_t* base = nullptr;
     if (use_bucket(c) && c->d_bk) {
         const size_t pl = (size_t)bucket_pieces(c) * 8192u;
-        if ((size_t)n_streams * pl * 8u >= need) base = c->d_bk + 256;   // BucketBatch::sfs, see ensure_bucket
+        if ((size_t)n_streams * pl * 8u >= need && c->bk_bytes >= 256u + need) base = c->d_bk + 256;   // BucketBatch::sfs, see ensure_bucket
     }
     if (!base) {
         if (need > c->rs_bytes) {
@@ -377,7 +377,7 @@ extern "C" size_t divans_gpu_lit_encode_bound(size_t n) {
 static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes,
                       uint32_t stream_len, uint32_t n_streams) {
     int rc = ensure_sf(c, n_streams); if (rc) return rc;
-    if (use_bucket(c)) {
+    if (use_bucket(c) && n_streams < (1u << 24)) {
         BucketBatch k;
         std::memset(&k, 0, sizeof(k));
         rc = ensure_bucket(c, n_streams, k); if (rc) return rc;
