@@ -17,7 +17,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // value of lane `n` of this 16-lane row, broadcast to the whole row (v_mov_b32_dpp row_newbcast)
 template <int N>
 __device__ __forceinline__ int row_bcast(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST(N), 0xf, 0xf, false);
+    // every lane of the row receives lane N, so the "old" operand is never used: leave it undefined (no zero-fill move)
+    return __builtin_amdgcn_mov_dpp(v, DPP_ROW_BCAST(N), 0xf, 0xf, false);
 }
 // value of the previous lane in the row, 0 for the first lane
 __device__ __forceinline__ int row_prev_or_zero(int v) {

@@ -96,6 +96,14 @@ struct Table {
 
 // frequentist_cdf.rs:74-85 on one entry per lane (li = lane index in row).  The host rejects speeds with
 // inc + lim + 16 > 0x7fff, so no i16 wrap can occur and plain 32-bit arithmetic is exact.
+// same, when the row's total before the update is already at hand (cdf[15] always takes the increment, so the
+// renormalisation test needs no second broadcast)
+__device__ __forceinline__ int blend_row_known_max(int c, int li, int sym, int inc, int lim, int old_max) {
+    c = (li >= sym) ? c + inc : c;
+    int t = c + li + 1;
+    int renorm = t - (t >> 2);
+    return old_max + inc >= lim ? renorm : c;
+}
 __device__ __forceinline__ int blend_row(int c, int li, int sym, int inc, int lim) {
     c = (li >= sym) ? c + inc : c;
     int c15 = row_bcast<15>(c);
@@ -213,7 +221,7 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
         packed = (uint32_t)row_gather((int)sf, rbase, sym);
         uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
         weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)(packed >> 16));
-        cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
+        cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
         tb.store(cref, cm);
     } else {
         int cv = ((MM < 0 || MM == 2) && rs.is_default) ? 4 * (li + 1) : st;
@@ -251,7 +259,7 @@ __device__ __forceinline__ uint32_t model_finish(const LitGeometry& g, const Tab
     const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
     const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
     int st = f.value;
-    if (!f.is_default) st = blend_row(st, li, sym, g.inc0, g.lim0);
+    if (!f.is_default) st = blend_row_known_max(st, li, sym, g.inc0, g.lim0, mx);   // cv == f.value here, so mx is its total
     if (CACHE != 0 || !f.is_default) tb.store(f.ref, st);
     return packed;
 }
@@ -530,7 +538,7 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const Ld
         uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
         uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
         weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)freq);
-        cm = blend_row(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2);
+        cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
         tb.store(cref, cm);
     }
     if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0);
@@ -562,7 +570,7 @@ __device__ __forceinline__ void finish_nibble(const LitGeometry& g, const Table<
     const uint32_t start = packed & 0xffffu, freq = packed >> 16;
     S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;     // helper_advance_sym, ans.rs:238
     int st = f.value;
-    if (!f.is_default) st = blend_row(st, li, sym, g.inc0, g.lim0);
+    if (!f.is_default) st = blend_row_known_max(st, li, sym, g.inc0, g.lim0, mx);   // cv == f.value here, so mx is its total
     if (CACHE != 0 || !f.is_default) tb.store(f.ref, st);
 }
 
