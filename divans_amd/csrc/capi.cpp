@@ -110,7 +110,9 @@ struct divans_gpu_codec {
     bool bucket_ok = false;       // the configuration allows it: order-1, no context map, no mixing, streams <= 64 KiB
     uint32_t encode_path = 0;     // 0 automatic (bucketed when bucket_ok), 1 streaming kernels, 2 bucketed
     uint8_t* d_bk = nullptr;      size_t bk_bytes = 0; uint32_t bk_streams = 0;
-    uint8_t* d_rs = nullptr;      size_t rs_bytes = 0;   // chunk-parallel rANS scratch when the bucket arrays are not there to reuse
+    uint8_t* d_rs = nullptr;      size_t rs_bytes = 0;
+    void* host_scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device buffers of the host-buffer entry points, grow-only
+    size_t host_scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // chunk-parallel rANS scratch when the bucket arrays are not there to reuse
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
     bool timing_pending_enc = false, timing_pending_dec = false;
@@ -268,6 +270,7 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_rs) (void)hipFree(c->d_rs);
+    for (void* q : c->host_scratch) if (q) (void)hipFree(q);
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
@@ -537,6 +540,19 @@ extern "C" int divans_gpu_lit_encode_host(divans_gpu_codec* c, const uint8_t* in
                                              out_total, nullptr, 0);
 }
 
+// The host-buffer entry points keep their device buffers between calls (allocating and freeing gigabytes per call
+// costs more than the kernels); `which` names the buffer, capacity only grows.
+template <typename T>
+static int host_scratch(divans_gpu_codec* c, int which, size_t bytes, T** out) {
+    if (bytes > c->host_scratch_cap[which]) {
+        if (c->host_scratch[which]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->host_scratch[which])); c->host_scratch[which] = nullptr; c->host_scratch_cap[which] = 0; }
+        if (hipMalloc(&c->host_scratch[which], bytes) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(host-buffer staging) failed");
+        c->host_scratch_cap[which] = bytes;
+    }
+    *out = (T*)c->host_scratch[which];
+    return 0;
+}
+
 extern "C" int divans_gpu_lit_encode_host_chunks(divans_gpu_codec* c, const uint8_t* in, uint32_t stream_len, uint32_t n_streams,
                                                  uint8_t* out_packed, size_t out_cap, uint64_t* out_offsets, uint32_t* out_sizes,
                                                  size_t* out_total, uint32_t* out_chunk_bytes, uint32_t max_chunks) {
@@ -548,20 +564,17 @@ extern "C" int divans_gpu_lit_encode_host_chunks(divans_gpu_codec* c, const uint
     uint8_t *d_in = nullptr, *d_slots = nullptr, *d_packed = nullptr;
     uint64_t *d_off = nullptr, *d_poff = nullptr, *d_total = nullptr; uint32_t* d_sz = nullptr; uint32_t* d_chunks = nullptr;
     int rc = 0;
-    auto cleanup = [&]() {
-        (void)hipFree(d_in); (void)hipFree(d_slots); (void)hipFree(d_packed); (void)hipFree(d_off); (void)hipFree(d_poff);
-        (void)hipFree(d_total); (void)hipFree(d_sz); (void)hipFree(d_chunks);
-    };
+    auto cleanup = [&]() {};
 #define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(DIVANS_GPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    TRY_OR_CLEAN(hipMalloc(&d_in, in_bytes + 64));
-    TRY_OR_CLEAN(hipMalloc(&d_slots, slot * n_streams + 64));
-    TRY_OR_CLEAN(hipMalloc(&d_packed, slot * n_streams + 64));
-    TRY_OR_CLEAN(hipMalloc(&d_off, sizeof(uint64_t) * n_streams));
-    TRY_OR_CLEAN(hipMalloc(&d_poff, sizeof(uint64_t) * n_streams));
-    TRY_OR_CLEAN(hipMalloc(&d_total, sizeof(uint64_t)));
-    TRY_OR_CLEAN(hipMalloc(&d_sz, sizeof(uint32_t) * n_streams));
+    if ((rc = host_scratch(c, 0, in_bytes + 64, &d_in))) return rc;
+    if ((rc = host_scratch(c, 1, slot * n_streams + 64, &d_slots))) return rc;
+    if ((rc = host_scratch(c, 2, slot * n_streams + 64, &d_packed))) return rc;
+    if ((rc = host_scratch(c, 3, sizeof(uint64_t) * n_streams, &d_off))) return rc;
+    if ((rc = host_scratch(c, 4, sizeof(uint64_t) * n_streams, &d_poff))) return rc;
+    if ((rc = host_scratch(c, 5, sizeof(uint64_t), &d_total))) return rc;
+    if ((rc = host_scratch(c, 6, sizeof(uint32_t) * n_streams, &d_sz))) return rc;
     if (out_chunk_bytes) {
-        TRY_OR_CLEAN(hipMalloc(&d_chunks, sizeof(uint32_t) * (size_t)n_streams * max_chunks));
+        if ((rc = host_scratch(c, 7, sizeof(uint32_t) * (size_t)n_streams * max_chunks, &d_chunks))) return rc;
         TRY_OR_CLEAN(hipMemsetAsync(d_chunks, 0, sizeof(uint32_t) * (size_t)n_streams * max_chunks, c->stream));
     }
     TRY_OR_CLEAN(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
@@ -595,11 +608,12 @@ extern "C" int divans_gpu_lit_decode_host(divans_gpu_codec* c, const uint8_t* in
         total = std::max<size_t>(total, in_offsets[i] + in_sizes[i]);
     }
     uint8_t *d_in = nullptr, *d_out = nullptr; uint64_t* d_off = nullptr; uint32_t* d_sz = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_off); (void)hipFree(d_sz); };
-    TRY_OR_CLEAN(hipMalloc(&d_in, total + 128));
-    TRY_OR_CLEAN(hipMalloc(&d_out, (size_t)stream_len * n_streams + 64));
-    TRY_OR_CLEAN(hipMalloc(&d_off, sizeof(uint64_t) * n_streams));
-    TRY_OR_CLEAN(hipMalloc(&d_sz, sizeof(uint32_t) * n_streams));
+    auto cleanup = [&]() {};
+    int rc0 = 0;
+    if ((rc0 = host_scratch(c, 0, total + 128, &d_in))) return rc0;
+    if ((rc0 = host_scratch(c, 1, (size_t)stream_len * n_streams + 64, &d_out))) return rc0;
+    if ((rc0 = host_scratch(c, 3, sizeof(uint64_t) * n_streams, &d_off))) return rc0;
+    if ((rc0 = host_scratch(c, 6, sizeof(uint32_t) * n_streams, &d_sz))) return rc0;
     TRY_OR_CLEAN(hipMemcpyAsync(d_in, in_packed, total, hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_off, in_offsets, sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_sz, in_sizes, sizeof(uint32_t) * n_streams, hipMemcpyHostToDevice, c->stream));
