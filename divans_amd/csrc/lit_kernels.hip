@@ -339,33 +339,36 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
 // Encode, pass 2: rANS.  One lane per stream, walks the (start,freq) pairs newest -> oldest and
 // writes the coded bytes right-aligned into the stream's slot.  ans.rs:302-378.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t div31(uint32_t n, uint32_t d, float rcp, uint32_t& rem) {
-    uint32_t q = (uint32_t)((float)n * rcp);
-    int32_t r = (int32_t)(n - q * d);
-    if (r < 0) { q -= 1; r += (int32_t)d; }
-    else if (r >= (int32_t)d) { q += 1; r -= (int32_t)d; }
-    rem = (uint32_t)r;
-    return q;
-}
-
 // The coded words leave through inline asm so that the compiler only sees in-order loads on vmcnt: with a visible
 // store next to them it waits with vmcnt(0) for every prefetched group, i.e. for the newest request as well.
 __device__ __forceinline__ void rans_store_word(uint32_t* p, uint32_t v) {
     asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 
+// (state / freq, state % freq) for state < freq << 48 (so state < 2^63, quotient < 2^48) in ONE double-precision step:
+// the product of (double)state and a reciprocal refined to full precision and biased low by 2^-49 is below the true
+// quotient x by less than x * 2^-48.4 + rounding < 1, so its integer part is q or q - 1 and a single compare of the
+// remainder (which then fits 32 bits) finishes it.  Checked against 64-bit '/' and '%' by selftest_division_kernel.
+__device__ __forceinline__ uint64_t rans_divmod(uint64_t state, uint32_t freq, uint32_t& rem) {
+    const double fd = (double)freq;
+    double y = __builtin_amdgcn_rcp(fd);
+    y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
+    y *= (1.0 - 0x1p-49);
+    const double qd = (double)state * y;
+    uint64_t q = (uint64_t)qd;
+    uint32_t r = (uint32_t)state - (uint32_t)q * freq;     // low 32 bits are enough: the true remainder is below 2 * freq
+    if (r >= freq) { q += 1; r -= freq; }
+    rem = r;
+    return q;
+}
+
 __device__ __forceinline__ uint64_t rans_put(uint64_t state, uint32_t start, uint32_t freq, uint32_t*& wp) {
     // rescale_lim = ((2^31 >> 15) << 32) * freq = freq << 48
     if (state >= ((uint64_t)freq << 48)) { rans_store_word(--wp, (uint32_t)state); state >>= 32; }
-    // state < freq * 2^48: long division by the 15-bit freq in three <2^31 / freq steps
-    float rcp = __builtin_amdgcn_rcpf((float)freq);
-    uint32_t hi = (uint32_t)(state >> 32), lo = (uint32_t)state;
-    uint32_t r1, r2, r3;
-    uint32_t q1 = div31(hi, freq, rcp, r1);
-    uint32_t q2 = div31((r1 << 16) | (lo >> 16), freq, rcp, r2);
-    uint32_t q3 = div31((r2 << 16) | (lo & 0xffffu), freq, rcp, r3);
-    uint64_t q = ((uint64_t)q1 << 32) | ((uint64_t)q2 << 16) | (uint64_t)q3;
-    return (q << 15) + (uint64_t)r3 + (uint64_t)start;
+    uint32_t r;
+    const uint64_t q = rans_divmod(state, freq, r);        // ans.rs:318-323: ((state / freq) << 15) + state % freq + start
+    return (q << 15) + (uint64_t)r + (uint64_t)start;
 }
 
 // one 65 536-symbol chunk [beg, end) of a stream's (start,freq) pairs, newest symbol first; words grow downwards from wp
@@ -694,12 +697,18 @@ __global__ void selftest_division_kernel(unsigned long long* mismatches) {
             bad += exact_div(n, mx, rcp) != n / mx;
             bad += scaled_div((int)c, (int)mx, biased_rcp15((int)mx)) != n / mx;
         }
-        // the rANS long division uses numerators up to 2^31 - 1
+        // the rANS step divides a state below mx << 48 by mx: boundary states, multiples of mx +- 1, and a spread of others
         for (uint32_t k = threadIdx.x; k < 4096u; k += blockDim.x) {
-            uint32_t n = (mx << 16) - 1u - k * 7u;
-            uint32_t rem;
-            uint32_t q = div31(n, mx, rcp, rem);
-            bad += (q != n / mx) | (rem != n % mx);
+            const uint64_t top = (uint64_t)mx << 48;
+            uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull + (uint64_t)mx * 0xD1B54A32D192ED03ull;
+            x ^= x >> 29;
+            const uint64_t cand[6] = {top - 1ull - k, (x % top), (x % top) / mx * mx, ((x % top) / mx * mx) + mx - 1ull,
+                                      (1ull << 31) + k * 977ull, (x >> (k & 31)) % top};
+            for (int j = 0; j < 6; ++j) {
+                uint32_t rem;
+                const uint64_t q = rans_divmod(cand[j], mx, rem);
+                bad += (q != cand[j] / mx) | (rem != (uint32_t)(cand[j] % mx));
+            }
         }
     }
     if (bad) atomicAdd(mismatches, bad);
