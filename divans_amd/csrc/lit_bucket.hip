@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     bool nxt_pending = false, drained = false;
     // four bytes in flight per lane: requested one loop iteration before they are coded
     uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t e4 = 0, e5 = 0, e6 = 0, e7 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
 
     // Every step issues exactly one byte load (from a harmless address when the lane has nothing to fetch) and the
     // pair store goes out through inline asm: the compiler then sees only in-order loads on vmcnt and waits with
@@ -249,22 +250,27 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     }
 
     for (;;) {
-        u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0; uint32_t pa0, pa1, pa2, pa3;
-        BK_STEP(e0, a0, pv0, pa0) BK_STEP(e1, a1, pv1, pa1) BK_STEP(e2, a2, pv2, pa2) BK_STEP(e3, a3, pv3, pa3)
-        {   // the four pairs of this iteration: one 32-byte run when they are neighbours in the sorted order (the usual
-            // case inside a bucket), single pairs otherwise -- a quarter of the write requests
-            const uint32_t i0 = pa0 & 0xffffu;
-            const bool run4 = (pa0 & pa1 & pa2 & pa3 & BK_VALID) && (pa1 & 0xffffu) == i0 + 1u && (pa2 & 0xffffu) == i0 + 2u && (pa3 & 0xffffu) == i0 + 3u;
-            if (run4) {
-                const u32x4 lo = {pv0.x, pv0.y, pv1.x, pv1.y}, hi = {pv2.x, pv2.y, pv3.x, pv3.y};
-                bk_store_quad((u32x4*)(cur_sfs + i0), lo); bk_store_quad((u32x4*)(cur_sfs + i0 + 2u), hi);
-            } else {
-                if (pa0 & BK_VALID) bk_store_pair(cur_sfs + i0, pv0);
-                if (pa1 & BK_VALID) bk_store_pair(cur_sfs + (pa1 & 0xffffu), pv1);
-                if (pa2 & BK_VALID) bk_store_pair(cur_sfs + (pa2 & 0xffffu), pv2);
-                if (pa3 & BK_VALID) bk_store_pair(cur_sfs + (pa3 & 0xffffu), pv3);
-            }
+        // eight steps per iteration (eight words in flight per lane), stored as two groups of four pairs: one 32-byte
+        // run when the four are neighbours in the sorted order (the usual case inside a bucket), single pairs otherwise
+#define BK_FOUR(E0, A0, E1, A1, E2, A2, E3, A3)                                                         \
+        {                                                                                               \
+            u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0; uint32_t pa0, pa1, pa2, pa3;         \
+            BK_STEP(E0, A0, pv0, pa0) BK_STEP(E1, A1, pv1, pa1) BK_STEP(E2, A2, pv2, pa2) BK_STEP(E3, A3, pv3, pa3) \
+            const uint32_t i0 = pa0 & 0xffffu;                                                          \
+            const bool run4 = (pa0 & pa1 & pa2 & pa3 & BK_VALID) && (pa1 & 0xffffu) == i0 + 1u && (pa2 & 0xffffu) == i0 + 2u && (pa3 & 0xffffu) == i0 + 3u; \
+            if (run4) {                                                                                 \
+                const u32x4 lo = {pv0.x, pv0.y, pv1.x, pv1.y}, hi = {pv2.x, pv2.y, pv3.x, pv3.y};       \
+                bk_store_quad((u32x4*)(cur_sfs + i0), lo); bk_store_quad((u32x4*)(cur_sfs + i0 + 2u), hi); \
+            } else {                                                                                    \
+                if (pa0 & BK_VALID) bk_store_pair(cur_sfs + i0, pv0);                                   \
+                if (pa1 & BK_VALID) bk_store_pair(cur_sfs + (pa1 & 0xffffu), pv1);                      \
+                if (pa2 & BK_VALID) bk_store_pair(cur_sfs + (pa2 & 0xffffu), pv2);                      \
+                if (pa3 & BK_VALID) bk_store_pair(cur_sfs + (pa3 & 0xffffu), pv3);                      \
+            }                                                                                           \
         }
+        BK_FOUR(e0, a0, e1, a1, e2, a2, e3, a3)
+        BK_FOUR(e4, a4, e5, a5, e6, a6, e7, a7)
+#undef BK_FOUR
         // a lane whose bucket ended at least one full iteration ago (all its bytes coded) takes its prefetched task
         const bool bytes_in_flight = fresh_finish;   // bytes requested in this iteration are coded in the next one
         if (!has_task) {
