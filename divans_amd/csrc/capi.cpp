@@ -246,13 +246,13 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->mix = cfg->context_mixing > 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
-    c->blocks = c->num_cus * 4u;  // mixing configurations: 16 waves = 64 streams per CU, 64-row cache (tuned on MI355X)
-    // high-nibble rows only: few and hot (32 ways ~ 90 % of their accesses); mixing configurations keep one unified cache
+    c->blocks = c->num_cus * 4u;  // without a row cache (more than 32766 rows per stream): 16 waves = 64 streams per CU
+    // row cache: high-nibble rows only -- few and hot (32 rows take ~90 % of their accesses)
     if (c->geom.total_rows < 0x7fffu) { c->cache_high = 64u; c->cache_low = 0u; c->cache_unified = false; }
-    if (!c->mix && c->cache_high) {
-        // without mixing the decode kernel needs 62 VGPRs and gains more from a seventh wave per SIMD than from the
-        // second half of the row cache: 7 workgroups per CU with 32-row caches, fewer when the
-        // context tables of a generic configuration take more of the CU's 160 KB of LDS
+    if (c->cache_high) {
+        // the kernels gain more from a seventh wave per SIMD than from the second half of the row cache (DESIGN.md
+        // section 7; the non-mixing decode kernel needs 62 VGPRs): 7 workgroups per CU with 32-row caches, fewer when
+        // the context tables of a generic configuration take more of the CU's 160 KB of LDS
         c->cache_high = 32u;
         const uint32_t lds_per_wg = (LIT_THREADS / 16) * c->cache_high * 34u + (c->geom.ctx_const < 0 ? LIT_BLOB_CTX_BYTES : 0u) +
                                     (c->geom.mm_uniform < 0 ? 8192u : 0u);
