@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X literal coder.
 
-Metric (BASELINE.json): MB/s encode+decode per GPU on 64 KiB metablocks, bit-exact vs the CPU path.
-A "step" = one encode pass + one decode pass of the hot path over the whole batch of independent
-64 KiB streams (configs[1]: 65 536 streams, stride-1 / context-map-off = reference TestSimple), inputs
-resident in HBM.  value = N * 65536 bytes * n_gpus / (t_enc + t_dec) in MB/s (10^6 B/s), whole job.
+Metric (BASELINE.json): MB/s encode+decode per GPU on 64 KiB metablocks, bit-exact vs the CPU path (= the in-repo
+oracle, a restatement of the reference's CPU path; the reference itself is Rust and cannot be built here).
+A "step" = one encode pass + one decode pass of the hot path over the whole batch of independent 64 KiB streams
+(configs[1]: 65 536 streams, stride 1 / context map off = reference TestSimple), inputs resident in HBM.
+value = N * 65536 bytes * n_gpus / (t_enc + t_dec) in MB/s (10^6 B/s), whole job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--config simple|mixing]
-Multi-GPU: one process per GPU (torch.distributed.run); streams are sharded by rank, no data-path
-collective (every stream is independent), weak scaling.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--config all|simple|mixing|decode_only]
+
+One JSON line.  `value` is always BASELINE configs[1]; at N = 1 the line also carries `configs.mixing` (configs[2]:
+context map + dynamic_context_mixing = 2) and `configs.decode_only` (configs[3]: pre-encoded random_then_unicode x 4096),
+each with its own bit-exactness flag, kernel times and roofline.
+
+Multi-GPU: `--gpus N` with no WORLD_SIZE in the environment re-launches itself as N ranks under torch.distributed.run
+(one process per GPU, RCCL); under an external launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Rank 0 builds the
+whole job's input and scatters contiguous stream ranges, every rank codes its shard (timed region: no collective in
+it, weak scaling), then the coded sizes are exchanged and the coded bytes gathered to rank 0 and checked there
+(divans_amd/sharding.py; reported as `multi_gpu`, never part of `value`).
 """
 import argparse
 import json
@@ -22,100 +31,201 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MASK64 = (1 << 64) - 1
 
 
-def make_device_blocks(torch, workload, corpus, first, count, block_len, device, chunk=2048):
-    out = torch.empty((count, block_len), dtype=torch.uint8, device=device)
+def _i64(v):
+    v &= MASK64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def device_blocks(torch, corpus_t, first, count, block_len, chunk=2048):
+    """tests/workload.make_blocks on the GPU (same bytes): block i = corpus[o_i : o_i + L], o_i = (i * 4099) mod
+    (len - L), then L // 100 bytes XORed with a non-zero value, positions / values from xorshift64* seeded
+    0x9E3779B97F4A7C15 ^ i.  int64 arithmetic wraps like uint64; logical right shifts are masked."""
+    dev = corpus_t.device
+    L = int(block_len)
+    span = corpus_t.numel() - L
+    out = torch.empty((count, L), dtype=torch.uint8, device=dev)
+    ar = torch.arange(L, device=dev, dtype=torch.int64)
+    lsr = lambda x, k: (x >> k) & ((1 << (64 - k)) - 1)
     for c0 in range(0, count, chunk):
         c1 = min(count, c0 + chunk)
-        blk = workload.make_blocks(corpus, first + c0, c1 - c0, block_len=block_len)
-        out[c0:c1].copy_(torch.from_numpy(blk), non_blocking=False)
+        idx = torch.arange(first + c0, first + c1, device=dev, dtype=torch.int64)
+        blk = corpus_t[((idx * 4099) % span)[:, None] + ar[None, :]]
+        x = idx ^ _i64(0x9E3779B97F4A7C15)
+        x = torch.where(x == 0, torch.ones_like(x), x)
+        rows = torch.arange(c1 - c0, device=dev, dtype=torch.int64)
+        for _ in range(L // 100):
+            x = x ^ lsr(x, 12)
+            x = x ^ (x << 25)
+            x = x ^ lsr(x, 27)
+            o = x * 2685821237909765
+            pos = lsr(o, 20) % L
+            val = (lsr(o, 8) & 0xFF).to(torch.uint8)
+            val = torch.where(val == 0, torch.ones_like(val), val)
+            blk[rows, pos] ^= val
+        out[c0:c1] = blk
     return out
 
 
-def cpu_baseline(cfg_name, workload, corpus, block_len, seconds_target=15.0):
-    """The C oracle ("port" of the reference CPU path) timed on this box's host cores, one independent
-    stream per worker thread, on a bounded sample of the same workload."""
+def usable_parallelism():
+    """How many host threads can actually run at once: affinity mask and cgroup CPU quota, whichever is smaller."""
+    info = {"nproc": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["affinity"] = info["nproc"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(path).read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+        except Exception:
+            pass
+    if quota is None:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    info["cgroup_cpu_quota"] = quota
+    usable = info["affinity"] if quota is None else max(1, min(info["affinity"], int(quota)))
+    info["usable"] = usable
+    return info
+
+
+def cpu_baseline(cfg_name, workload, corpus, block_len):
+    """The C oracle ("port" of the reference CPU path) timed on this box's host cores on a bounded sample of the same
+    workload: (1) one thread, 256 blocks; (2) one independent stream per worker on every usable core.  Workers allocate
+    their coder state and buffers before a start barrier; each direction is timed as wall clock from the barrier release
+    to the last worker finishing (oracle/literal.c orc_lit_batch_bench)."""
     import ctypes
-    import numpy as np
     import pyoracle as po
     try:
         lib = po.lib(native=True)
     except Exception:
         lib = po.lib()
     cfg = po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
-    cores = os.cpu_count() or 1
-    # one stream per worker thread at a time; ~2-5 MB/s/thread encode+decode => ~10-30 s for 64 streams of 64 KiB each
-    per_core = max(4, int(64 * 65536 / max(block_len, 1)))
-    n = cores * per_core
-    blocks = workload.make_blocks(corpus, 0, n, block_len=block_len)
-    enc = ctypes.c_double(0); dec = ctypes.c_double(0); coded = ctypes.c_uint64(0)
-    t0 = time.time()
-    rc = lib.orc_lit_batch_roundtrip(ctypes.byref(cfg), blocks.ctypes.data, n, block_len, cores,
+    par = usable_parallelism()
+
+    def run(n, threads):
+        blocks = workload.make_blocks(corpus, 0, n, block_len=block_len)
+        enc = ctypes.c_double(0); dec = ctypes.c_double(0); coded = ctypes.c_uint64(0)
+        rc = lib.orc_lit_batch_bench(ctypes.byref(cfg), blocks.ctypes.data, n, block_len, threads,
                                      ctypes.byref(enc), ctypes.byref(dec), ctypes.byref(coded))
-    wall = time.time() - t0
-    assert rc == 0, "oracle round trip failed"
-    total = n * block_len
+        assert rc == 0, "oracle round trip failed"
+        total = n * block_len
+        return {"streams": n, "threads": threads, "enc_s": enc.value, "dec_s": dec.value,
+                "encode_MBps": round(total / 1e6 / enc.value, 2), "decode_MBps": round(total / 1e6 / dec.value, 2),
+                "MBps": round(total / 1e6 / (enc.value + dec.value), 2)}
+
+    scale = max(1, 65536 // max(block_len, 1))
+    single = run((256 if cfg_name == "simple" else 96) * scale, 1)
+    threads = par["usable"]
+    allc = run(threads * (48 if cfg_name == "simple" else 24) * scale, threads)
+    factor = allc["MBps"] / single["MBps"]
+    note = ""
+    if factor < 0.5 * threads:
+        note = (f"; all-core scaling {factor:.1f}x of {threads} threads: every worker walks its own 12.6 MB of prior tables "
+                f"(2 x 3*256*256 rows as the reference lays them out, codec/priors.rs:35-37), so the cores share L3 / memory bandwidth")
     return {
-        "value": round(total / 1e6 / (enc.value + dec.value), 2), "unit": "MB/s", "cores": cores, "kind": "port",
-        "sample": f"{n} x {block_len} B streams of the same workload, {cores} threads (1 stream/thread), "
-                  f"enc {enc.value:.2f}s + dec {dec.value:.2f}s busiest-thread time, wall {wall:.1f}s",
-        "encode_MBps": round(total / 1e6 / enc.value, 2), "decode_MBps": round(total / 1e6 / dec.value, 2),
+        "value": allc["MBps"], "unit": "MB/s", "cores": threads, "kind": "port",
+        "sample": (f"all cores: {allc['streams']} x {block_len} B streams of the same workload on {threads} threads (1 stream per thread at a time), "
+                   f"wall enc {allc['enc_s']:.2f}s + dec {allc['dec_s']:.2f}s; single thread: {single['streams']} streams, "
+                   f"enc {single['enc_s']:.2f}s + dec {single['dec_s']:.2f}s; buffers allocated before the start barrier" + note),
+        "encode_MBps": allc["encode_MBps"], "decode_MBps": allc["decode_MBps"],
+        "single_thread": {k: single[k] for k in ("streams", "MBps", "encode_MBps", "decode_MBps")},
+        "all_cores": {k: allc[k] for k in ("streams", "threads", "MBps", "encode_MBps", "decode_MBps")},
+        "scaling_factor": round(factor, 2), "parallelism": par,
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=65536, help="independent 64 KiB streams per GPU")
-    ap.add_argument("--block-len", type=int, default=65536)
-    ap.add_argument("--config", choices=["simple", "mixing"], default="simple")
-    ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
-    ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per stream, 8 or 16 (tuning)")
-    ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
-    ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--diag-data", choices=["corpus", "zeros", "random", "repeat1k"], default="corpus",
-                    help="diagnostics only: 'zeros' touches two CDF rows per stream (cache-resident ceiling)")
-    args = ap.parse_args()
+def load_traffic(cfg_name, n, block_len):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (profiles/traffic_latest.json)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        ent = tj if "configs" not in tj else tj["configs"].get(cfg_name, {})
+        if ent.get("streams") == n and ent.get("block_bytes") == block_len and ent.get("config", cfg_name) == cfg_name:
+            return ent["kernels"]
+    except Exception:
+        pass
+    return {}
 
-    import numpy as np
+
+def roofline_of(kern_ms, alg_bytes, traffic):
+    dom = max(kern_ms, key=kern_ms.get)
+    achieved = alg_bytes[dom] / 1e9 / (kern_ms[dom] / 1e3) if kern_ms[dom] > 0 else 0.0
+    t = traffic.get(dom, {}).get("hbm_bytes_per_launch") if traffic else None
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": t, "algorithmic_bytes_per_launch": alg_bytes[dom]}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a plain shell: become N ranks (one per GPU) under torch.distributed.run."""
     import torch
-    import divans_amd as da
-    import workload
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.exit(f"bench: --gpus {args.gpus} needs {args.gpus} GPUs on this node, {have} visible (no CPU fallback, no silent single-rank run)")
+    port = 29400 + os.getpid() % 500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    from divans_amd import sharding
-    N, L = args.streams, args.block_len
-    first, last = sharding.shard_bounds(N * world, rank, world)   # weak scaling: every rank owns N streams of the job's N*world
-    assert last - first == N
-    corpus = workload.load_corpus()
-    if args.diag_data == "zeros":
-        d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev)
-    elif args.diag_data == "random":
-        d_in = torch.randint(0, 256, (N, L), dtype=torch.uint8, device=dev)
-    elif args.diag_data == "repeat1k":
-        d_in = make_device_blocks(torch, workload, corpus, first, N, L, dev)
-        d_in = d_in[:, :1024].repeat(1, L // 1024).contiguous()
-    else:
-        d_in = make_device_blocks(torch, workload, corpus, first, N, L, dev)
-    cfg = da.config_simple() if args.config == "simple" else da.config_context_mixing()
-    codec = da.LiteralCodec(cfg, L, device=local_rank)
+def timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, warmup, barrier):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    rec = {"enc": [], "dec": [], "model": [], "rans": [], "dkern": []}
+
+    def step(record):
+        # the codec launches on torch's current stream, so these events bracket its kernels
+        ev[0].record()
+        codec.encode_batch(d_in, N, L, outs)
+        ev[1].record()
+        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
+        ev[2].record()
+        if record:
+            torch.cuda.synchronize()
+            rec["enc"].append(ev[0].elapsed_time(ev[1])); rec["dec"].append(ev[1].elapsed_time(ev[2]))
+            inf = codec.info()   # hipEvent timings taken inside the C ABI around each kernel launch, on the launch stream
+            rec["model"].append(inf.last_model_ms); rec["rans"].append(inf.last_rans_ms); rec["dkern"].append(inf.last_decode_ms)
+
+    for _ in range(warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    barrier()
+    return time.perf_counter() - t0, rec
+
+
+def verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, n_check):
+    """Correctness on the codec's very first pass (its scratch holds nothing from an earlier pass that could stand in for
+    skipped work), outside the timed region: exact round trip of every stream + coded bytes == oracle on a spread of streams."""
+    codec.encode_batch(d_in, N, L, outs)
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(d_back, d_in)) and codec.status() == 0
+    offs = outs["offsets"].cpu().numpy(); sz = outs["sizes"].cpu().numpy()
+    picks = sorted(set([0, N // 2, N - 1] + list(range(0, N, max(1, N // n_check)))))
+    host_in = d_in[picks].cpu().numpy()
+    for k, i in enumerate(picks):
+        ref = po.lit_encode(ocfg, host_in[k])
+        got = outs["out"][int(offs[i]):int(offs[i]) + int(sz[i])].cpu().numpy()
+        ok = ok and got.size == ref.size and bool((got == ref).all())
+    return ok, len(picks)
+
+
+def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note=""):
+    """encode+decode config (simple or mixing): verify, time, report."""
+    cfg = da.config_simple() if name == "simple" else da.config_context_mixing()
+    ocfg = po.config_simple() if name == "simple" else po.config_context_mixing()
+    codec = da.LiteralCodec(cfg, L, device=dev.index)
     if args.blocks_per_cu:
-        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        cus = torch.cuda.get_device_properties(dev.index).multi_processor_count
         codec.set_geometry(blocks=max(1, int(cus * args.blocks_per_cu)))
     if args.cache_rows >= 0:
         codec.set_geometry(cache_rows=args.cache_rows)
@@ -128,6 +238,132 @@ def main():
         codec.set_split_cache(hi_rows, lo_rows)
     outs = codec.alloc_encode_outputs(N, L)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
+    ok, checked = True, 0
+    if not args.no_verify:
+        ok, checked = verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, args.check_streams)
+        first_sizes = outs["sizes"].clone(); d_back.zero_()
+    steps = args.steps if name == "simple" else max(1, min(args.steps, 2))
+    elapsed, rec = timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, args.warmup if name == "simple" else min(args.warmup, 1), barrier)
+    if not args.no_verify:   # the timed passes must have produced the same thing
+        ok = ok and bool(torch.equal(outs["sizes"], first_sizes)) and bool(torch.equal(d_back, d_in)) and codec.status() == 0
+    coded_total = int(outs["sizes"].to(torch.int64).sum().item())
+    avg = lambda xs: sum(xs) / max(len(xs), 1)
+    kern = {"lit_decode_kernel": avg(rec["dkern"]), "encode_model_pass": avg(rec["model"]), "encode_rans_pass": avg(rec["rans"])}
+    raw = N * L
+    # algorithmic bytes per launch: decode reads C + writes raw; the model pass reads raw and hands
+    # 4 B per nibble to the rANS pass; the rANS pass reads that spill and writes C
+    alg = {"lit_decode_kernel": raw + coded_total, "encode_model_pass": raw + 8 * raw, "encode_rans_pass": 8 * raw + coded_total}
+    res = {
+        "elapsed": elapsed, "steps": steps, "ok": ok, "checked_vs_oracle": checked, "coded_total": coded_total,
+        "encode_MBps": round(raw / 1e6 / (avg(rec["enc"]) / 1e3), 2), "decode_MBps": round(raw / 1e6 / (avg(rec["dec"]) / 1e3), 2),
+        "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
+        "roofline": roofline_of(kern, alg, load_traffic(name, N, L)),
+    }
+    return res, codec, outs
+
+
+def run_decode_only(torch, da, po, args, dev, copies=4096):
+    """BASELINE configs[3]: testdata/random_then_unicode (291 949 B) cut into 5 blocks of at most 64 KiB, each coded ONCE
+    on the CPU by the oracle as an independent stream under TestContextMixing options, the coded streams replicated
+    x4096 in HBM, all decoded by the GPU and every copy compared with the original."""
+    import lzma
+    import numpy as np
+    with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
+        data = np.frombuffer(f.read(), dtype=np.uint8).copy()
+    L = 65536
+    blocks = [data[i:i + L] for i in range(0, data.size, L)]
+    ocfg = po.config_context_mixing()
+    coded = [po.lit_encode(ocfg, b) for b in blocks]
+    nb = len(blocks)
+    al = [(c.size + 3) & ~3 for c in coded]
+    one = np.zeros(sum(al), dtype=np.uint8)
+    pos = 0
+    for c, a in zip(coded, al):
+        one[pos:pos + c.size] = c; pos += a
+    N = nb * copies
+    d_coded = torch.from_numpy(one).to(dev).repeat(copies)
+    in_off = torch.tensor(np.cumsum([0] + al[:-1]), dtype=torch.int64, device=dev)
+    d_in_off = (in_off[None, :] + torch.arange(copies, device=dev, dtype=torch.int64)[:, None] * int(sum(al))).reshape(-1).contiguous()
+    d_in_sz = torch.tensor([c.size for c in coded], dtype=torch.int32, device=dev).repeat(copies).contiguous()
+    out_off1 = torch.tensor(np.cumsum([0] + [b.size for b in blocks[:-1]]), dtype=torch.int64, device=dev)
+    d_out_off = (out_off1[None, :] + torch.arange(copies, device=dev, dtype=torch.int64)[:, None] * int(data.size)).reshape(-1).contiguous()
+    d_out_sz = torch.tensor([b.size for b in blocks], dtype=torch.int32, device=dev).repeat(copies).contiguous()
+    d_out = torch.zeros(copies * data.size, dtype=torch.uint8, device=dev)
+    codec = da.LiteralCodec(da.config_context_mixing(), L, device=dev.index)
+    orig = torch.from_numpy(data).to(dev)
+
+    def decode():
+        codec.decode_batch(d_coded, d_in_off, d_in_sz, N, L, d_out, out_offsets=d_out_off, out_sizes=d_out_sz)
+
+    decode(); torch.cuda.synchronize()
+    ok = bool((d_out.view(copies, data.size) == orig[None, :]).all().item()) and codec.status() == 0
+    d_out.zero_()
+    steps = max(1, args.steps)
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    ms, kms = [], []
+    for _ in range(steps):
+        ev0.record(); decode(); ev1.record(); torch.cuda.synchronize()
+        ms.append(ev0.elapsed_time(ev1)); kms.append(codec.info().last_decode_ms)
+    ok = ok and bool((d_out.view(copies, data.size) == orig[None, :]).all().item())
+    raw, ctot = copies * int(data.size), copies * int(sum(c.size for c in coded))
+    kern = {"lit_decode_kernel": sum(kms) / len(kms)}
+    res = {
+        "workload": f"testdata/random_then_unicode ({data.size} B) as {nb} independent streams (4 x 65536 + {blocks[-1].size} B), coded once by the "
+                    f"oracle under TestContextMixing options, x{copies} copies = {N} streams resident in HBM, decode only, every copy compared",
+        "bit_exact": ok, "streams": N, "steps": steps, "ms_per_step": round(sum(ms) / len(ms), 3),
+        "value": round(raw / 1e6 / (sum(ms) / len(ms) / 1e3), 2), "unit": "MB/s decode",
+        "compressed_ratio": round(ctot / raw, 4), "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
+        "roofline": roofline_of(kern, {"lit_decode_kernel": raw + ctot}, load_traffic("decode_only", N, L)),
+    }
+    codec.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=65536, help="independent 64 KiB streams per GPU")
+    ap.add_argument("--block-len", type=int, default=65536)
+    ap.add_argument("--config", choices=["all", "simple", "mixing", "decode_only"], default="all",
+                    help="all = configs[1] as the headline + configs[2] and configs[3] as sub-records (N = 1); a single name runs only that one")
+    ap.add_argument("--check-streams", type=int, default=256, help="streams whose coded bytes are compared with the oracle before timing")
+    ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
+    ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per stream, 8 or 16 (tuning)")
+    ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
+    ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--diag-data", choices=["corpus", "zeros", "random", "repeat1k"], default="corpus",
+                    help="diagnostics only: 'zeros' touches two CDF rows per stream (cache-resident ceiling)")
+    args = ap.parse_args()
+
+    env_world = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus > 1 and env_world == 0:
+        spawn_ranks(args)          # does not return
+    world = max(env_world, 1)
+    if env_world and args.gpus not in (1, world):
+        sys.exit(f"bench: --gpus {args.gpus} contradicts WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import divans_amd as da
+    import pyoracle as po
+    import workload
+    from divans_amd import sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench: rank {rank} needs GPU {local_rank}; {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -135,101 +371,126 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    enc_ms, dec_ms, model_ms, rans_ms, dkern_ms = [], [], [], [], []
+    N, L = args.streams, args.block_len
+    total_streams = N * world      # weak scaling: every rank owns N streams of the job's N * world
+    first, last = sharding.shard_bounds(total_streams, rank, world)
+    assert last - first == N
+    corpus = workload.load_corpus()
+    mg = None
+    if args.diag_data == "zeros":
+        d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev)
+    elif args.diag_data == "random":
+        d_in = torch.randint(0, 256, (N, L), dtype=torch.uint8, device=dev)
+    else:
+        corpus_t = torch.from_numpy(corpus).to(dev)
+        if world > 1:
+            # rank 0 holds the job's input and scatters contiguous stream ranges (SURVEY.md 8e / north_star)
+            full = device_blocks(torch, corpus_t, 0, total_streams, L) if rank == 0 else None
+            barrier(); t0 = time.perf_counter()
+            d_in = sharding.scatter_streams(full, total_streams, L, dev)
+            barrier(); scatter_s = time.perf_counter() - t0
+            d_in = d_in.contiguous().clone() if rank == 0 else d_in
+            mg = {"scatter_ms": round(sharding.max_over_ranks(scatter_s, dev) * 1e3, 3)}
+            if rank != 0:
+                full = None
+        else:
+            d_in = device_blocks(torch, corpus_t, first, N, L)
+        # the GPU generator must be the committed workload (tests/workload.py), byte for byte
+        probe = workload.make_blocks(corpus, first, min(N, 3), block_len=L)
+        assert bool((d_in[:probe.shape[0]].cpu().numpy() == probe).all()), "device workload generator differs from tests/workload.py"
+        if args.diag_data == "repeat1k":
+            d_in = d_in[:, :1024].repeat(1, L // 1024).contiguous()
 
-    def step(record):
-        # the codec launches on torch's current stream, so these events bracket its kernels
-        ev[0].record()
-        codec.encode_batch(d_in, N, L, outs)
-        ev[1].record()
-        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
-        ev[2].record()
-        if record:
-            torch.cuda.synchronize()
-            enc_ms.append(ev[0].elapsed_time(ev[1])); dec_ms.append(ev[1].elapsed_time(ev[2]))
-            inf = codec.info()   # hipEvent timings taken inside the C ABI around each kernel launch
-            model_ms.append(inf.last_model_ms); rans_ms.append(inf.last_rans_ms); dkern_ms.append(inf.last_decode_ms)
+    head_name = "simple" if args.config in ("all", "simple") else ("mixing" if args.config == "mixing" else None)
+    line = None
+    codec = None
+    if head_name:
+        res, codec, outs = run_pair_config(torch, da, po, head_name, d_in, N, L, args, dev, barrier)
+        elapsed = sharding.max_over_ranks(res["elapsed"], dev)
+        coded_all, ok_count = sharding.sum_over_ranks([res["coded_total"], int(res["ok"])], dev)
+        ok_all = ok_count == world
+        K = res["steps"]
+        if world > 1:
+            # variable-length gather of the coded streams to rank 0 (outside the timed region), checked there
+            barrier(); t0 = time.perf_counter()
+            packed, poff, ptotal = codec.pack(outs, N)
+            blob, goffs, gsizes = sharding.gather_coded(packed, outs["sizes"].to(torch.int64), total_streams)
+            barrier(); gather_s = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+            g_ok = 1
+            if rank == 0:
+                ocfg = po.config_simple() if head_name == "simple" else po.config_context_mixing()
+                g_ok = int(int(gsizes.sum().item()) == coded_all)
+                for r in range(world):
+                    rb, re = sharding.shard_bounds(total_streams, r, world)
+                    for i in (rb, (rb + re) // 2, re - 1):
+                        ref = po.lit_encode(ocfg, full[i].cpu().numpy())
+                        got = blob[int(goffs[i]):int(goffs[i]) + int(gsizes[i])].cpu().numpy()
+                        g_ok &= int(got.size == ref.size and bool((got == ref).all()))
+            g_ok, = sharding.sum_over_ranks([g_ok if rank == 0 else 1], dev)
+            ok_all = ok_all and g_ok == world
+            step_s = elapsed / K
+            mg.update({"gather_ms": round(gather_s * 1e3, 3), "gathered_bytes": int(coded_all), "gather_checked_on_rank0": bool(g_ok == world),
+                       "rccl_world_size": world,
+                       "scatter_gather_inclusive_MBps": round(total_streams * L / 1e6 / (step_s + mg["scatter_ms"] / 1e3 + gather_s), 2)})
+            per_rank = [0.0] * world
+            t = torch.zeros(world, dtype=torch.float64, device=dev); t[rank] = res["elapsed"] / K * 1e3
+            dist.all_reduce(t)
+            mg["per_rank_ms_per_step"] = [round(float(x), 3) for x in t.tolist()]
+        if rank == 0:
+            total_bytes = total_streams * L
+            cfg_text = ("TestSimple: stride 1, context map off (BASELINE configs[1])" if head_name == "simple"
+                        else "TestContextMixing: context map + dynamic_context_mixing=2 (BASELINE configs[2])")
+            line = {
+                "metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU",
+                "value": round(total_bytes / 1e6 / (elapsed / K), 2), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+                "ms_per_step": round(elapsed * 1e3 / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u16/u64 integer", "data": "synthetic",
+                "config": {"workload": f"{N} independent {L} B streams per GPU cut from alice29||asyoulik (stride 4099, 1% xorshift64* perturbation); {cfg_text}",
+                           "streams_per_gpu": N, "block_bytes": L, "sharding": "contiguous stream ranges per rank; no collective inside the timed region"},
+                "bit_exact": bool(ok_all), "bit_exact_against": f"in-repo C oracle (restatement of the reference CPU path; compressed bytes unpinned vs the Rust build): "
+                                                                f"coded bytes of {res['checked_vs_oracle']} streams per rank + exact round trip of all",
+                "compressed_ratio": round(coded_all / float(total_bytes), 4),
+                "encode_MBps": res["encode_MBps"], "decode_MBps": res["decode_MBps"],
+                "kernel_ms": res["kernel_ms"], "roofline": res["roofline"],
+            }
+            if mg:
+                line["multi_gpu"] = mg
+        codec.close(); codec = None
+        del outs
+        torch.cuda.empty_cache()
+        if not ok_all and rank == 0:
+            print(json.dumps(line))
+            sys.exit("bench: GPU output is NOT bit-exact / round-trip failed")
 
-    # correctness first, on the codec's very first pass (scratch buffers hold nothing from an earlier pass that could
-    # stand in for work a kernel skipped); outside the timed region
-    ok = True
-    if not args.no_verify:
-        step(False)
-        torch.cuda.synchronize()
-        ok = bool(torch.equal(d_back, d_in))
-        # bit-exactness of the coded streams against the CPU oracle on a spread of streams
-        import pyoracle as po
-        ocfg = po.config_simple() if args.config == "simple" else po.config_context_mixing()
-        offs = outs["offsets"].cpu().numpy(); sz = outs["sizes"].cpu().numpy()
-        for i in sorted(set([0, N // 2, N - 1] + list(range(0, N, max(1, N // 8))))):
-            ref = po.lit_encode(ocfg, d_in[i].cpu().numpy())
-            got = outs["out"][int(offs[i]):int(offs[i]) + int(sz[i])].cpu().numpy()
-            ok = ok and got.size == ref.size and bool((got == ref).all())
-        first_sizes = outs["sizes"].clone(); d_back.zero_()
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dev)
-
-    sizes = outs["sizes"].to(torch.int64)
-    coded_total = int(sizes.sum().item())
-    if not args.no_verify:   # the timed passes must have produced the same thing
-        ok = ok and bool(torch.equal(outs["sizes"], first_sizes)) and bool(torch.equal(d_back, d_in))
-    coded_all, ok_count = sharding.sum_over_ranks([coded_total, int(ok)], dev)
-    ok_all = ok_count == world
+    if world == 1 and args.config in ("all", "mixing", "decode_only"):
+        sub = {}
+        if args.config == "all":
+            r2, c2, o2 = run_pair_config(torch, da, po, "mixing", d_in, N, L, args, dev, barrier)
+            c2.close(); del o2; torch.cuda.empty_cache()
+            sub["mixing"] = {
+                "workload": "same streams, TestContextMixing: context map cm[i]=i&63, utf8, block type 1, dynamic_context_mixing=2 (BASELINE configs[2])",
+                "bit_exact": bool(r2["ok"]), "checked_vs_oracle": r2["checked_vs_oracle"], "steps": r2["steps"],
+                "ms_per_step": round(r2["elapsed"] * 1e3 / r2["steps"], 3),
+                "value": round(N * L / 1e6 / (r2["elapsed"] / r2["steps"]), 2), "unit": "MB/s encode+decode",
+                "encode_MBps": r2["encode_MBps"], "decode_MBps": r2["decode_MBps"], "compressed_ratio": round(r2["coded_total"] / float(N * L), 4),
+                "kernel_ms": r2["kernel_ms"], "roofline": r2["roofline"],
+            }
+        if args.config in ("all", "decode_only"):
+            sub["decode_only"] = run_decode_only(torch, da, po, args, dev)
+        if line is None:
+            line = {"metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU", "value": None, "unit": "MB/s", "n_gpus": 1,
+                    "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic",
+                    "config": {"workload": f"sub-config run: {args.config}"}}
+        line["configs"] = sub
+        bad = [k for k, v in sub.items() if not v["bit_exact"]]
+        if bad:
+            print(json.dumps(line))
+            sys.exit(f"bench: sub-config {bad} is NOT bit-exact")
 
     if rank == 0:
-        K = args.steps
-        ms_per_step = elapsed * 1e3 / K
-        total_bytes = N * L * world
-        value = total_bytes / 1e6 / (elapsed / K)
-        avg = lambda xs: sum(xs) / max(len(xs), 1)
-        # dominant kernel: the one with the largest average launch duration
-        # hipEvent spans taken inside the C ABI: the decode kernel; the encoder's model pass (bucket_sort/tasks/chain/unsort
-        # kernels, or lit_model_encode_kernel on the streaming path); its rANS pass (rans_encode2 + rans_stitch kernels)
-        kern = {"lit_decode_kernel": avg(dkern_ms), "encode_model_pass": avg(model_ms), "encode_rans_pass": avg(rans_ms)}
-        dom = max(kern, key=kern.get)
-        raw, coded = N * L, coded_total
-        # algorithmic bytes per launch: decode reads C + writes raw; the model pass reads raw and
-        # hands 4 B per nibble to the rANS pass; the rANS pass reads that spill and writes C
-        alg = {"lit_decode_kernel": raw + coded, "encode_model_pass": raw + 8 * raw, "encode_rans_pass": 8 * raw + coded}[dom]
-        achieved = alg / 1e9 / (kern[dom] / 1e3)
-        # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes of this same workload, committed under profiles/
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            if tj.get("streams") == N and tj.get("block_bytes") == L and tj.get("config") == args.config:
-                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        line = {
-            "metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU",
-            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16/u64 integer", "data": "synthetic",
-            "config": {"workload": f"{N} independent {L} B streams per GPU cut from alice29||asyoulik (stride 4099, 1% xorshift64* "
-                                   f"perturbation); {'TestSimple: stride 1, context map off (BASELINE configs[1])' if args.config == 'simple' else 'TestContextMixing: context map + dynamic_context_mixing=2 (BASELINE configs[2])'}",
-                       "streams_per_gpu": N, "block_bytes": L, "sharding": "streams split by rank, no collective"},
-            "bit_exact": bool(ok_all),
-            "compressed_ratio": round(coded_all / float(total_bytes), 4),
-            "encode_MBps": round(N * L / 1e6 / (avg(enc_ms) / 1e3), 2), "decode_MBps": round(N * L / 1e6 / (avg(dec_ms) / 1e3), 2),
-            "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg},
-        }
-        if not args.no_cpu_baseline and world == 1:   # the host-core baseline is a single-GPU-run item
-            line["cpu_baseline"] = cpu_baseline(args.config, workload, corpus, L)
+        if not args.no_cpu_baseline and world == 1 and head_name:   # the host-core baseline is a single-GPU-run item
+            line["cpu_baseline"] = cpu_baseline(head_name, workload, corpus, L)
         print(json.dumps(line))
-        if not ok_all:
-            sys.exit("bench: GPU output is NOT bit-exact / round-trip failed")
-    codec.close()
     if world > 1:
         dist.destroy_process_group()
 

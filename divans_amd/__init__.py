@@ -97,6 +97,7 @@ def load_library():
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
     L.divans_gpu_lit_model_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
+    L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
     _LIB = L
     return L
 
@@ -109,7 +110,7 @@ def exported_symbols():
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_lit_model_batch",
-        "divans_gpu_selftest_division",
+        "divans_gpu_selftest_division", "divans_gpu_codec_status",
     ]
 
 
@@ -192,6 +193,13 @@ class LiteralCodec:
         i = GpuInfo()
         _check(self._lib.divans_gpu_codec_info(self._h, ctypes.byref(i)), "divans_gpu_codec_info")
         return i
+
+    def status(self):
+        """Synchronises and returns (then clears) the sticky device status word: 1 = invalid (start,freq) in an encode
+        pass, 2 = a decoded stream failed its integrity check (truncated / corrupt / wrong configuration)."""
+        st = ctypes.c_uint32(0)
+        _check(self._lib.divans_gpu_codec_status(self._h, ctypes.byref(st)), "divans_gpu_codec_status")
+        return int(st.value)
 
     def selftest_division(self):
         m = ctypes.c_uint64(0)

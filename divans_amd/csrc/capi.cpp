@@ -228,6 +228,8 @@ static int ensure_sf(divans_gpu_codec* c, uint32_t n_streams) {
     return 0;
 }
 
+extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c);
+
 extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_config* cfg, int device, void* hip_stream,
                                        uint32_t max_stream_len) {
     if (!out || !cfg || max_stream_len == 0) return fail(DIVANS_GPU_EINVAL, "null argument");
@@ -242,7 +244,7 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->max_stream_len = (max_stream_len + 1u) & ~1u;   // even: keeps every stream's start/freq spill 16-byte aligned
     std::vector<uint8_t> blob;
     int rc = derive_geometry(*cfg, c->geom, blob);
-    if (rc) { delete c; return rc; }
+    if (rc) { divans_gpu_codec_destroy(c); return rc; }
     c->mix = cfg->context_mixing > 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
@@ -252,21 +254,24 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     if (c->cache_high) {
         // the kernels gain more from a seventh wave per SIMD than from the second half of the row cache (DESIGN.md
         // section 7; the non-mixing decode kernel needs 62 VGPRs): 7 workgroups per CU with 32-row caches, fewer when
-        // the context tables of a generic configuration take more of the CU's 160 KB of LDS
+        // the context tables of a generic configuration take more of the CU's 160 KB of LDS (the kernels stage the
+        // mixing mask unless the mixing value is one they are specialised for: 0 or 4, see effective_mm)
         c->cache_high = 32u;
+        const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
         const uint32_t lds_per_wg = (LIT_THREADS / 16) * c->cache_high * 34u + (c->geom.ctx_const < 0 ? LIT_BLOB_CTX_BYTES : 0u) +
-                                    (c->geom.mm_uniform < 0 ? 8192u : 0u);
+                                    (mask_in_lds ? 8192u : 0u);
         const uint32_t fit = (160u * 1024u) / lds_per_wg;
         c->blocks = c->num_cus * std::max(1u, std::min(7u, fit));
     }
     c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && c->geom.ctx_const >= 0 && c->max_stream_len <= 65536u;
     c->packed8 = false;   // the packed 8-lane kernels (set_lane_layout(8)) are bit-identical; on MI355X the 16-lane ones are faster
-    if (hipMalloc(&c->d_blob, LIT_BLOB_BYTES) != hipSuccess || hipMalloc(&c->d_status, 64) != hipSuccess) {
-        delete c; return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed");
-    }
-    HIP_TRY(hipMemcpy(c->d_blob, blob.data(), LIT_BLOB_BYTES, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(c->d_status, 0, 64));
-    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    hipError_t he = hipMalloc(&c->d_blob, LIT_BLOB_BYTES);
+    if (he == hipSuccess) he = hipMalloc(&c->d_status, 64);
+    if (he != hipSuccess) { divans_gpu_codec_destroy(c); return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed"); }
+    if (he == hipSuccess) he = hipMemcpy(c->d_blob, blob.data(), LIT_BLOB_BYTES, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemset(c->d_status, 0, 64);
+    for (auto& e : c->ev) if (he == hipSuccess) he = hipEventCreate(&e);
+    if (he != hipSuccess) { divans_gpu_codec_destroy(c); return fail(DIVANS_GPU_EHIP, std::string("codec setup: ") + hipGetErrorString(he)); }
     *out = c;
     return 0;
 }
@@ -409,7 +414,7 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
     b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
-    b.sf = c->d_sf;
+    b.sf = c->d_sf; b.status = c->d_status;
     set_cache_fields(c, b);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (c->packed8) HIP_TRY(launch_model_encode_p8(b, c->blocks, c->stream));
@@ -484,7 +489,7 @@ extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d
     b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
-    b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes;
+    b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes; b.status = c->d_status;
     set_cache_fields(c, b);
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     if (c->packed8) HIP_TRY(launch_decode_p8(b, c->blocks, c->stream));
@@ -524,6 +529,19 @@ extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info)
     info->table_bytes = (uint64_t)resident_groups(c) * c->geom.total_rows * 32u;
     info->scratch_bytes = c->sf_bytes;
     info->last_model_ms = c->last_model_ms; info->last_rans_ms = c->last_rans_ms; info->last_decode_ms = c->last_decode_ms;
+    return 0;
+}
+
+// Sticky device status word of the batch entry points: waits for the codec's stream, returns the bits set since the last
+// call and clears them.  bit 0: the rANS pass met an invalid (start,freq); bit 1: a decoded stream failed its integrity check.
+extern "C" int divans_gpu_codec_status(divans_gpu_codec* c, uint32_t* status) {
+    if (!c || !status) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, c->d_status, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h) HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(h), c->stream));
+    *status = h;
     return 0;
 }
 
@@ -587,6 +605,7 @@ extern "C" int divans_gpu_lit_encode_host_chunks(divans_gpu_codec* c, const uint
         if ((rc = host_scratch(c, 7, sizeof(uint32_t) * (size_t)n_streams * max_chunks, &d_chunks))) return rc;
         TRY_OR_CLEAN(hipMemsetAsync(d_chunks, 0, sizeof(uint32_t) * (size_t)n_streams * max_chunks, c->stream));
     }
+    TRY_OR_CLEAN(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));   // this call reports only its own status
     TRY_OR_CLEAN(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
     rc = encode_batch_impl(c, d_in, nullptr, nullptr, stream_len, n_streams, d_slots, slot, d_off, d_sz, d_chunks, max_chunks);
     if (rc) { cleanup(); return rc; }
@@ -600,7 +619,7 @@ extern "C" int divans_gpu_lit_encode_host_chunks(divans_gpu_codec* c, const uint
     if (out_chunk_bytes)
         TRY_OR_CLEAN(hipMemcpyAsync(out_chunk_bytes, d_chunks, sizeof(uint32_t) * (size_t)n_streams * max_chunks, hipMemcpyDeviceToHost, c->stream));
     TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
-    if (status) { (void)hipMemset(c->d_status, 0, 64); cleanup(); return fail(DIVANS_GPU_EINVAL, "model produced an invalid (start,freq): unsupported speed/CDF state"); }
+    if (status) { (void)hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream); cleanup(); return fail(DIVANS_GPU_EINVAL, "model produced an invalid (start,freq): unsupported speed/CDF state"); }
     if (total > out_cap) { cleanup(); return fail(DIVANS_GPU_ECAP, "out_cap too small for the packed streams"); }
     TRY_OR_CLEAN(hipMemcpy(out_packed, d_packed, total, hipMemcpyDeviceToHost));
     *out_total = total;
@@ -624,13 +643,20 @@ extern "C" int divans_gpu_lit_decode_host(divans_gpu_codec* c, const uint8_t* in
     if ((rc0 = host_scratch(c, 1, (size_t)stream_len * n_streams + 64, &d_out))) return rc0;
     if ((rc0 = host_scratch(c, 3, sizeof(uint64_t) * n_streams, &d_off))) return rc0;
     if ((rc0 = host_scratch(c, 6, sizeof(uint32_t) * n_streams, &d_sz))) return rc0;
+    TRY_OR_CLEAN(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));   // this call reports only its own status
     TRY_OR_CLEAN(hipMemcpyAsync(d_in, in_packed, total, hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_off, in_offsets, sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(d_sz, in_sizes, sizeof(uint32_t) * n_streams, hipMemcpyHostToDevice, c->stream));
     int rc = divans_gpu_lit_decode_batch(c, d_in, d_off, d_sz, n_streams, d_out, nullptr, nullptr, stream_len);
     if (rc) { cleanup(); return rc; }
+    uint32_t status = 0;
+    TRY_OR_CLEAN(hipMemcpyAsync(&status, c->d_status, sizeof(status), hipMemcpyDeviceToHost, c->stream));
     TRY_OR_CLEAN(hipMemcpyAsync(out, d_out, (size_t)stream_len * n_streams, hipMemcpyDeviceToHost, c->stream));
     TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
     cleanup();
+    if (status & LIT_STATUS_BAD_STREAM) {
+        (void)hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream);
+        return fail(DIVANS_GPU_ECORRUPT, "a coded stream is truncated, corrupt or was coded under another configuration (final rANS states / word count mismatch)");
+    }
     return 0;
 }

@@ -38,6 +38,7 @@ struct DivansDecompressorState {
     CAllocator alloc;
     bool skip_crc = false;
     bool failed = false, decoded = false;
+    size_t max_output = (size_t)1 << 30;   // bound on the decoded size a stream may claim (divans_decompressor_set_max_output_size)
     std::vector<uint8_t> input, output;
     size_t cursor = 0;
 };
@@ -89,7 +90,12 @@ DivansResult divans_set_option(struct DivansCompressorState* s, DivansOptionSele
 
 static bool start(DivansCompressorState* s) {
     s->started = true;
-    if (s->opt.use_brotli != 0) s->failed = true;   // brotli command selection is out of scope; no silent substitute
+    // BrotliCompressionSetting (src/ffi/compressor.rs:168-210): the reference's default (UseBrotliCommandSelection) and
+    // UseBrotliBitstream run the brotli front-end to choose Copy / Dict / Literal commands.  That front-end is outside this
+    // library; every setting codes the input with the internal command selection
+    // (raw_to_cmd/mod.rs:105-181: one PredictionMode + Literal commands).  The result is a valid .divans stream any
+    // reference decoder accepts -- larger than a brotli-assisted one -- so c/example.c, which sets no
+    // options, round-trips through this library unchanged.
     if (s->opt.dynamic_context_mixing >= 15) s->failed = true;   // codec/interface.rs:359 assert
     return !s->failed;
 }
@@ -189,7 +195,7 @@ DivansResult divans_decode(struct DivansDecompressorState* s, const uint8_t* in,
         const size_t n = s->input.size();
         if (n < 16 + 3 + 8 || std::memcmp(s->input.data() + n - 4, "ans~", 4) != 0) return DIVANS_NEEDS_MORE_INPUT;
         size_t consumed = 0;
-        const divans_host::ParseStatus st = divans_host::parse_container(s->input.data(), n, s->skip_crc, 0, s->output, &consumed);
+        const divans_host::ParseStatus st = divans_host::parse_container(s->input.data(), n, s->skip_crc, 0, s->output, &consumed, s->max_output);
         if (st == divans_host::PARSE_NEED_MORE) return DIVANS_NEEDS_MORE_INPUT;   // "ans~" occurred inside the payload
         if (st != divans_host::PARSE_OK) { s->failed = true; return DIVANS_FAILURE; }
         s->decoded = true;
@@ -201,6 +207,9 @@ DivansResult divans_decode(struct DivansDecompressorState* s, const uint8_t* in,
     s->cursor += n; *out_off += n;
     return s->cursor == s->output.size() ? DIVANS_SUCCESS : DIVANS_NEEDS_MORE_OUTPUT;
 }
+
+// extension (not in c/divans/ffi.h): the literal lengths of a stream are its own claim; refuse streams that claim more
+void divans_decompressor_set_max_output_size(struct DivansDecompressorState* s, size_t max_bytes) { if (s) s->max_output = max_bytes; }
 
 void divans_free_decompressor(struct DivansDecompressorState* s) {
     if (!s) return;

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 
 namespace divans_host {
 
@@ -502,9 +503,47 @@ static void drain(Mux& mux, CallSink& sink, int id, const std::vector<uint8_t>& 
     }
 }
 
+// One divans_gpu_codec per configuration is kept alive between per-stream states (creating one allocates its CDF
+// tables, spill and staging buffers on the device): a released handle parks its codec here and the next stream with the
+// same divans_lit_config on the same device picks it up if it is large enough.
+struct CodecCache {
+    std::mutex mu;
+    divans_gpu_codec* codec = nullptr; int device = -1; uint32_t max_len = 0;
+    std::unique_ptr<divans_lit_config> cfg;
+    ~CodecCache() { /* the HIP runtime may already be gone at process exit: leave the codec to the OS */ }
+};
+static CodecCache& codec_cache() { static CodecCache* c = new CodecCache(); return *c; }
+
 struct GpuCodecHandle {
-    divans_gpu_codec* c = nullptr;
-    ~GpuCodecHandle() { if (c) divans_gpu_codec_destroy(c); }
+    divans_gpu_codec* c = nullptr; int device = 0; uint32_t max_len = 0;
+    std::unique_ptr<divans_lit_config> cfg;
+    int acquire(const divans_lit_config& want, int dev, uint32_t need_len) {
+        CodecCache& cc = codec_cache();
+        {
+            std::lock_guard<std::mutex> g(cc.mu);
+            if (cc.codec && cc.device == dev && cc.max_len >= need_len && std::memcmp(cc.cfg.get(), &want, sizeof(want)) == 0) {
+                c = cc.codec; cc.codec = nullptr; device = dev; max_len = cc.max_len; cfg = std::move(cc.cfg);
+                return 0;
+            }
+        }
+        cfg = std::make_unique<divans_lit_config>(want);
+        device = dev; max_len = std::max<uint32_t>(need_len, 65536u);
+        int rc = divans_gpu_codec_create(&c, cfg.get(), dev, nullptr, max_len);
+        if (rc) return rc;
+        (void)divans_gpu_codec_set_geometry(c, 1, 0xffffffffu);   // one stream: one workgroup's worth of tables is plenty
+        return 0;
+    }
+    ~GpuCodecHandle() {
+        if (!c) return;
+        CodecCache& cc = codec_cache();
+        divans_gpu_codec* old = nullptr;
+        {
+            std::lock_guard<std::mutex> g(cc.mu);
+            old = cc.codec;
+            cc.codec = c; cc.device = device; cc.max_len = max_len; cc.cfg = std::move(cfg);
+        }
+        if (old) divans_gpu_codec_destroy(old);
+    }
 };
 
 int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
@@ -536,9 +575,8 @@ int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, si
         auto cfg = std::make_unique<divans_lit_config>();
         probe.fill_lit_config(*cfg, 0);
         GpuCodecHandle h;
-        int rc = divans_gpu_codec_create(&h.c, cfg.get(), device, nullptr, (uint32_t)n);
+        int rc = h.acquire(*cfg, device, (uint32_t)n);
         if (rc) return rc;
-        (void)divans_gpu_codec_set_geometry(h.c, 1, 0xffffffffu);   // one stream: one workgroup's worth of tables is plenty
         const uint32_t max_chunks = (uint32_t)((2 * n + 65535) / 65536);
         lit.resize(divans_gpu_lit_encode_bound(n) + 64);
         chunk_bytes.assign(max_chunks, 0);
@@ -598,7 +636,8 @@ int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, si
     return 0;
 }
 
-ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed) {
+ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,
+                            size_t max_output) {
     out.clear();
     if (n < 16) return PARSE_NEED_MORE;
     if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f) return PARSE_CORRUPT;   // divans_decompressor.rs:38-52
@@ -639,6 +678,10 @@ ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int devi
             if (!model.literal_length(nc, 15, len)) return PARSE_CORRUPT;
             total += len; seen_literal = true;
             if (total > 0x7fffffffu) return PARSE_UNSUPPORTED;
+            // the literal lengths are the stream's own claim: bound them before anything is allocated for them.  A literal
+            // byte costs the LIT coder at least ~0.0007 bytes (two nibbles at the largest probability the fastest
+            // speed allows), so a stream claiming more than 4096 bytes per coded LIT byte is lying.
+            if (total > max_output || total > (uint64_t)mux.s[1].avail() * 4096u + 65536u) return PARSE_CORRUPT;
         } else return PARSE_UNSUPPORTED;   // Copy / Dict / command- and distance- block switches
         if (cd.starved) return PARSE_CORRUPT;
     }
@@ -650,15 +693,16 @@ ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int devi
         for (auto& s : cfg->literal_adaptation) s = divans_speed{0x10, 0x2000};
     }
     GpuCodecHandle h;
-    if (divans_gpu_codec_create(&h.c, cfg.get(), device, nullptr, (uint32_t)total)) return PARSE_GPU_ERROR;
-    (void)divans_gpu_codec_set_geometry(h.c, 1, 0xffffffffu);
+    if (h.acquire(*cfg, device, (uint32_t)total)) return PARSE_GPU_ERROR;
     // the kernels read whole 32-bit words; LIT streams are 16 + 4k bytes per chunk by construction
     std::vector<uint8_t> lit(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
     if (lit.size() % 4) return PARSE_CORRUPT;
     lit.resize(lit.size() + 64, 0);
     const uint64_t off = 0; const uint32_t size = (uint32_t)(lit.size() - 64);
     out.resize(total);
-    if (divans_gpu_lit_decode_host(h.c, lit.data(), &off, &size, 1, out.data(), (uint32_t)total)) return PARSE_GPU_ERROR;
+    const int drc = divans_gpu_lit_decode_host(h.c, lit.data(), &off, &size, 1, out.data(), (uint32_t)total);
+    if (drc == DIVANS_GPU_ECORRUPT) { out.clear(); return PARSE_CORRUPT; }   // short / corrupt / mismatched LIT stream
+    if (drc) return PARSE_GPU_ERROR;
     return PARSE_OK;
 }
 

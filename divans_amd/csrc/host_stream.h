@@ -31,7 +31,9 @@ int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, si
 
 enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
 // Decodes a complete container (header .. "ans~").  PARSE_NEED_MORE when `n` bytes do not yet hold the whole stream.
-ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed);
+// `max_output` bounds the decoded size the stream may claim (literal lengths come from the stream itself).
+ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,
+                            size_t max_output = (size_t)1 << 30);
 
 uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n);   // src/codec/crc32.rs
 

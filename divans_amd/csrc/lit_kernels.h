@@ -43,7 +43,10 @@ struct LitBatch {
     uint32_t cache_rows_low;    // same for low-nibble rows (ignored when cache_unified)
     uint32_t cache_mode;        // 0 none, 1 unified (cache_rows_high rows serve both tables), 2 high-nibble rows only, 3 separate high / low
     uint32_t cache_bytes_per_wg;  // 16 * (rows_high + rows_low) * (32 + 2)
+    uint32_t* status;           // device word: bit 0 = encoder saw an invalid (start,freq), bit 1 = decoder integrity check failed
 };
+constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
+constexpr uint32_t LIT_STATUS_BAD_STREAM = 2u;    // decode: a chunk did not end with both states at 2^31, or the coded words were not consumed exactly
 
 struct RansBatch {
     const uint32_t* sf; uint32_t n_streams, stream_len, max_stream_len; const uint32_t* in_sizes;

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
     uint64_t off = (uint64_t)((uint8_t*)wp - b.out);
     b.out_offsets[s] = off;
     b.out_sizes[s] = (uint32_t)(slot_end - (uint8_t*)wp);
-    if (bad) atomicOr(b.status, 1u);
+    if (bad) atomicOr(b.status, LIT_STATUS_BAD_MODEL);
 }
 
 // Streams of one or two chunks (at most 65 536 bytes): the chunks are independent rANS runs (states restart at 2^31,
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode2_kernel(const RansBa
         b.out_offsets[s] = (uint64_t)(slot_end - b.out) - total;
         b.chunk0_sizes[s] = size;
     }
-    if (bad) atomicOr(b.status, 1u);
+    if (bad) atomicOr(b.status, LIT_STATUS_BAD_MODEL);
 }
 
 __global__ __launch_bounds__(256) void rans_stitch_kernel(const RansBatch b) {
@@ -598,6 +598,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
         uint64_t last8 = 0;
         uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];
         uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
+        bool corrupt = false;
         uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
         FetchedRow rowH = {};
         if (!MIX) rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
@@ -647,7 +648,13 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                 }
                 if ((uint32_t)li < cnt) __builtin_nontemporal_store((uint8_t)outb, out + base + li);
             }
+            // rANS is an exact inverse: a chunk that was coded from the start states 2^31 (ans.rs:135-136,331-378) decodes back
+            // to exactly those; anything else means a truncated, corrupt or mismatched stream (the reference would stall on
+            // NeedsMoreInput or fail its checksum)
+            corrupt |= (SA != (1ull << 31)) | (SB != (1ull << 31));
         }
+        corrupt |= ww.pos != ww.nwords;     // every coded word consumed, none read past the end
+        if (corrupt && li == 0 && b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
     }
 }
 

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_p8_kernel(const LitBat
         uint64_t last8 = 0;
         uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];
         uint64_t SA = 0, SB = 0;
+        bool corrupt = false;
         uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
         Fetched8 rowH = p8_fetch<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
         for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
@@ -290,7 +291,10 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_p8_kernel(const LitBat
                 }
                 if ((uint32_t)j < cnt) __builtin_nontemporal_store((uint8_t)outb, out + base + j);
             }
+            corrupt |= (SA != (1ull << 31)) | (SB != (1ull << 31));   // see lit_decode_kernel
         }
+        corrupt |= ww.pos != ww.nwords;
+        if (corrupt && j == 0 && b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
     }
 }
 

@@ -1,11 +1,22 @@
 """Multi-GPU partitioning of a batch of independent literal streams.
 
 Every 64 KiB stream is its own divans stream (own priors, own rANS states, own output): there is no exchange
-step in the data path, so GPU g of G simply owns a contiguous range of streams.  torch.distributed (RCCL on
-ROCm, gloo in the CPU tests) is used for the barrier, the max-over-ranks timing and for gathering the per-stream
-coded sizes to rank 0 -- never for the payload of the timed region."""
+step inside the coding path, so GPU g of G simply owns a contiguous range of streams.  What does move between
+GPUs is what BASELINE.json's north_star names: the input ranges go out from rank 0 (`scatter_streams`), the
+per-stream coded sizes are exchanged (`gather_stream_sizes`) and the coded bytes come back to rank 0 as one
+variable-length gather (`gather_coded`).  All of it is point-to-point `torch.distributed` send/recv batched into
+one group per step (RCCL over xGMI on ROCm: rank 0 talks to every peer over its own link, nothing ring-shaped;
+gloo in the CPU tests), plus all_reduce / all_gather for the scalars."""
 import torch
 import torch.distributed as dist
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 def shard_bounds(n_streams, rank, world):
@@ -17,22 +28,21 @@ def shard_bounds(n_streams, rank, world):
 
 def max_over_ranks(seconds, device):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _world() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def sum_over_ranks(values, device):
     t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _world() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(x) for x in t.tolist()]
 
 
 def gather_stream_sizes(local_sizes, n_streams):
     """Per-stream coded sizes of the whole job on every rank (variable shard lengths => padded all_gather)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    world, rank = _world(), _rank()
     if world == 1:
         return local_sizes.clone()
     longest = max(shard_bounds(n_streams, r, world)[1] - shard_bounds(n_streams, r, world)[0] for r in range(world))
@@ -46,3 +56,70 @@ def gather_stream_sizes(local_sizes, n_streams):
         out.append(parts[r][:e - b])
     assert out[rank].numel() == local_sizes.numel()
     return torch.cat(out)
+
+
+def _run_p2p(ops):
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def scatter_streams(all_streams, n_streams, stream_len, device, dtype=torch.uint8):
+    """Rank 0 holds `all_streams` ([n_streams, stream_len], on `device`); every rank returns its contiguous shard
+    [shard_bounds) as a [count, stream_len] tensor.  One send per peer, posted as a single batch."""
+    world, rank = _world(), _rank()
+    b, e = shard_bounds(n_streams, rank, world)
+    if world == 1:
+        return all_streams[b:e]
+    if rank == 0:
+        ops = []
+        for r in range(1, world):
+            rb, re = shard_bounds(n_streams, r, world)
+            if re > rb:
+                ops.append(dist.P2POp(dist.isend, all_streams[rb:re].contiguous(), r))
+        _run_p2p(ops)
+        return all_streams[b:e]
+    mine = torch.empty((e - b, stream_len), dtype=dtype, device=device)
+    if e > b:
+        _run_p2p([dist.P2POp(dist.irecv, mine, 0)])
+    return mine
+
+
+def gather_coded(local_packed, local_sizes, n_streams):
+    """Variable-length gather of the coded streams to rank 0.
+
+    `local_packed`: this rank's coded streams back to back (stream i of the shard at the exclusive prefix sum of the
+    sizes rounded up to `align`); `local_sizes`: their byte sizes (int64/int32).  Returns on rank 0
+    (blob, offsets, sizes) covering all n_streams in job order, on the other ranks (None, None, sizes):
+    first the size exchange (all_gather), then one recv per peer sized from it."""
+    world, rank = _world(), _rank()
+    sizes = gather_stream_sizes(local_sizes.to(torch.int64), n_streams)
+    if world == 1:
+        offs = torch.cumsum(_aligned(sizes), 0) - _aligned(sizes)
+        return local_packed, offs, sizes
+    al = _aligned(sizes)
+    offs = torch.cumsum(al, 0) - al
+    shard_bytes = []
+    for r in range(world):
+        rb, re = shard_bounds(n_streams, r, world)
+        shard_bytes.append(int(al[rb:re].sum().item()))
+    if rank == 0:
+        blob = torch.empty(sum(shard_bytes), dtype=torch.uint8, device=local_packed.device)
+        blob[:shard_bytes[0]] = local_packed[:shard_bytes[0]]
+        ops, pos = [], shard_bytes[0]
+        for r in range(1, world):
+            if shard_bytes[r]:
+                ops.append(dist.P2POp(dist.irecv, blob[pos:pos + shard_bytes[r]], r))
+            pos += shard_bytes[r]
+        _run_p2p(ops)
+        return blob, offs, sizes
+    if shard_bytes[rank]:
+        _run_p2p([dist.P2POp(dist.isend, local_packed[:shard_bytes[rank]].contiguous(), 0)])
+    return None, None, sizes
+
+
+PACK_ALIGN = 4   # divans_gpu_pack_streams places every coded stream on a 4-byte boundary (coded streams are whole words)
+
+
+def _aligned(sizes):
+    return (sizes + (PACK_ALIGN - 1)) // PACK_ALIGN * PACK_ALIGN

@@ -76,6 +76,9 @@ struct DivansDecompressorState *divans_new_decompressor_with_custom_alloc(struct
 DivansResult divans_decode(struct DivansDecompressorState *state, const uint8_t *input_buf_ptr, size_t input_size,
                            size_t *input_offset, uint8_t *output_buf_ptr, size_t output_size, size_t *output_offset); /* mod.rs:236-262 */
 void divans_free_decompressor(struct DivansDecompressorState *mfd);                                   /* mod.rs:312-323 */
+/* Extension (not in the reference): the decoded size is the stream's own claim (literal lengths on the CMD coder); a
+ * stream that claims more than `max_bytes` (default 1 GiB) is refused with DIVANS_FAILURE before anything is allocated. */
+void divans_decompressor_set_max_output_size(struct DivansDecompressorState *state, size_t max_bytes);
 
 /* helper allocators through the state's CAllocator, src/ffi/mod.rs:111-145,276-309 */
 uint8_t *divans_compressor_malloc_u8(struct DivansCompressorState *state, size_t size);

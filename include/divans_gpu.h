@@ -28,6 +28,7 @@ extern "C" {
 #define DIVANS_GPU_ENOMEM (-2)   /* device allocation failed */
 #define DIVANS_GPU_EHIP (-3)     /* HIP runtime error (see divans_gpu_last_error) */
 #define DIVANS_GPU_ECAP (-4)     /* an output slot was too small */
+#define DIVANS_GPU_ECORRUPT (-5) /* a coded stream failed the decoder's integrity check (host-buffer decode entry point) */
 
 #define DIVANS_GPU_MAX_LITERAL_CONTEXT_MAP_SIZE (256 * 64) /* brotli MAX_LITERAL_CONTEXT_MAP_SIZE */
 #define DIVANS_GPU_NUM_MIXING_VALUES 8192                  /* codec/interface.rs:137 */
@@ -87,6 +88,18 @@ int divans_gpu_lit_model_batch(divans_gpu_codec *c, const uint8_t *d_in, const u
 int divans_gpu_lit_decode_batch(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
                                 const uint32_t *d_in_sizes, uint32_t n_streams, uint8_t *d_out,
                                 const uint64_t *d_out_offsets, const uint32_t *d_out_sizes, uint32_t stream_len);
+
+/* Status of the device-pointer batch calls (they are asynchronous and return before the kernels ran).  Waits for the
+ * codec's stream, stores the bits set since the previous call in *status and clears them:
+ *   DIVANS_GPU_STATUS_BAD_MODEL  (1): an encode pass met a (start,freq) outside 15 bits / freq == 0 -- a CDF state the
+ *                                     supported speeds cannot produce (the reference would debug_assert, ans.rs:305-309)
+ *   DIVANS_GPU_STATUS_BAD_STREAM (2): a decoded stream did not end every 65 536-symbol chunk with both rANS states at
+ *                                     2^31 or did not consume exactly its coded words: truncated / corrupt input, or coded
+ *                                     under another configuration (the reference would stall on NeedsMoreInput, ans.rs:173-223).
+ * The host-buffer wrappers check the same word themselves and return DIVANS_GPU_EINVAL / DIVANS_GPU_ECORRUPT. */
+#define DIVANS_GPU_STATUS_BAD_MODEL 1u
+#define DIVANS_GPU_STATUS_BAD_STREAM 2u
+int divans_gpu_codec_status(divans_gpu_codec *c, uint32_t *status);
 
 /* Compacts the right-aligned slots into one contiguous buffer (4-byte aligned starts):
  * d_packed_offsets[i] = exclusive prefix sum of round_up(sizes,4); returns total via *d_total (device u64). */

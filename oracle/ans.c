@@ -28,8 +28,13 @@ void orc_ans_encoder_init(orc_ans_encoder *e) {
 }
 
 void orc_ans_encoder_free(orc_ans_encoder *e) {
-    free(e->start); free(e->freq); orc_bytes_free(&e->out);
+    free(e->start); free(e->freq); free(e->words_scratch); orc_bytes_free(&e->out);
     memset(e, 0, sizeof(*e));
+}
+
+/* start another stream with the buffers of the previous one (the CPU-baseline workers allocate once, outside the timed region) */
+void orc_ans_encoder_reset(orc_ans_encoder *e) {
+    e->n_pending = 0; e->out.len = 0; e->failed = 0;
 }
 
 /* ans.rs:331-378 flush_chunk + ans.rs:302-329 reverse_put_sym.
@@ -39,7 +44,8 @@ void orc_ans_encoder_free(orc_ans_encoder *e) {
 void orc_ans_flush_chunk(orc_ans_encoder *e) {
     uint32_t len = e->n_pending;
     if (len == 0) return;
-    uint32_t *words = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)len);
+    if (!e->words_scratch) e->words_scratch = (uint32_t *)malloc(sizeof(uint32_t) * ORC_ANS_NUM_SYMBOLS_BEFORE_FLUSH);
+    uint32_t *words = e->words_scratch;  /* at most one word per symbol */
     size_t nwords = 0;
     uint64_t state_a = ENC_START_STATE, state_b = ENC_START_STATE;
     for (uint32_t k = 0; k < len; ++k) {        /* newest symbol first */
@@ -72,7 +78,6 @@ void orc_ans_flush_chunk(orc_ans_encoder *e) {
     }
     e->out.len += 16 + 4 * nwords;
     e->n_pending = 0;
-    free(words);
 }
 
 /* ans.rs:287-301 */

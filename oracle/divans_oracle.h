@@ -79,8 +79,10 @@ typedef struct {
     uint32_t n_pending;
     orc_bytes out;           /* finished chunks, in the order the decoder reads them */
     int failed;              /* freq<=0 or start<0 seen (reference debug_asserts) */
+    uint32_t *words_scratch; /* renormalisation words of the chunk being flushed (reused between chunks) */
 } orc_ans_encoder;
 void orc_ans_encoder_init(orc_ans_encoder *e);
+void orc_ans_encoder_reset(orc_ans_encoder *e);
 void orc_ans_encoder_free(orc_ans_encoder *e);
 void orc_ans_put_start_freq(orc_ans_encoder *e, orc_prob start, orc_prob freq); /* ans.rs:287-301 */
 void orc_ans_put_nibble(orc_ans_encoder *e, uint8_t sym, const orc_cdf16 *cdf, orc_sym_start_freq *coded); /* ans.rs:279-286 */
@@ -140,6 +142,12 @@ size_t orc_lit_stream_encode_trace(const orc_lit_config *cfg, const uint8_t *in,
 /* batch helper for the CPU baseline: nthreads>=1 pthreads, each stream independent */
 int orc_lit_batch_roundtrip(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len,
                             int nthreads, double *enc_seconds, double *dec_seconds, uint64_t *coded_bytes);
+
+/* CPU baseline proper: every worker allocates its coder state, ANS buffers and output slots BEFORE a start barrier;
+ * all workers then encode their streams (stream i -> worker i % nthreads), meet at a second barrier and decode them.
+ * enc_wall / dec_wall = wall clock from the barrier release to the last worker finishing that direction. */
+int orc_lit_batch_bench(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len,
+                        int nthreads, double *enc_wall, double *dec_wall, uint64_t *coded_bytes);
 
 /* ---- complete literal-only .divans streams (stream.c) ---- */
 typedef struct {

@@ -415,3 +415,87 @@ int orc_lit_batch_roundtrip(const orc_lit_config *cfg, const uint8_t *in, size_t
     free(th); free(args);
     return bad ? -1 : 0;
 }
+
+
+/* ---- CPU baseline with nothing but coding inside the timed regions ---- */
+typedef struct {
+    const orc_lit_config *cfg;
+    const uint8_t *in;
+    size_t n_streams, stream_len;
+    int tid, nthreads;
+    pthread_barrier_t *bar;
+    uint8_t *coded; size_t slot; size_t *coded_len;   /* shared output slots, one per stream */
+    double enc_begin, enc_end, dec_begin, dec_end;
+    uint64_t coded_total;
+    int bad;
+} bench_arg;
+
+static void *bench_worker(void *p) {
+    bench_arg *a = (bench_arg *)p;
+    orc_lit_state *s = orc_lit_state_new(a->cfg);
+    orc_ans_encoder enc;
+    orc_ans_encoder_init(&enc);
+    enc.words_scratch = (uint32_t *)malloc(sizeof(uint32_t) * ORC_ANS_NUM_SYMBOLS_BEFORE_FLUSH);
+    enc.out.data = (uint8_t *)malloc(a->slot); enc.out.cap = a->slot;
+    uint8_t *back = (uint8_t *)malloc(a->stream_len ? a->stream_len : 1);
+    memset(enc.out.data, 0, a->slot); memset(back, 0, a->stream_len);      /* fault the pages in */
+    pthread_barrier_wait(a->bar);
+    a->enc_begin = now_s();
+    for (size_t i = (size_t)a->tid; i < a->n_streams; i += (size_t)a->nthreads) {
+        lit_state_reset(s, a->cfg);
+        orc_ans_encoder_reset(&enc);
+        orc_lit_encode_bytes(s, &enc, a->in + i * a->stream_len, a->stream_len);
+        orc_ans_flush_chunk(&enc);
+        if (enc.failed || enc.out.len > a->slot) { a->bad = 1; a->coded_len[i] = 0; continue; }
+        memcpy(a->coded + i * a->slot, enc.out.data, enc.out.len);
+        a->coded_len[i] = enc.out.len; a->coded_total += enc.out.len;
+    }
+    a->enc_end = now_s();
+    pthread_barrier_wait(a->bar);
+    a->dec_begin = now_s();
+    for (size_t i = (size_t)a->tid; i < a->n_streams; i += (size_t)a->nthreads) {
+        lit_state_reset(s, a->cfg);
+        orc_ans_decoder dec;
+        orc_ans_decoder_init(&dec, a->coded + i * a->slot, a->coded_len[i]);
+        orc_lit_decode_bytes(s, &dec, back, a->stream_len);
+        if (dec.starved || memcmp(back, a->in + i * a->stream_len, a->stream_len) != 0) a->bad = 1;
+    }
+    a->dec_end = now_s();
+    orc_ans_encoder_free(&enc); free(back);
+    orc_lit_state_free(s);
+    return NULL;
+}
+
+int orc_lit_batch_bench(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len,
+                        int nthreads, double *enc_wall, double *dec_wall, uint64_t *coded_bytes) {
+    if (nthreads < 1) nthreads = 1;
+    const size_t slot = stream_len * 2 + 64;
+    uint8_t *coded = (uint8_t *)malloc(slot * (n_streams ? n_streams : 1));
+    size_t *coded_len = (size_t *)calloc(n_streams ? n_streams : 1, sizeof(size_t));
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    bench_arg *args = (bench_arg *)calloc((size_t)nthreads, sizeof(bench_arg));
+    pthread_barrier_t bar;
+    if (!coded || !coded_len || !th || !args || pthread_barrier_init(&bar, NULL, (unsigned)nthreads) != 0) return -1;
+    memset(coded, 0, slot * (n_streams ? n_streams : 1));
+    for (int t = 0; t < nthreads; ++t) {
+        args[t].cfg = cfg; args[t].in = in; args[t].n_streams = n_streams; args[t].stream_len = stream_len;
+        args[t].tid = t; args[t].nthreads = nthreads; args[t].bar = &bar;
+        args[t].coded = coded; args[t].slot = slot; args[t].coded_len = coded_len;
+        pthread_create(&th[t], NULL, bench_worker, &args[t]);
+    }
+    double eb = 1e300, ee = 0, db = 1e300, de = 0; uint64_t total = 0; int bad = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        pthread_join(th[t], NULL);
+        if (args[t].enc_begin < eb) eb = args[t].enc_begin;
+        if (args[t].enc_end > ee) ee = args[t].enc_end;
+        if (args[t].dec_begin < db) db = args[t].dec_begin;
+        if (args[t].dec_end > de) de = args[t].dec_end;
+        total += args[t].coded_total; bad |= args[t].bad;
+    }
+    if (enc_wall) *enc_wall = ee - eb;
+    if (dec_wall) *dec_wall = de - db;
+    if (coded_bytes) *coded_bytes = total;
+    pthread_barrier_destroy(&bar);
+    free(coded); free(coded_len); free(th); free(args);
+    return bad ? -1 : 0;
+}

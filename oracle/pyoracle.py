@@ -93,6 +93,8 @@ def lib(native=False):
     L.orc_lit_batch_roundtrip.argtypes = [ctypes.POINTER(LitConfig), ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+    L.orc_lit_batch_bench.restype = ctypes.c_int
+    L.orc_lit_batch_bench.argtypes = L.orc_lit_batch_roundtrip.argtypes
     L.orc_cdf_default.argtypes = [ctypes.POINTER(Cdf16)]
     L.orc_cdf_blend.argtypes = [ctypes.POINTER(Cdf16), ctypes.c_uint8, Speed]
     L.orc_cdf_average.argtypes = [ctypes.POINTER(Cdf16), ctypes.POINTER(Cdf16), ctypes.c_int32, ctypes.POINTER(Cdf16)]
