@@ -125,7 +125,7 @@ def cpu_baseline(cfg_name, workload, corpus, block_len):
     scale = max(1, 65536 // max(block_len, 1))
     single = run((256 if cfg_name == "simple" else 96) * scale, 1)
     threads = par["usable"]
-    allc = run(threads * (48 if cfg_name == "simple" else 24) * scale, threads)
+    allc = run(threads * (256 if cfg_name == "simple" else 96) * scale, threads)
     factor = allc["MBps"] / single["MBps"]
     note = ""
     if factor < 0.5 * threads:
@@ -389,7 +389,6 @@ def main():
             barrier(); t0 = time.perf_counter()
             d_in = sharding.scatter_streams(full, total_streams, L, dev)
             barrier(); scatter_s = time.perf_counter() - t0
-            d_in = d_in.contiguous().clone() if rank == 0 else d_in
             mg = {"scatter_ms": round(sharding.max_over_ranks(scatter_s, dev) * 1e3, 3)}
             if rank != 0:
                 full = None
@@ -432,7 +431,6 @@ def main():
             mg.update({"gather_ms": round(gather_s * 1e3, 3), "gathered_bytes": int(coded_all), "gather_checked_on_rank0": bool(g_ok == world),
                        "rccl_world_size": world,
                        "scatter_gather_inclusive_MBps": round(total_streams * L / 1e6 / (step_s + mg["scatter_ms"] / 1e3 + gather_s), 2)})
-            per_rank = [0.0] * world
             t = torch.zeros(world, dtype=torch.float64, device=dev); t[rank] = res["elapsed"] / K * 1e3
             dist.all_reduce(t)
             mg["per_rank_ms_per_step"] = [round(float(x), 3) for x in t.tolist()]

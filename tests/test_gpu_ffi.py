@@ -127,8 +127,9 @@ def test_option_errors():
     assert L.divans_set_option(st, 12, 15) == 3                # palette index out of range
     buf = np.empty(100, np.uint8); wo = ctypes.c_size_t(0); ro = ctypes.c_size_t(0)
     data = np.zeros(10, np.uint8)
-    # default options select the brotli front end, which this build does not carry: loud failure, no fallback
-    assert L.divans_encode(st, data.ctypes.data, 10, ctypes.byref(ro), buf.ctypes.data, 100, ctypes.byref(wo)) == 3
+    # options are only legal before the first encode (OptionStage, ffi/compressor.rs:63-66)
+    assert L.divans_encode(st, data.ctypes.data, 10, ctypes.byref(ro), buf.ctypes.data, 100, ctypes.byref(wo)) == 1
+    assert L.divans_set_option(st, 2, 16) == 3
     L.divans_free_compressor(st)
     assert L.divans_encode(None, data.ctypes.data, 10, ctypes.byref(ro), buf.ctypes.data, 100, ctypes.byref(wo)) == 3
 
@@ -145,3 +146,84 @@ def test_c_harness(tmp_path, corpus):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     coded = np.fromfile(dv, dtype=np.uint8)
     assert (po.stream_decompress(coded, 100000) == corpus[:100000]).all()
+
+
+def test_default_options_encode_literal_only(corpus):
+    """c/example.c sets no options: the default BrotliCompressionSetting asks for the brotli front end, which this library
+    does not carry; the stream is coded with the internal command selection instead (a valid .divans stream, same bytes as
+    DIVANS_OPTION_USE_BROTLI_COMMAND_SELECTION = 0) and round-trips."""
+    data = corpus[1000:1000 + 30000]
+    coded = ffi_compress(data, [])
+    assert (coded == ffi_compress(data, [(5, 0)])).all()
+    ref = po.stream_compress_raw(data, po.stream_options(call_buffer_size=65536))
+    assert coded.size == ref.size and (coded == ref).all()
+    assert (ffi_decompress(coded, data.size) == data).all()
+
+
+def test_corrupt_and_truncated_streams_fail(corpus):
+    """a damaged LIT stream must not decode to garbage with DIVANS_SUCCESS."""
+    L = _lib()
+    data = corpus[:40000]
+    coded = ffi_compress(data, [(5, 0)]).copy()
+
+    def decode_result(buf, skip_crc):
+        L.divans_new_decompressor_with_custom_alloc.restype = ctypes.c_void_p
+        L.divans_new_decompressor_with_custom_alloc.argtypes = [CAllocator, ctypes.c_uint8, ctypes.c_uint8]
+        st = L.divans_new_decompressor_with_custom_alloc(CAllocator(None, None, None), skip_crc, 0)
+        out = np.empty(1 << 20, np.uint8); ro = ctypes.c_size_t(0); wo = ctypes.c_size_t(0)
+        r = L.divans_decode(st, buf.ctypes.data, buf.size, ctypes.byref(ro), out.ctypes.data, out.size, ctypes.byref(wo))
+        L.divans_free_decompressor(st)
+        return r, out[:wo.value]
+
+    r, out = decode_result(coded, 0)
+    assert r == 0 and (out == data).all()
+    # flip one byte in the middle of the payload: with the CRC checked the trailer catches it, with skip_crc the literal
+    # decoder's own integrity check (final rANS states / word count) must
+    bad = coded.copy(); bad[coded.size // 2] ^= 0x40
+    assert decode_result(bad, 0)[0] == 3
+    assert decode_result(bad, 1)[0] == 3
+    # a stream cut short never reports success
+    assert decode_result(coded[:coded.size - 500].copy(), 0)[0] in (1, 3)
+
+
+def test_batch_status_reports_bad_streams(corpus):
+    import torch
+    import divans_amd as da
+    import workload
+    blocks = workload.make_blocks(corpus, 0, 32, block_len=4096)
+    codec = da.LiteralCodec(da.config_simple(), 4096)
+    d_in = torch.from_numpy(blocks).cuda()
+    outs = codec.alloc_encode_outputs(32, 4096)
+    codec.encode_batch(d_in, 32, 4096, outs)
+    back = torch.empty_like(d_in)
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], 32, 4096, back)
+    assert codec.status() == 0 and torch.equal(back, d_in)
+    # stream 7 loses its last word, stream 9 gets a flipped bit: both must be flagged, the sticky word is cleared by the read
+    sizes = outs["sizes"].clone(); sizes[7] -= 4
+    codec.decode_batch(outs["out"], outs["offsets"], sizes, 32, 4096, back)
+    assert codec.status() == 2 and codec.status() == 0
+    dmg = outs["out"].clone(); dmg[int(outs["offsets"][9]) + 40] ^= 1
+    codec.decode_batch(dmg, outs["offsets"], outs["sizes"], 32, 4096, back)
+    assert codec.status() == 2
+    # a stream decoded under the wrong configuration is caught the same way
+    other = da.LiteralCodec(da.config_context_mixing(), 4096)
+    other.decode_batch(outs["out"], outs["offsets"], outs["sizes"], 32, 4096, back)
+    assert other.status() == 2
+    other.close(); codec.close()
+
+
+REF_EXAMPLE = os.path.join(ROOT, "oracle", "_ref", "ffi_example")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXAMPLE), reason="oracle/_ref/ffi_example is built by __graft_entry__.build() where /root/reference is mounted")
+@pytest.mark.parametrize("args,env", [([], {}), (["-l"], {}), (["-l", "-cm", "-m2", "-s1"], {}), (["-l", "-w12"], {"NO_MALLOC": "1"}), ([], {"RUST_MALLOC": "1"})])
+def test_reference_example_c_unmodified(args, env, tmp_path, corpus):
+    """The reference's own harness (c/example.c + arg.h + custom_alloc.h, compiled verbatim by oracle/Makefile `ref_example`)
+    linked against libdivans_hip.so: compress -> decompress -> memcmp, built-in text and a 100 kB file, real / fake / libc allocators."""
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([REF_EXAMPLE] + args, capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0 and "reduced to" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    src = tmp_path / "in.bin"
+    corpus[:100000].tofile(src)
+    r = subprocess.run([REF_EXAMPLE] + args + [str(src)], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0 and "File length 100000 reduced to" in r.stdout, (r.returncode, r.stdout, r.stderr)
