@@ -46,6 +46,18 @@ class LitConfig(ctypes.Structure):
     ]
 
 
+class LitSegment(ctypes.Structure):
+    """divans_lit_segment (include/divans_gpu.h): one Literal command of a general stream."""
+    _fields_ = [("len", ctypes.c_uint32), ("btype", ctypes.c_uint32), ("last8", ctypes.c_uint64)]
+
+
+class IrOptions(ctypes.Structure):
+    """divans_ir_options (include/divans_ir.h)."""
+    _fields_ = [("dynamic_context_mixing", ctypes.c_uint8), ("use_context_map", ctypes.c_uint8), ("force_stride", ctypes.c_uint8),
+                ("has_prior_depth", ctypes.c_uint8), ("prior_depth", ctypes.c_uint8), ("has_literal_adaptation", ctypes.c_uint8),
+                ("literal_adaptation", Speed * 4)]
+
+
 class GpuInfo(ctypes.Structure):
     _fields_ = [
         ("rows_per_stream", ctypes.c_uint32), ("resident_groups", ctypes.c_uint32),
@@ -98,6 +110,22 @@ def load_library():
     L.divans_gpu_lit_model_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
+    L.divans_gpu_codec_set_block_types.argtypes = [vp, u32]
+    L.divans_gpu_lit_encode_segments_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, vp, u64, vp, vp]
+    L.divans_gpu_lit_decode_segments_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, u32]
+    sz = ctypes.c_size_t
+    L.divans_ir_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]
+    L.divans_ir_free.argtypes = [vp]
+    L.divans_ir_free.restype = None
+    for name in ("divans_ir_num_commands", "divans_ir_raw_size", "divans_ir_literal_size", "divans_ir_num_segments"):
+        getattr(L, name).argtypes = [vp]; getattr(L, name).restype = sz
+    L.divans_ir_count.argtypes = [vp, ctypes.c_int]; L.divans_ir_count.restype = sz
+    L.divans_ir_num_block_types.argtypes = [vp]; L.divans_ir_num_block_types.restype = u32
+    L.divans_ir_expand.argtypes = [vp, vp, sz]
+    L.divans_ir_literal_segments.argtypes = [vp, vp, sz, vp, sz]
+    L.divans_ir_options_default.argtypes = [ctypes.POINTER(IrOptions)]
+    L.divans_ir_options_default.restype = None
+    L.divans_ir_lit_config.argtypes = [vp, ctypes.POINTER(IrOptions), ctypes.POINTER(LitConfig)]
     _LIB = L
     return L
 
@@ -110,8 +138,79 @@ def exported_symbols():
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_lit_model_batch",
-        "divans_gpu_selftest_division", "divans_gpu_codec_status",
+        "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_block_types",
+        "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
     ]
+
+
+def exported_ir_symbols():
+    """Entry points include/divans_ir.h declares."""
+    return ["divans_ir_parse", "divans_ir_free", "divans_ir_num_commands", "divans_ir_count", "divans_ir_raw_size", "divans_ir_expand",
+            "divans_ir_literal_size", "divans_ir_num_segments", "divans_ir_num_block_types", "divans_ir_literal_segments",
+            "divans_ir_options_default", "divans_ir_lit_config"]
+
+
+class CommandIR:
+    """The reference's textual command IR (src/bin/divans.rs:191-483) parsed by the product's host code: expansion to the
+    original bytes (cmd_to_raw) and the literal coder's view of a general stream (literal bytes + one segment per Literal
+    command).  Host-only: works without a GPU."""
+    KINDS = {"copy": 0, "dict": 1, "literal": 3, "ltype": 4, "ctype": 5, "dtype": 6, "prediction": 7}
+
+    def __init__(self, text):
+        self._lib = load_library()
+        if isinstance(text, str):
+            text = text.encode()
+        h = ctypes.c_void_p()
+        _check(self._lib.divans_ir_parse(text, len(text), ctypes.byref(h)), "divans_ir_parse")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.divans_ir_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count(self, kind):
+        return int(self._lib.divans_ir_count(self._h, self.KINDS[kind]))
+
+    @property
+    def num_block_types(self):
+        return int(self._lib.divans_ir_num_block_types(self._h))
+
+    def expand(self):
+        n = int(self._lib.divans_ir_raw_size(self._h))
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        _check(self._lib.divans_ir_expand(self._h, out.ctypes.data, n), "divans_ir_expand")
+        return out[:n]
+
+    def literal_segments(self):
+        """(literal bytes uint8[n], segments structured array with fields len / btype / last8)"""
+        n = int(self._lib.divans_ir_literal_size(self._h)); k = int(self._lib.divans_ir_num_segments(self._h))
+        lit = np.empty(max(n, 1), dtype=np.uint8)
+        segs = np.zeros(max(k, 1), dtype=np.dtype([("len", "<u4"), ("btype", "<u4"), ("last8", "<u8")]))
+        _check(self._lib.divans_ir_literal_segments(self._h, lit.ctypes.data, n, segs.ctypes.data, k), "divans_ir_literal_segments")
+        return lit[:n], segs[:k]
+
+    def lit_config(self, **options):
+        o = IrOptions()
+        self._lib.divans_ir_options_default(ctypes.byref(o))
+        for key, val in options.items():
+            if key == "literal_adaptation":
+                o.has_literal_adaptation = 1
+                for i, (inc, lim) in enumerate(val):
+                    o.literal_adaptation[i].inc = inc; o.literal_adaptation[i].lim = lim
+            elif key == "prior_depth":
+                o.has_prior_depth = 1; o.prior_depth = val
+            else:
+                setattr(o, key, val)
+        cfg = LitConfig()
+        _check(self._lib.divans_ir_lit_config(self._h, ctypes.byref(o), ctypes.byref(cfg)), "divans_ir_lit_config")
+        return cfg
 
 
 def config_simple():
@@ -224,6 +323,23 @@ class LiteralCodec:
             in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams),
             outputs["out"].data_ptr(), int(outputs["slot"]), outputs["offsets"].data_ptr(),
             outputs["sizes"].data_ptr()), "divans_gpu_lit_encode_batch")
+
+    def set_block_types(self, n_btypes):
+        """Context tables for literal block types 0 .. n_btypes-1 (general streams with BlockSwitchLiteral commands)."""
+        _check(self._lib.divans_gpu_codec_set_block_types(self._h, int(n_btypes)), "divans_gpu_codec_set_block_types")
+
+    def encode_segments_batch(self, d_in, in_offsets, in_sizes, n_streams, stream_len, seg_begin, segs, outputs):
+        """General streams: stream i = in_sizes[i] literal bytes at in_offsets[i], split by the divans_lit_segment records
+        segs[seg_begin[i] : seg_begin[i+1]] (device tensors: seg_begin int32[n+1], segs uint8 view of the 16-byte records)."""
+        _check(self._lib.divans_gpu_lit_encode_segments_batch(
+            self._h, d_in.data_ptr(), in_offsets.data_ptr(), in_sizes.data_ptr(), int(stream_len), int(n_streams),
+            seg_begin.data_ptr(), segs.data_ptr(), outputs["out"].data_ptr(), int(outputs["slot"]), outputs["offsets"].data_ptr(),
+            outputs["sizes"].data_ptr()), "divans_gpu_lit_encode_segments_batch")
+
+    def decode_segments_batch(self, d_coded, d_offsets, d_sizes, n_streams, stream_len, seg_begin, segs, d_out, out_offsets, out_sizes):
+        _check(self._lib.divans_gpu_lit_decode_segments_batch(
+            self._h, d_coded.data_ptr(), d_offsets.data_ptr(), d_sizes.data_ptr(), int(n_streams), seg_begin.data_ptr(), segs.data_ptr(),
+            d_out.data_ptr(), out_offsets.data_ptr(), out_sizes.data_ptr(), int(stream_len)), "divans_gpu_lit_decode_segments_batch")
 
     def model_batch(self, d_in, n_streams, stream_len, in_offsets=None, in_sizes=None):
         """Model pass only: int32 device tensor [n_streams, 2 * M] of start | freq << 16 per nibble (M = max_stream_len, even)."""

@@ -25,6 +25,7 @@ static int fail(int code, const std::string& msg) { g_last_error = msg; return c
     } while (0)
 
 extern "C" const char* divans_gpu_last_error(void) { return g_last_error.c_str(); }
+namespace divans_host { int set_last_error(int code, const std::string& msg) { return fail(code, msg); } }
 
 // ---- configuration helpers -------------------------------------------------------------------
 static const divans_speed kSpeedMud = {0x10, 0x2000};  // probability/interface.rs:323 / codec/interface.rs:188-190
@@ -118,7 +119,11 @@ struct divans_gpu_codec {
     bool timing_pending_enc = false, timing_pending_dec = false;
 };
 
-static int derive_geometry(const divans_lit_config& cfg, LitGeometry& g, std::vector<uint8_t>& blob) {
+// Tables are built for the literal block types [bt_first, bt_first + n_btypes): one for a batch of single-segment
+// streams (cfg.btype), all of 0..max for streams with BlockSwitchLiteral commands between their segments.
+static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint32_t n_btypes, LitGeometry& g, std::vector<uint8_t>& blob) {
+    if (n_btypes == 0 || n_btypes > LIT_MAX_BTYPES || bt_first + n_btypes > 256u)
+        return fail(DIVANS_GPU_EINVAL, "a codec keeps context tables for 1..8 consecutive literal block types");
     if (cfg.prediction_mode > 3) return fail(DIVANS_GPU_EINVAL, "prediction_mode must be 0..3 (codec/interface.rs:252-256)");
     if (cfg.context_mixing >= 15) return fail(DIVANS_GPU_EINVAL, "context_mixing must be < 15 (codec/interface.rs:359)");
     for (int i = 0; i < 4; ++i) {
@@ -128,11 +133,11 @@ static int derive_geometry(const divans_lit_config& cfg, LitGeometry& g, std::ve
         if (s.inc < 0 || s.lim <= 0 || s.inc > 0x4000 || s.lim > 0x4000 || (int)s.inc + (int)s.lim + 16 > 0x7fff)
             return fail(DIVANS_GPU_EINVAL, "literal_adaptation speed outside the supported range");
     }
-    blob.assign(LIT_BLOB_BYTES, 0);
+    const uint32_t mix_off = LIT_BLOB_CTXF + LIT_CTXF_BYTES * n_btypes;
+    blob.assign(mix_off + DIVANS_GPU_NUM_MIXING_VALUES, 0);
     uint8_t lut0[256], lut1[256];
     make_luts(cfg.prediction_mode, lut0, lut1);
-    const uint8_t* cmap64 = cfg.literal_context_map + 64u * cfg.btype;  // literal.rs:114 cmap_index = sel + (btype << 6)
-    std::memcpy(&blob[LIT_BLOB_MIX], cfg.mixing_mask, DIVANS_GPU_NUM_MIXING_VALUES);
+    std::memcpy(&blob[mix_off], cfg.mixing_mask, DIVANS_GPU_NUM_MIXING_VALUES);
     // lut1 takes at most 8 distinct values (SIGN: 0..7, UTF8: 0..3, MSB6/LSB6: 0): class them so the kernel
     // can fold lut0 | lut1 | context map into one LDS read keyed by (prev, class(prev_prev))
     int class_of_value[256]; std::memset(class_of_value, -1, sizeof(class_of_value));
@@ -146,18 +151,22 @@ static int derive_geometry(const divans_lit_config& cfg, LitGeometry& g, std::ve
     }
     bool ctx_seen[256] = {false};
     uint32_t maxctx = 0; int first = -1; bool constant = true;
-    for (int prev = 0; prev < 256; ++prev) {
-        for (int k = 0; k < 8; ++k) {
-            const uint8_t sel = (uint8_t)((lut0[prev] | class_value[k < nclass ? k : 0]) & 63);
-            const uint8_t c = cmap64[sel];
-            blob[LIT_BLOB_CTXF + prev * 8 + k] = c;
-            if (k >= nclass) continue;
-            ctx_seen[c] = true;
-            maxctx = std::max<uint32_t>(maxctx, c);
-            if (first < 0) first = c; else if (c != first) constant = false;
+    for (uint32_t bt = 0; bt < n_btypes; ++bt) {
+        const uint8_t* cmap64 = cfg.literal_context_map + 64u * (bt_first + bt);  // literal.rs:114 cmap_index = sel + (btype << 6)
+        for (int prev = 0; prev < 256; ++prev) {
+            for (int k = 0; k < 8; ++k) {
+                const uint8_t sel = (uint8_t)((lut0[prev] | class_value[k < nclass ? k : 0]) & 63);
+                const uint8_t c = cmap64[sel];
+                blob[LIT_BLOB_CTXF + LIT_CTXF_BYTES * bt + prev * 8 + k] = c;
+                if (k >= nclass) continue;
+                ctx_seen[c] = true;
+                maxctx = std::max<uint32_t>(maxctx, c);
+                if (first < 0) first = c; else if (c != first) constant = false;
+            }
         }
     }
     std::memset(&g, 0, sizeof(g));
+    g.bt_first = bt_first; g.n_btypes = n_btypes; g.mix_off = mix_off;
     g.nctx = maxctx + 1;
     g.ctx_const = constant ? first : -1;
     // reachable mixing values: index = ctx | nibble << 8 | (low ? 4096 : 0)  (literal.rs:176-183)
@@ -228,6 +237,26 @@ static int ensure_sf(divans_gpu_codec* c, uint32_t n_streams) {
     return 0;
 }
 
+// launch geometry, LDS cache organisation and encoder path that follow from the table geometry
+static void configure_from_geometry(divans_gpu_codec* c) {
+    c->blocks = c->num_cus * 4u;  // without a row cache (more than 32766 rows per stream): 16 waves = 64 streams per CU
+    c->cache_high = c->cache_low = 0u; c->cache_unified = false;
+    // row cache: high-nibble rows only -- few and hot (32 rows take ~90 % of their accesses)
+    if (c->geom.total_rows < 0x7fffu) {
+        // the kernels gain more from a seventh wave per SIMD than from the second half of the row cache (DESIGN.md
+        // section 7; the non-mixing decode kernel needs 62 VGPRs): 7 workgroups per CU with 32-row caches, fewer when
+        // the context tables of a generic configuration take more of the CU's 160 KB of LDS (the kernels stage the
+        // mixing mask unless the mixing value is one they are specialised for: 0 or 4, see effective_mm)
+        c->cache_high = 32u;
+        const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
+        const uint32_t lds_per_wg = (LIT_THREADS / 16) * c->cache_high * 34u +
+                                    (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
+        const uint32_t fit = (160u * 1024u) / lds_per_wg;
+        c->blocks = c->num_cus * std::max(1u, std::min(7u, fit));
+    }
+    c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && c->geom.ctx_const >= 0 && c->max_stream_len <= 65536u;
+}
+
 extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c);
 
 extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_config* cfg, int device, void* hip_stream,
@@ -243,32 +272,16 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     c->cfg = *cfg;
     c->max_stream_len = (max_stream_len + 1u) & ~1u;   // even: keeps every stream's start/freq spill 16-byte aligned
     std::vector<uint8_t> blob;
-    int rc = derive_geometry(*cfg, c->geom, blob);
+    int rc = derive_geometry(*cfg, cfg->btype, 1, c->geom, blob);
     if (rc) { divans_gpu_codec_destroy(c); return rc; }
     c->mix = cfg->context_mixing > 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
-    c->blocks = c->num_cus * 4u;  // without a row cache (more than 32766 rows per stream): 16 waves = 64 streams per CU
-    // row cache: high-nibble rows only -- few and hot (32 rows take ~90 % of their accesses)
-    if (c->geom.total_rows < 0x7fffu) { c->cache_high = 64u; c->cache_low = 0u; c->cache_unified = false; }
-    if (c->cache_high) {
-        // the kernels gain more from a seventh wave per SIMD than from the second half of the row cache (DESIGN.md
-        // section 7; the non-mixing decode kernel needs 62 VGPRs): 7 workgroups per CU with 32-row caches, fewer when
-        // the context tables of a generic configuration take more of the CU's 160 KB of LDS (the kernels stage the
-        // mixing mask unless the mixing value is one they are specialised for: 0 or 4, see effective_mm)
-        c->cache_high = 32u;
-        const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
-        const uint32_t lds_per_wg = (LIT_THREADS / 16) * c->cache_high * 34u + (c->geom.ctx_const < 0 ? LIT_BLOB_CTX_BYTES : 0u) +
-                                    (mask_in_lds ? 8192u : 0u);
-        const uint32_t fit = (160u * 1024u) / lds_per_wg;
-        c->blocks = c->num_cus * std::max(1u, std::min(7u, fit));
-    }
-    c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && c->geom.ctx_const >= 0 && c->max_stream_len <= 65536u;
-    c->packed8 = false;   // the packed 8-lane kernels (set_lane_layout(8)) are bit-identical; on MI355X the 16-lane ones are faster
-    hipError_t he = hipMalloc(&c->d_blob, LIT_BLOB_BYTES);
+    configure_from_geometry(c);
+    hipError_t he = hipMalloc(&c->d_blob, LIT_BLOB_MAX_BYTES);
     if (he == hipSuccess) he = hipMalloc(&c->d_status, 64);
     if (he != hipSuccess) { divans_gpu_codec_destroy(c); return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed"); }
-    if (he == hipSuccess) he = hipMemcpy(c->d_blob, blob.data(), LIT_BLOB_BYTES, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(c->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemset(c->d_status, 0, 64);
     for (auto& e : c->ev) if (he == hipSuccess) he = hipEventCreate(&e);
     if (he != hipSuccess) { divans_gpu_codec_destroy(c); return fail(DIVANS_GPU_EHIP, std::string("codec setup: ") + hipGetErrorString(he)); }
@@ -339,6 +352,23 @@ static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, RansBatc
     return 0;
 }
 
+// General streams switch the literal block type between Literal commands (BlockSwitchLiteral): rebuild the context
+// tables for block types 0 .. n_btypes-1 (the segment entry points index them by divans_lit_segment::btype).
+extern "C" int divans_gpu_codec_set_block_types(divans_gpu_codec* c, uint32_t n_btypes) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    HIP_TRY(hipSetDevice(c->device));
+    LitGeometry g; std::vector<uint8_t> blob;
+    int rc = derive_geometry(c->cfg, 0, n_btypes, g, blob); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    c->geom = g;
+    if (c->d_tables) { HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }
+    const bool was_packed = c->packed8;
+    configure_from_geometry(c);
+    c->packed8 = was_packed;
+    return 0;
+}
+
 extern "C" int divans_gpu_codec_set_encode_path(divans_gpu_codec* c, uint32_t path) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (path > 2u) return fail(DIVANS_GPU_EINVAL, "path must be 0 (automatic), 1 (streaming) or 2 (bucketed)");
@@ -393,9 +423,9 @@ extern "C" size_t divans_gpu_lit_encode_bound(size_t n) {
 
 // Encoder pass 1: fills c->d_sf with (start | freq << 16) per nibble, position order.  Records ev[0], ev[1] around it.
 static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes,
-                      uint32_t stream_len, uint32_t n_streams) {
+                      uint32_t stream_len, uint32_t n_streams, const uint32_t* d_seg_begin = nullptr, const divans_lit_segment* d_segs = nullptr) {
     int rc = ensure_sf(c, n_streams); if (rc) return rc;
-    if (use_bucket(c) && n_streams < (1u << 24)) {
+    if (use_bucket(c) && n_streams < (1u << 24) && !d_segs) {   // segment lists (context reloads between Literal commands) go through the streaming kernels
         BucketBatch k;
         std::memset(&k, 0, sizeof(k));
         rc = ensure_bucket(c, n_streams, k); if (rc) return rc;
@@ -415,7 +445,9 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
     b.sf = c->d_sf; b.status = c->d_status;
+    b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
+    if (d_segs && (c->packed8 || b.cache_mode != 2u)) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache");
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (c->packed8) HIP_TRY(launch_model_encode_p8(b, c->blocks, c->stream));
     else HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
@@ -426,7 +458,8 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
 static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                              const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                              uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes,
-                             uint32_t* d_chunk_bytes, uint32_t max_chunks);
+                             uint32_t* d_chunk_bytes, uint32_t max_chunks,
+                             const uint32_t* d_seg_begin = nullptr, const divans_lit_segment* d_segs = nullptr);
 
 extern "C" int divans_gpu_lit_encode_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                                            const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
@@ -438,15 +471,17 @@ extern "C" int divans_gpu_lit_encode_batch(divans_gpu_codec* c, const uint8_t* d
 static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                              const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                              uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes,
-                             uint32_t* d_chunk_bytes, uint32_t max_chunks) {
+                             uint32_t* d_chunk_bytes, uint32_t max_chunks,
+                             const uint32_t* d_seg_begin, const divans_lit_segment* d_segs) {
     if (!c || !d_in || !d_out || !d_out_offsets || !d_out_sizes) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if ((d_seg_begin == nullptr) != (d_segs == nullptr)) return fail(DIVANS_GPU_EINVAL, "seg_begin and segs go together");
     if (n_streams == 0) return 0;
     if ((d_in_offsets == nullptr) != (d_in_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
     if (stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "stream_len exceeds the codec's max_stream_len");
     if (out_slot % 16 != 0 || out_slot < divans_gpu_lit_encode_bound(d_in_sizes ? c->max_stream_len : stream_len))
         return fail(DIVANS_GPU_ECAP, "out_slot must be a multiple of 16 and >= divans_gpu_lit_encode_bound()");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams); if (rc) return rc;
+    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, d_seg_begin, d_segs); if (rc) return rc;
     RansBatch r;
     r.sf = c->d_sf; r.n_streams = n_streams; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
     r.in_sizes = d_in_sizes; r.out = d_out; r.out_slot = out_slot; r.out_offsets = d_out_offsets; r.out_sizes = d_out_sizes;
@@ -459,6 +494,15 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     c->timing_pending_enc = true;
     return 0;
+}
+
+extern "C" int divans_gpu_lit_encode_segments_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                                                    const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                                                    const uint32_t* d_seg_begin, const divans_lit_segment* d_segs,
+                                                    uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes) {
+    if (!d_seg_begin || !d_segs) return fail(DIVANS_GPU_EINVAL, "null segment list");
+    return encode_batch_impl(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, d_out, out_slot, d_out_offsets,
+                             d_out_sizes, nullptr, 0, d_seg_begin, d_segs);
 }
 
 extern "C" int divans_gpu_lit_model_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
@@ -475,9 +519,29 @@ extern "C" int divans_gpu_lit_model_batch(divans_gpu_codec* c, const uint8_t* d_
     return 0;
 }
 
+static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                             const uint32_t* d_in_sizes, uint32_t n_streams, uint8_t* d_out,
+                             const uint64_t* d_out_offsets, const uint32_t* d_out_sizes, uint32_t stream_len,
+                             const uint32_t* d_seg_begin, const divans_lit_segment* d_segs);
+
 extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                                            const uint32_t* d_in_sizes, uint32_t n_streams, uint8_t* d_out,
                                            const uint64_t* d_out_offsets, const uint32_t* d_out_sizes, uint32_t stream_len) {
+    return decode_batch_impl(c, d_in, d_in_offsets, d_in_sizes, n_streams, d_out, d_out_offsets, d_out_sizes, stream_len, nullptr, nullptr);
+}
+
+extern "C" int divans_gpu_lit_decode_segments_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                                                    const uint32_t* d_in_sizes, uint32_t n_streams,
+                                                    const uint32_t* d_seg_begin, const divans_lit_segment* d_segs, uint8_t* d_out,
+                                                    const uint64_t* d_out_offsets, const uint32_t* d_out_sizes, uint32_t stream_len) {
+    if (!d_seg_begin || !d_segs) return fail(DIVANS_GPU_EINVAL, "null segment list");
+    return decode_batch_impl(c, d_in, d_in_offsets, d_in_sizes, n_streams, d_out, d_out_offsets, d_out_sizes, stream_len, d_seg_begin, d_segs);
+}
+
+static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                             const uint32_t* d_in_sizes, uint32_t n_streams, uint8_t* d_out,
+                             const uint64_t* d_out_offsets, const uint32_t* d_out_sizes, uint32_t stream_len,
+                             const uint32_t* d_seg_begin, const divans_lit_segment* d_segs) {
     if (!c || !d_in || !d_in_offsets || !d_in_sizes || !d_out) return fail(DIVANS_GPU_EINVAL, "null argument");
     if (n_streams == 0) return 0;
     if ((d_out_offsets == nullptr) != (d_out_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
@@ -490,7 +554,9 @@ extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes; b.status = c->d_status;
+    b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
+    if (d_segs && (c->packed8 || b.cache_mode != 2u)) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache");
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     if (c->packed8) HIP_TRY(launch_decode_p8(b, c->blocks, c->stream));
     else HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));

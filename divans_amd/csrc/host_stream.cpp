@@ -156,6 +156,7 @@ static uint8_t speed_to_u8(int16_t d) {
     if (d != 0) { const int16_t rem = (int16_t)(d - (int16_t)(1 << (length - 1))); mant = (int16_t)(rem << 3) >> (length - 1); }
     return (uint8_t)((length << 3) | mant);
 }
+uint8_t speed_to_f8(int16_t v) { return speed_to_u8(v); }
 static int16_t u8_to_speed(uint8_t d) {
     if (d < 8) return 0;
     const int lg = (d >> 3) - 1;
@@ -164,13 +165,6 @@ static int16_t u8_to_speed(uint8_t d) {
 }
 
 // ---------------------------------------------------------------- command-stream model
-struct PredictionModeIn {                 // what raw_to_cmd hands over (raw_to_cmd/mod.rs:115-143)
-    uint8_t prediction_mode = 0, is_adv = 0;
-    std::vector<uint8_t> literal_context_map, distance_context_map, mixing_values;
-    bool has_context_speeds = false;
-    uint8_t cm_speed[2][2] = {{0, 0}, {0, 0}}, stride_speed[2][2] = {{0, 0}, {0, 0}}, combined_speed[2][2] = {{0, 0}, {0, 0}};
-};
-
 class CommandModel {
   public:
     explicit CommandModel(const StreamOptions& o) {
@@ -545,6 +539,21 @@ struct GpuCodecHandle {
         if (old) divans_gpu_codec_destroy(old);
     }
 };
+
+int lit_config_from_prediction_mode(const StreamOptions& opt, const PredictionModeIn* pm, divans_lit_config& cfg) {
+    std::memset(&cfg, 0, sizeof(cfg));
+    if (!pm) {   // LiteralBookKeeping::new, codec/interface.rs:244-262: zero maps, lsb6, default speeds
+        for (auto& s : cfg.literal_adaptation) s = divans_speed{0x10, 0x2000};
+        return 0;
+    }
+    CommandModel probe(opt);
+    RansEncoder scratch;
+    NibbleCoder pn; pn.enc = &scratch;
+    probe.command_type(pn, 7);
+    if (!probe.prediction_mode(pn, pm)) return DIVANS_GPU_EINVAL;
+    probe.fill_lit_config(cfg, 0);
+    return 0;
+}
 
 int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
                     std::vector<uint8_t>& out) {

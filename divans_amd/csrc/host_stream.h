@@ -22,6 +22,16 @@ struct StreamOptions {            // DivansCompressorOptions, src/interface.rs:4
     int use_brotli = 1;           // BrotliCompressionSetting (only 0 = internal command selection is implemented)
 };
 
+struct PredictionModeIn {                 // the PredictionMode command as the encoder receives it (raw_to_cmd/mod.rs:115-143, bin/divans.rs:199-316)
+    uint8_t prediction_mode = 0, is_adv = 0;
+    std::vector<uint8_t> literal_context_map, distance_context_map, mixing_values;
+    bool has_context_speeds = false;
+    uint8_t cm_speed[2][2] = {{0, 0}, {0, 0}}, stride_speed[2][2] = {{0, 0}, {0, 0}}, combined_speed[2][2] = {{0, 0}, {0, 0}};   // (inc, lim) as f8
+};
+// What LiteralBookKeeping holds after `pm` went through the CMD coder under `opt` (null pm: the constructor defaults).
+int lit_config_from_prediction_mode(const StreamOptions& opt, const PredictionModeIn* pm, divans_lit_config& cfg);
+uint8_t speed_to_f8(int16_t v);           // probability/interface.rs:566-575
+
 // Builds the complete container for `input` exactly as the reference's literal-only internal compressor would
 // (src/divans_compressor.rs:276-426 + src/raw_to_cmd/mod.rs:105-181), `call_buffer` = size of the output buffer
 // the caller hands to each flush call (the Mux slicing depends on it, src/mux.rs:445-476).

@@ -95,13 +95,14 @@ __device__ __forceinline__ LdsView load_config_to_lds(uint8_t* lds, const LitBat
     uint8_t* p = lds + b.cache_bytes_per_wg;
     v.ctx = p;
     if (!CTXC) {
+        const uint32_t ctx_bytes = LIT_BLOB_CTXF + LIT_CTXF_BYTES * b.geom.n_btypes;
         const uint32_t* src = (const uint32_t*)(b.blob + LIT_BLOB_LUT1CLASS);
-        for (uint32_t i = threadIdx.x; i < LIT_BLOB_CTX_BYTES / 4; i += blockDim.x) ((uint32_t*)p)[i] = src[i];
-        p += LIT_BLOB_CTX_BYTES;
+        for (uint32_t i = threadIdx.x; i < ctx_bytes / 4; i += blockDim.x) ((uint32_t*)p)[i] = src[i];
+        p += ctx_bytes;
     }
     v.mix = p;
     if (MM < 0) {
-        const uint32_t* src = (const uint32_t*)(b.blob + LIT_BLOB_MIX);
+        const uint32_t* src = (const uint32_t*)(b.blob + b.geom.mix_off);
         for (uint32_t i = threadIdx.x; i < 8192 / 4; i += blockDim.x) ((uint32_t*)p)[i] = src[i];
     }
     __syncthreads();
@@ -109,12 +110,34 @@ __device__ __forceinline__ LdsView load_config_to_lds(uint8_t* lds, const LitBat
 }
 
 // Context of the next byte: literal.rs:87-117 with lut0 / lut1 / context map fused on the host into
-// LIT_BLOB_CTXF[prev][lut1 class of prev_prev]; `k1` (that class) is carried over from the previous byte.
+// LIT_BLOB_CTXF[block type][prev][lut1 class of prev_prev]; `ctab` = byte offset of the current block type's table,
+// `k1` (that class) is carried over from the previous byte.
 template <bool CTXC>
-__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds_ctx, uint32_t prev, uint32_t k1) {
+__device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds_ctx, uint32_t ctab, uint32_t prev, uint32_t k1) {
     if (CTXC) return (uint32_t)g.ctx_const;
-    return lds_ctx[LIT_BLOB_CTXF + (prev << 3) + k1];
+    return lds_ctx[ctab + (prev << 3) + k1];
 }
+
+// Walks a stream's segment list (general streams: one segment per Literal command).  `left` = bytes of the current
+// segment still to code; advance() is called when it reaches zero and installs the next segment's context.
+struct SegCursor {
+    const LitSegment* segs; uint32_t idx, end, left;
+    __device__ __forceinline__ void advance(const LitGeometry& g, uint64_t& last8, uint32_t& ctab) {
+        while (left == 0u && idx < end) {
+            const u32x4 sg = *(const u32x4*)(segs + idx);
+            ++idx;
+            left = sg.x;
+            last8 = ((uint64_t)sg.w << 32) | sg.z;
+            uint32_t t = sg.y - g.bt_first;
+            t = t < g.n_btypes ? t : g.n_btypes - 1u;     // the host sizes the tables from the block types it saw; stay inside them
+            ctab = LIT_BLOB_CTXF + t * LIT_CTXF_BYTES;
+        }
+    }
+    __device__ __forceinline__ void start(const LitBatch& b, uint32_t s, uint64_t& last8, uint32_t& ctab) {
+        segs = b.segs; idx = b.seg_begin[s]; end = b.seg_begin[s + 1]; left = 0u;
+        advance(b.geom, last8, ctab);
+    }
+};
 
 }  // namespace divans_hip
 #endif

@@ -11,10 +11,11 @@ constexpr int RANS_THREADS = 64;    // one wave, one lane per stream
 
 // per-batch constant tables staged in LDS by every workgroup
 constexpr uint32_t LIT_BLOB_LUT1CLASS = 0;  // class (<8) of literal_lut1[b]: index of its value among the distinct lut1 values
-constexpr uint32_t LIT_BLOB_CTXF = 256;     // [prev][class]: literal_context_map[(lut0[prev] | lut1 value) + 64*btype], literal.rs:97-115
-constexpr uint32_t LIT_BLOB_MIX = 256 + 2048;  // mixing_mask[8192]
-constexpr uint32_t LIT_BLOB_CTX_BYTES = 256 + 2048;
-constexpr uint32_t LIT_BLOB_BYTES = 256 + 2048 + 8192;
+constexpr uint32_t LIT_BLOB_CTXF = 256;     // [block type][prev][class]: literal_context_map[(lut0[prev] | lut1 value) + 64*btype], literal.rs:97-115
+constexpr uint32_t LIT_CTXF_BYTES = 2048;   // one block type's table; n_btypes of them follow each other
+constexpr uint32_t LIT_MAX_BTYPES = 8;      // block types one codec keeps context tables for (LDS: 2 KB each)
+// then mixing_mask[8192] at LitGeometry::mix_off = 256 + 2048 * n_btypes
+constexpr uint32_t LIT_BLOB_MAX_BYTES = 256 + LIT_CTXF_BYTES * LIT_MAX_BTYPES + 8192;
 
 // How the (3 x 256 x 256) prior cube of LiteralNibblePriors (codec/priors.rs:35-37) is compacted for
 // one configuration: only the planes / context columns the configuration can reach are materialised.
@@ -28,7 +29,15 @@ struct LitGeometry {
     int32_t mm_uniform;   // the mixing value when every reachable entry is equal, else -1
     int32_t ctx_const;    // the context when the context map is constant, else -1
     int32_t inc0, lim0, inc1, lim1, inc2, lim2, inc3, lim3;  // literal_adaptation Speeds (scalars: no dynamic indexing of kernargs)
+    uint32_t bt_first, n_btypes;   // context tables exist for literal block types [bt_first, bt_first + n_btypes)
+    uint32_t mix_off;              // byte offset of mixing_mask inside the configuration blob
 };
+
+// One Literal command of a general stream (codec/mod.rs:711-792): `len` literal bytes coded with the literal block type
+// `btype` (BlockSwitchLiteral, codec/interface.rs:289-292) after last_8_literals has been reloaded from the ring buffer
+// (the 8 output bytes before the command, newest in bits 56..63; codec/mod.rs:771-783).  Priors, Weights and the rANS
+// coder run on across segments: a stream's literals are ONE LIT_CODER byte stream.
+struct LitSegment { uint32_t len, btype, last8_lo, last8_hi; };
 
 struct LitBatch {
     const uint8_t* blob;        // LIT_BLOB_BYTES of configuration tables
@@ -43,6 +52,8 @@ struct LitBatch {
     uint32_t cache_rows_low;    // same for low-nibble rows (ignored when cache_unified)
     uint32_t cache_mode;        // 0 none, 1 unified (cache_rows_high rows serve both tables), 2 high-nibble rows only, 3 separate high / low
     uint32_t cache_bytes_per_wg;  // 16 * (rows_high + rows_low) * (32 + 2)
+    const uint32_t* seg_begin;  // [n_streams + 1] first segment of every stream in `segs`, or null: each stream is one segment
+    const LitSegment* segs;     //   with zero context and the block type the tables were built for
     uint32_t* status;           // device word: bit 0 = encoder saw an invalid (start,freq), bit 1 = decoder integrity check failed
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits

@@ -264,7 +264,7 @@ __device__ __forceinline__ uint32_t model_finish(const LitGeometry& g, const Tab
     return packed;
 }
 
-template <int MM, bool CTXC, bool MIX, int CACHE>
+template <int MM, bool CTXC, bool MIX, int CACHE, bool SEG>
 __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
@@ -280,18 +280,21 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
         init_table(tb, g.total_rows, li);
         Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};  // model_weights[1]=high, [0]=low (literal.rs:230)
         uint64_t last8 = 0;
-        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];   // lut1 class of prev_prev = 0
+        uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
+        SegCursor sc;
+        if (SEG) sc.start(b, s, last8, ctab);
+        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS + (uint32_t)((last8 >> 48) & 0xffu)];   // lut1 class of prev_prev
         // each lane holds one literal byte of the current and of the next 16-byte window (coalesced reads)
         uint32_t mine = ((uint32_t)li < len) ? in[li] : 0u;
         uint32_t nxt = (16u + li < len) ? in[16u + li] : 0u;
         // Non-mixing path: every symbol is known, so each row is requested one nibble ahead (right after the previous
         // row of the SAME table has been stored) and the model math of one nibble runs under the fetch of the next.
         uint32_t cur = (uint32_t)row_gather((int)mine, rbase, 0);
-        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, (uint32_t)(last8 >> 56), k1);
         FetchedRow rowH = {}, rowL = {};
         if (!MIX) {
-            rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
-            rowL = fetch_row<false, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, cur >> 4);
+            rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);
+            rowL = fetch_row<false, MM, CACHE>(g, lv, tb, ctx_cur, last8, cur >> 4);
         }
         for (uint32_t base = 0; base < len; base += 16) {
             const uint32_t cnt = len - base < 16u ? len - base : 16u;
@@ -300,22 +303,28 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
                 if (MIX) {
                     const uint32_t byte = (uint32_t)row_gather((int)mine, rbase, (int)k);
                     const uint32_t prev = (uint32_t)(last8 >> 56);
-                    const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
+                    const uint32_t ctx = context_of<CTXC>(g, lv.ctx, ctab, prev, k1);
                     if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                     const uint32_t hi = byte >> 4, lo = byte & 15u;
                     const uint32_t ph = model_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, (int)hi, wh);
                     const uint32_t pl = model_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, (int)lo, wl);
                     last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                    if (SEG) {   // the next Literal command starts from the ring buffer's last 8 bytes and its own block type
+                        if (--sc.left == 0u) {
+                            sc.advance(g, last8, ctab);
+                            if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + (uint32_t)((last8 >> 48) & 0xffu)];
+                        }
+                    }
                     pend_a = (uint32_t)li == k ? ph : pend_a;
                     pend_b = (uint32_t)li == k ? pl : pend_b;
                 } else {
                     const uint32_t byte = cur;
                     const uint32_t nb = (uint32_t)row_gather((int)(k + 1u < 16u ? mine : nxt), rbase, (int)((k + 1u) & 15u));
                     const uint32_t ph = model_finish<CACHE>(g, tb, li, rbase, rowH, (int)(byte >> 4));
-                    const uint32_t prev = (uint32_t)(last8 >> 56);
-                    if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                     last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-                    ctx_cur = context_of<CTXC>(g, lv.ctx, byte, k1);
+                    if (SEG) { if (--sc.left == 0u) sc.advance(g, last8, ctab); }
+                    if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + (uint32_t)((last8 >> 48) & 0xffu)];
+                    ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, (uint32_t)(last8 >> 56), k1);
                     rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);           // next byte's high row
                     const uint32_t pl = model_finish<CACHE>(g, tb, li, rbase, rowL, (int)(byte & 15u));
                     rowL = fetch_row<false, MM, CACHE>(g, lv, tb, ctx_cur, last8, nb >> 4);     // next byte's low row
@@ -577,7 +586,7 @@ __device__ __forceinline__ void finish_nibble(const LitGeometry& g, const Table<
     if (CACHE != 0 || !f.is_default) tb.store(f.ref, st);
 }
 
-template <int MM, bool CTXC, bool MIX, int CACHE>
+template <int MM, bool CTXC, bool MIX, int CACHE, bool SEG>
 __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
@@ -596,12 +605,15 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
         init_table(tb, g.total_rows, li);
         Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};
         uint64_t last8 = 0;
-        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];
+        uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
+        SegCursor sc;
+        if (SEG) sc.start(b, s, last8, ctab);
+        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS + (uint32_t)((last8 >> 48) & 0xffu)];
         uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
         bool corrupt = false;
-        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, (uint32_t)(last8 >> 56), k1);
         FetchedRow rowH = {};
-        if (!MIX) rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
+        if (!MIX) rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);
         for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
             // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
             {
@@ -616,7 +628,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                 for (uint32_t k = 0; k < cnt; ++k) {
                     if (MIX) {
                         const uint32_t prev = (uint32_t)(last8 >> 56);
-                        const uint32_t ctx = context_of<CTXC>(g, lv.ctx, prev, k1);
+                        const uint32_t ctx = context_of<CTXC>(g, lv.ctx, ctab, prev, k1);
                         if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                         // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
                         if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
@@ -625,6 +637,12 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                         const uint32_t lo = decode_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, SB, wl);
                         const uint32_t byte = (hi << 4) | lo;
                         last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+                        if (SEG) {
+                            if (--sc.left == 0u) {
+                                sc.advance(g, last8, ctab);
+                                if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + (uint32_t)((last8 >> 48) & 0xffu)];
+                            }
+                        }
                         outb = (uint32_t)li == k ? byte : outb;
                     } else {
                         // rowH (this byte's high-nibble row) was requested while the previous byte was being finished
@@ -637,10 +655,10 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                         const int cvl = rowL.is_default ? 4 * (li + 1) : rowL.value;
                         const uint32_t lo = (uint32_t)search_symbol(cvl, (uint32_t)SB & 0x7fffu, rbase);
                         const uint32_t byte = (hi << 4) | lo;
-                        const uint32_t prev = (uint32_t)(last8 >> 56);
-                        if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                         last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-                        ctx_cur = context_of<CTXC>(g, lv.ctx, byte, k1);
+                        if (SEG) { if (--sc.left == 0u) sc.advance(g, last8, ctab); }
+                        if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + (uint32_t)((last8 >> 48) & 0xffu)];
+                        ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, (uint32_t)(last8 >> 56), k1);
                         rowH = fetch_row<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);   // next byte's row (harmless past the end)
                         finish_nibble<CACHE>(g, tb, li, rbase, rowL, cvl, (int)lo, SB);
                         outb = (uint32_t)li == k ? byte : outb;
@@ -727,24 +745,25 @@ __global__ void selftest_division_kernel(unsigned long long* mismatches) {
 typedef void (*LitKernel)(const LitBatch);
 
 #define LIT_PICK(KERNEL)                                                                                     \
-    template <int CACHE>                                                                                     \
+    template <int CACHE, bool SEG>                                                                           \
     static LitKernel pick_##KERNEL(int mm, bool ctxc, bool mix) {                                            \
         const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 4 + (ctxc ? 2 : 0) + (mix ? 1 : 0);              \
         switch (key) {                                                                                       \
-        case 0: return KERNEL<-1, false, false, CACHE>; case 1: return KERNEL<-1, false, true, CACHE>;       \
-        case 2: return KERNEL<-1, true, false, CACHE>;  case 3: return KERNEL<-1, true, true, CACHE>;        \
-        case 4: return KERNEL<0, false, false, CACHE>;  case 5: return KERNEL<0, false, true, CACHE>;        \
-        case 6: return KERNEL<0, true, false, CACHE>;   case 7: return KERNEL<0, true, true, CACHE>;         \
-        case 8: return KERNEL<4, false, false, CACHE>;  case 9: return KERNEL<4, false, true, CACHE>;        \
-        case 10: return KERNEL<4, true, false, CACHE>;  default: return KERNEL<4, true, true, CACHE>;        \
+        case 0: return KERNEL<-1, false, false, CACHE, SEG>; case 1: return KERNEL<-1, false, true, CACHE, SEG>;   \
+        case 2: return KERNEL<-1, true, false, CACHE, SEG>;  case 3: return KERNEL<-1, true, true, CACHE, SEG>;    \
+        case 4: return KERNEL<0, false, false, CACHE, SEG>;  case 5: return KERNEL<0, false, true, CACHE, SEG>;    \
+        case 6: return KERNEL<0, true, false, CACHE, SEG>;   case 7: return KERNEL<0, true, true, CACHE, SEG>;     \
+        case 8: return KERNEL<4, false, false, CACHE, SEG>;  case 9: return KERNEL<4, false, true, CACHE, SEG>;    \
+        case 10: return KERNEL<4, true, false, CACHE, SEG>;  default: return KERNEL<4, true, true, CACHE, SEG>;    \
         }                                                                                                    \
     }                                                                                                        \
-    static LitKernel pick_mode_##KERNEL(int cache_mode, int mm, bool ctxc, bool mix) {                       \
+    static LitKernel pick_mode_##KERNEL(int cache_mode, bool seg, int mm, bool ctxc, bool mix) {             \
+        if (seg) return pick_##KERNEL<2, true>(mm, ctxc, mix);   /* segment lists: built for the default cache organisation only */ \
         switch (cache_mode) {                                                                                \
-        case 1: return pick_##KERNEL<1>(mm, ctxc, mix);                                                      \
-        case 2: return pick_##KERNEL<2>(mm, ctxc, mix);                                                      \
-        case 3: return pick_##KERNEL<3>(mm, ctxc, mix);                                                      \
-        default: return pick_##KERNEL<0>(mm, ctxc, mix);                                                     \
+        case 1: return pick_##KERNEL<1, false>(mm, ctxc, mix);                                               \
+        case 2: return pick_##KERNEL<2, false>(mm, ctxc, mix);                                               \
+        case 3: return pick_##KERNEL<3, false>(mm, ctxc, mix);                                               \
+        default: return pick_##KERNEL<0, false>(mm, ctxc, mix);                                              \
         }                                                                                                    \
     }
 LIT_PICK(lit_model_encode_kernel)
@@ -755,7 +774,7 @@ static int effective_mm(int mm) { return (mm == 0 || mm == 4) ? mm : -1; }
 
 uint32_t lit_lds_bytes(const LitBatch& b) {
     uint32_t bytes = b.cache_bytes_per_wg;
-    if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTX_BYTES;
+    if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTXF + LIT_CTXF_BYTES * b.geom.n_btypes;
     if (effective_mm(b.geom.mm_uniform) < 0) bytes += 8192u;
     return bytes;
 }
@@ -763,7 +782,8 @@ uint32_t lit_lds_bytes(const LitBatch& b) {
 hipError_t launch_model_encode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
     const LitBatch& b = b_in;
     const int mm = effective_mm(b.geom.mm_uniform);
-    LitKernel k = pick_mode_lit_model_encode_kernel((int)b.cache_mode, mm, b.geom.ctx_const >= 0, mix);
+    if (b.segs && b.cache_mode != 2u) return hipErrorInvalidValue;
+    LitKernel k = pick_mode_lit_model_encode_kernel((int)b.cache_mode, b.segs != nullptr, mm, b.geom.ctx_const >= 0, mix);
     const uint32_t lds = lit_lds_bytes(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);
@@ -784,7 +804,8 @@ hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
 hipError_t launch_decode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
     const LitBatch& b = b_in;
     const int mm = effective_mm(b.geom.mm_uniform);
-    LitKernel k = pick_mode_lit_decode_kernel((int)b.cache_mode, mm, b.geom.ctx_const >= 0, mix);
+    if (b.segs && b.cache_mode != 2u) return hipErrorInvalidValue;
+    LitKernel k = pick_mode_lit_decode_kernel((int)b.cache_mode, b.segs != nullptr, mm, b.geom.ctx_const >= 0, mix);
     const uint32_t lds = lit_lds_bytes(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_p8_kernel(const 
         uint32_t mine = ((uint32_t)j < len) ? in[j] : 0u;
         uint32_t nxt = (8u + j < len) ? in[8u + j] : 0u;
         uint32_t cur = (uint32_t)__builtin_amdgcn_ds_bpermute(sbase << 2, (int)mine);
-        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, LIT_BLOB_CTXF, 0u, k1);
         Fetched8 rowH = p8_fetch<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
         Fetched8 rowL = p8_fetch<false, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, cur >> 4);
         for (uint32_t base = 0; base < len; base += 8) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_p8_kernel(const 
                 const uint32_t prev = (uint32_t)(last8 >> 56);
                 if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                 last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-                ctx_cur = context_of<CTXC>(g, lv.ctx, byte, k1);
+                ctx_cur = context_of<CTXC>(g, lv.ctx, LIT_BLOB_CTXF, byte, k1);
                 rowH = p8_fetch<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);
                 const uint32_t pl = p8_model_finish<false, CACHE>(g, tb, j, sbase, rowL, (int)(byte & 15u));
                 rowL = p8_fetch<false, MM, CACHE>(g, lv, tb, ctx_cur, last8, nb >> 4);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_p8_kernel(const LitBat
         uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS];
         uint64_t SA = 0, SB = 0;
         bool corrupt = false;
-        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, 0u, k1);
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, LIT_BLOB_CTXF, 0u, k1);
         Fetched8 rowH = p8_fetch<true, MM, CACHE>(g, lv, tb, ctx_cur, 0ull, 0u);
         for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
             {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_p8_kernel(const LitBat
                     const uint32_t prev = (uint32_t)(last8 >> 56);
                     if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                     last8 = (last8 >> 8) | ((uint64_t)byte << 56);
-                    ctx_cur = context_of<CTXC>(g, lv.ctx, byte, k1);
+                    ctx_cur = context_of<CTXC>(g, lv.ctx, LIT_BLOB_CTXF, byte, k1);
                     rowH = p8_fetch<true, MM, CACHE>(g, lv, tb, ctx_cur, last8, 0u);
                     p8_finish_nibble<false, CACHE>(g, tb, j, sbase, rowL, cvl, mxl, (int)lo, SB);
                     outb = (uint32_t)j == k ? byte : outb;
@@ -318,7 +318,7 @@ static int p8_effective_mm(int mm) { return (mm == 0 || mm == 4) ? mm : -1; }
 
 uint32_t lit_lds_bytes_p8(const LitBatch& b) {
     uint32_t bytes = b.cache_mode ? P8_GROUPS * b.cache_rows_high * 34u : 0u;
-    if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTX_BYTES;
+    if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTXF + LIT_CTXF_BYTES * b.geom.n_btypes;
     if (p8_effective_mm(b.geom.mm_uniform) < 0) bytes += 8192u;
     return bytes;
 }

@@ -89,6 +89,29 @@ int divans_gpu_lit_decode_batch(divans_gpu_codec *c, const uint8_t *d_in, const 
                                 const uint32_t *d_in_sizes, uint32_t n_streams, uint8_t *d_out,
                                 const uint64_t *d_out_offsets, const uint32_t *d_out_sizes, uint32_t stream_len);
 
+/* ---- general streams: literals of one stream split into segments ------------------------------------------------
+ * In a stream with Copy / Dict commands the literal coder's 8-byte context (last_8_literals) is reloaded from the ring
+ * buffer after every command (src/codec/mod.rs:771-783) and BlockSwitchLiteral commands change the literal block type
+ * between Literal commands (src/codec/interface.rs:289-292), while the priors, the mixing Weights and the LIT rANS coder
+ * run on: all literal bytes of the stream are ONE LIT_CODER byte stream.  One segment = one Literal command. */
+typedef struct divans_lit_segment {
+    uint32_t len;      /* literal bytes of this command (> 0) */
+    uint32_t btype;    /* literal block type in force (< the count given to divans_gpu_codec_set_block_types) */
+    uint64_t last8;    /* the 8 output bytes before the command, oldest in bits 0..7, newest in bits 56..63 */
+} divans_lit_segment;
+/* context tables for literal block types 0 .. n_btypes-1 (1..8) instead of the single divans_lit_config::btype */
+int divans_gpu_codec_set_block_types(divans_gpu_codec *c, uint32_t n_btypes);
+/* As divans_gpu_lit_encode_batch / _decode_batch; stream i's literal bytes (in command order, concatenated) are split
+ * by the segments d_segs[d_seg_begin[i] .. d_seg_begin[i+1]) (device arrays; d_seg_begin has n_streams + 1 entries). */
+int divans_gpu_lit_encode_segments_batch(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
+                                         const uint32_t *d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                                         const uint32_t *d_seg_begin, const divans_lit_segment *d_segs,
+                                         uint8_t *d_out, uint64_t out_slot, uint64_t *d_out_offsets, uint32_t *d_out_sizes);
+int divans_gpu_lit_decode_segments_batch(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
+                                         const uint32_t *d_in_sizes, uint32_t n_streams,
+                                         const uint32_t *d_seg_begin, const divans_lit_segment *d_segs, uint8_t *d_out,
+                                         const uint64_t *d_out_offsets, const uint32_t *d_out_sizes, uint32_t stream_len);
+
 /* Status of the device-pointer batch calls (they are asynchronous and return before the kernels ran).  Waits for the
  * codec's stream, stores the bits set since the previous call in *status and clears them:
  *   DIVANS_GPU_STATUS_BAD_MODEL  (1): an encode pass met a (start,freq) outside 15 bits / freq == 0 -- a CDF state the

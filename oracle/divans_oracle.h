@@ -143,6 +143,12 @@ size_t orc_lit_stream_encode_trace(const orc_lit_config *cfg, const uint8_t *in,
 int orc_lit_batch_roundtrip(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len,
                             int nthreads, double *enc_seconds, double *dec_seconds, uint64_t *coded_bytes);
 
+/* literals of a general stream: one segment per Literal command (block type, reloaded last_8_literals) */
+size_t orc_lit_segments_encode(const orc_lit_config *cfg, const uint8_t *lit, size_t n, const uint32_t *seg_len,
+                               const uint32_t *seg_btype, const uint64_t *seg_last8, size_t nseg, uint8_t *out, size_t cap);
+int orc_lit_segments_decode(const orc_lit_config *cfg, const uint8_t *in, size_t in_len, const uint32_t *seg_len,
+                            const uint32_t *seg_btype, const uint64_t *seg_last8, size_t nseg, uint8_t *out, size_t n);
+
 /* CPU baseline proper: every worker allocates its coder state, ANS buffers and output slots BEFORE a start barrier;
  * all workers then encode their streams (stream i -> worker i % nthreads), meet at a second barrier and decode them.
  * enc_wall / dec_wall = wall clock from the barrier release to the last worker finishing that direction. */
@@ -187,6 +193,7 @@ typedef struct {
 size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command *cmds, size_t n_cmds, uint8_t *out, size_t cap);
 size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, size_t n, uint8_t *out, size_t cap);
 int orc_stream_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+int orc_lit_config_from_prediction_mode(const orc_stream_options *o, const orc_prediction_mode *pm, uint8_t btype, orc_lit_config *cfg);
 int orc_mux_demux(const uint8_t *in, size_t n, uint8_t *s0, size_t *n0, uint8_t *s1, size_t *n1, size_t *consumed);
 
 /* ---- CRC-32C, src/codec/crc32.rs ---- */

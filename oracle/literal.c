@@ -499,3 +499,50 @@ int orc_lit_batch_bench(const orc_lit_config *cfg, const uint8_t *in, size_t n_s
     free(coded); free(coded_len); free(th); free(args);
     return bad ? -1 : 0;
 }
+
+
+/* ---- general streams: the literals of a stream with Copy / Dict commands in between (codec/mod.rs:711-792).
+ * One segment per Literal command: the block type in force (obs_literal_block_switch, codec/interface.rs:289-292) and
+ * last_8_literals as reloaded from the ring buffer after the previous command (codec/mod.rs:771-783).  Priors, Weights
+ * and the LIT coder persist across segments. */
+size_t orc_lit_segments_encode(const orc_lit_config *cfg, const uint8_t *lit, size_t n, const uint32_t *seg_len,
+                               const uint32_t *seg_btype, const uint64_t *seg_last8, size_t nseg, uint8_t *out, size_t cap) {
+    orc_lit_config *c = (orc_lit_config *)malloc(sizeof(*c));
+    memcpy(c, cfg, sizeof(*c));
+    orc_lit_state *s = orc_lit_state_new(c);
+    orc_ans_encoder enc;
+    orc_ans_encoder_init(&enc);
+    size_t pos = 0;
+    for (size_t k = 0; k < nseg && pos + seg_len[k] <= n; ++k) {
+        if (c->btype != (uint8_t)seg_btype[k]) { c->btype = (uint8_t)seg_btype[k]; orc_lit_state_reconfigure(s, c); }
+        orc_lit_set_last8(s, seg_last8[k]);
+        orc_lit_encode_bytes(s, &enc, lit + pos, seg_len[k]);
+        pos += seg_len[k];
+    }
+    orc_ans_flush_chunk(&enc);
+    size_t ret = enc.out.len;
+    if (enc.failed || ret > cap || pos != n) ret = (size_t)-1;
+    else memcpy(out, enc.out.data, ret);
+    orc_ans_encoder_free(&enc);
+    orc_lit_state_free(s); free(c);
+    return ret;
+}
+
+int orc_lit_segments_decode(const orc_lit_config *cfg, const uint8_t *in, size_t in_len, const uint32_t *seg_len,
+                            const uint32_t *seg_btype, const uint64_t *seg_last8, size_t nseg, uint8_t *out, size_t n) {
+    orc_lit_config *c = (orc_lit_config *)malloc(sizeof(*c));
+    memcpy(c, cfg, sizeof(*c));
+    orc_lit_state *s = orc_lit_state_new(c);
+    orc_ans_decoder dec;
+    orc_ans_decoder_init(&dec, in, in_len);
+    size_t pos = 0;
+    for (size_t k = 0; k < nseg && pos + seg_len[k] <= n; ++k) {
+        if (c->btype != (uint8_t)seg_btype[k]) { c->btype = (uint8_t)seg_btype[k]; orc_lit_state_reconfigure(s, c); }
+        orc_lit_set_last8(s, seg_last8[k]);
+        orc_lit_decode_bytes(s, &dec, out + pos, seg_len[k]);
+        pos += seg_len[k];
+    }
+    int rc = (dec.starved || pos != n) ? -1 : 0;
+    orc_lit_state_free(s); free(c);
+    return rc;
+}

@@ -93,6 +93,14 @@ def lib(native=False):
     L.orc_lit_batch_roundtrip.argtypes = [ctypes.POINTER(LitConfig), ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+    L.orc_lit_segments_encode.restype = ctypes.c_size_t
+    L.orc_lit_segments_encode.argtypes = [ctypes.POINTER(LitConfig), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    L.orc_lit_segments_decode.restype = ctypes.c_int
+    L.orc_lit_segments_decode.argtypes = [ctypes.POINTER(LitConfig), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    L.orc_lit_config_from_prediction_mode.restype = ctypes.c_int
+    L.orc_lit_config_from_prediction_mode.argtypes = [ctypes.POINTER(StreamOptions), ctypes.c_void_p, ctypes.c_uint8, ctypes.POINTER(LitConfig)]
     L.orc_lit_batch_bench.restype = ctypes.c_int
     L.orc_lit_batch_bench.argtypes = L.orc_lit_batch_roundtrip.argtypes
     L.orc_cdf_default.argtypes = [ctypes.POINTER(Cdf16)]
@@ -217,3 +225,38 @@ def stream_decompress(coded, max_out):
     if rc != 0:
         raise RuntimeError(f"oracle stream decompress failed rc={rc}")
     return out[:n.value].copy()
+
+
+def lit_segments_encode(cfg, lit, seg_len, seg_btype, seg_last8):
+    """LIT-coder bytes of a general stream: literal bytes `lit` split into Literal commands (lengths, block types, reloaded last_8_literals)."""
+    lit = np.ascontiguousarray(lit, dtype=np.uint8)
+    sl = np.ascontiguousarray(seg_len, dtype=np.uint32); sb = np.ascontiguousarray(seg_btype, dtype=np.uint32)
+    s8 = np.ascontiguousarray(seg_last8, dtype=np.uint64)
+    cap = 2 * lit.size + 64
+    out = np.empty(cap, dtype=np.uint8)
+    r = lib().orc_lit_segments_encode(ctypes.byref(cfg), lit.ctypes.data, lit.size, sl.ctypes.data, sb.ctypes.data, s8.ctypes.data, sl.size,
+                                      out.ctypes.data, cap)
+    if r == ctypes.c_size_t(-1).value:
+        raise RuntimeError("oracle segment encode failed")
+    return out[:r].copy()
+
+
+def lit_segments_decode(cfg, coded, n, seg_len, seg_btype, seg_last8):
+    coded = np.ascontiguousarray(coded, dtype=np.uint8)
+    sl = np.ascontiguousarray(seg_len, dtype=np.uint32); sb = np.ascontiguousarray(seg_btype, dtype=np.uint32)
+    s8 = np.ascontiguousarray(seg_last8, dtype=np.uint64)
+    out = np.empty(max(n, 1), dtype=np.uint8)
+    r = lib().orc_lit_segments_decode(ctypes.byref(cfg), coded.ctypes.data, coded.size, sl.ctypes.data, sb.ctypes.data, s8.ctypes.data, sl.size,
+                                      out.ctypes.data, n)
+    if r != 0:
+        raise RuntimeError("oracle segment decode failed")
+    return out[:n]
+
+
+def lit_config_from_prediction_mode(options, pm, btype=0):
+    """LiteralBookKeeping after the encoder coded PredictionMode `pm` (a PredictionMode struct or None) under `options`."""
+    cfg = LitConfig()
+    r = lib().orc_lit_config_from_prediction_mode(ctypes.byref(options), ctypes.byref(pm) if pm is not None else None, btype, ctypes.byref(cfg))
+    if r != 0:
+        raise RuntimeError("oracle could not code the PredictionMode command")
+    return cfg

@@ -670,6 +670,26 @@ size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, s
 /* ------------------------------------------------------------------ decoder */
 static void no_drain(void *p) { (void)p; }
 
+/* What LiteralBookKeeping holds after the encoder has coded `pm` under options `o` (obs_prediction_mode_context_map,
+ * codec/interface.rs:293-319); pm == NULL: the constructor defaults (codec/interface.rs:244-262). */
+int orc_lit_config_from_prediction_mode(const orc_stream_options *o, const orc_prediction_mode *pm, uint8_t btype, orc_lit_config *cfg) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->btype = btype;
+    for (int i = 0; i < 4; ++i) cfg->literal_adaptation[i] = SP_MUD;
+    if (!pm) return 0;
+    cmd_state *c = (cmd_state *)malloc(sizeof(cmd_state));
+    cmd_state_init(c, o);
+    orc_ans_encoder enc;
+    orc_ans_encoder_init(&enc);
+    cmd_coder cc = {&enc, NULL};
+    code_command_type(c, &cc, no_drain, NULL, 7);
+    orc_prediction_mode_result r;
+    int rc = code_prediction_mode(c, &cc, no_drain, NULL, pm, &r);
+    if (!rc) lit_config_from_pm(cfg, &r, btype, r.mixing_math);
+    orc_ans_encoder_free(&enc); free(c);
+    return rc;
+}
+
 int orc_stream_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
     if (n < 16 + 3 + 8) return -1;
     if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f) return -2;  /* divans_decompressor.rs:38-52 */

@@ -97,6 +97,12 @@ def main():
     mix = [int(x) for x in pred[k + 1:m]]
     assert len(lmap) == 128 and len(mix) == 8192 and all(x == "0" for x in pred[m:] if x.isdigit())
     np.array(lmap + mix, dtype=np.uint8).tofile(f"{OUT}/alice29_priors_prediction.bin")
+    # 7. the textual command IRs of testdata/ (captured brotli runs; what src/bin/integration_test.rs:76-108 recodes back to the
+    #    raw files, and what BASELINE configs[0](ii) feeds the codec) and the one raw file not already in the corpora
+    for name in ("alice29", "alice29-q11", "alice29-priors", "asyoulik", "random_then_unicode", "ends_with_truncated_dictionary"):
+        with lzma.open(f"{OUT}/ir_{name}.ir.xz", "wb", preset=9 | lzma.PRESET_EXTREME) as f:
+            f.write(open(f"{REF}/testdata/{name}.ir", "rb").read())
+    np.frombuffer(open(f"{REF}/testdata/ends_with_truncated_dictionary", "rb").read(), dtype=np.uint8).tofile(f"{OUT}/ends_with_truncated_dictionary.bin")
     print("golden fixtures written to", OUT)
 
 

@@ -23,6 +23,13 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(da.exported_symbols())
     for sym in declared:
         assert hasattr(L, sym), sym
+    # the reference's per-stream ABI (c/divans/ffi.h) and the IR host layer
+    for header, expect in (("divans_ffi.h", None), ("divans_ir.h", set(da.exported_ir_symbols()))):
+        decl = _declared(header)
+        if expect is not None:
+            assert set(decl) == expect
+        for sym in decl:
+            assert hasattr(L, sym), (header, sym)
 
 
 def test_config_helpers_match_oracle_configs():
