@@ -447,7 +447,7 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
     b.sf = c->d_sf; b.status = c->d_status;
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
-    if (d_segs && (c->packed8 || b.cache_mode != 2u)) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache");
+    if (d_segs && (c->packed8 || (b.cache_mode != 2u && b.cache_mode != 0u))) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache or none");
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (c->packed8) HIP_TRY(launch_model_encode_p8(b, c->blocks, c->stream));
     else HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
@@ -556,7 +556,7 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes; b.status = c->d_status;
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
-    if (d_segs && (c->packed8 || b.cache_mode != 2u)) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache");
+    if (d_segs && (c->packed8 || (b.cache_mode != 2u && b.cache_mode != 0u))) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache or none");
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     if (c->packed8) HIP_TRY(launch_decode_p8(b, c->blocks, c->stream));
     else HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));

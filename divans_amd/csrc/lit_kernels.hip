@@ -200,9 +200,26 @@ __device__ __forceinline__ Table<CACHE> make_table(const LitBatch& b, uint8_t* l
 // ---------------------------------------------------------------------------------------------
 // Encode, pass 1: adaptive model.  bytes -> (start | freq << 16) per nibble.
 // ---------------------------------------------------------------------------------------------
+// The Weights update (weights.rs:23-38) is per-stream scalar work.  Both nibbles of a byte own a Weights object
+// (model_weights[1] high, [0] low, literal.rs:230) that is only read again one byte later, so the mixing paths hand the three
+// probabilities of each nibble back (`wfreqs` = cm freq | stride freq << 16, the mixed freq is in the returned pair) and the byte
+// loop runs ONE update for both: lanes 0..7 of the row carry the high nibble's Weights, lanes 8..15 the low nibble's.
+struct WeightsPair {
+    Weights w;   // lane-varying: high nibble's object in lanes 0..7, low nibble's in lanes 8..15
+    __device__ __forceinline__ void init() { w.w0 = 1; w.w1 = 1; w.norm = 1 << 14; }
+    __device__ __forceinline__ int norm_high() const { return row_bcast<0>(w.norm); }
+    __device__ __forceinline__ int norm_low() const { return row_bcast<8>(w.norm); }
+    __device__ __forceinline__ void update(int li, uint32_t freqs_h, uint32_t pmix_h, uint32_t freqs_l, uint32_t pmix_l) {
+        const bool hi = li < 8;
+        const uint32_t fr = hi ? freqs_h : freqs_l;
+        const uint32_t pm = hi ? pmix_h : pmix_l;
+        weights_update(w, (int)(short)(fr & 0xffffu), (int)(short)(fr >> 16), (int)(short)pm);
+    }
+};
+
 template <bool HIGH, int MM, bool MIX, int CACHE>
 __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb, int li, int rbase,
-                                                 uint32_t ctx, uint64_t last8, uint32_t hi_nib, int sym, Weights& w) {
+                                                 uint32_t ctx, uint64_t last8, uint32_t hi_nib, int sym, int mix_rate, uint32_t& wfreqs) {
     const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
     RowRef sref, cref;
     int st = tb.load(rs.stride_row, sref, HIGH);
@@ -210,7 +227,7 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
     if (MIX) {
         int cm = tb.load(rs.cm_row, cref, HIGH);
         int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
-        int p = average_rows(cm, st, cmax, smax, w.norm);
+        int p = average_rows(cm, st, cmax, smax, mix_rate);
         int pmax = row_bcast<15>(p);
         uint32_t dp = scaled_div(p, pmax, biased_rcp15(pmax));
         uint32_t dc = scaled_div(cm, cmax, biased_rcp15(cmax));
@@ -219,8 +236,7 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
         uint32_t sf = (uint32_t)(dpp + 1) | ((uint32_t)((int)dp - dpp - 1) << 16);
         uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
         packed = (uint32_t)row_gather((int)sf, rbase, sym);
-        uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
-        weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)(packed >> 16));
+        wfreqs = (uint32_t)row_gather((int)ff, rbase, sym);
         cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
         tb.store(cref, cm);
     } else {
@@ -278,7 +294,8 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
         const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
         uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
         init_table(tb, g.total_rows, li);
-        Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};  // model_weights[1]=high, [0]=low (literal.rs:230)
+        WeightsPair wp; wp.init();
+        int nh = 1 << 14, nl = 1 << 14;     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
         uint64_t last8 = 0;
         uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
         SegCursor sc;
@@ -306,8 +323,11 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
                     const uint32_t ctx = context_of<CTXC>(g, lv.ctx, ctab, prev, k1);
                     if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                     const uint32_t hi = byte >> 4, lo = byte & 15u;
-                    const uint32_t ph = model_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, (int)hi, wh);
-                    const uint32_t pl = model_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, (int)lo, wl);
+                    uint32_t fh = 0, fl = 0;
+                    const uint32_t ph = model_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, (int)hi, nh, fh);
+                    const uint32_t pl = model_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, (int)lo, nl, fl);
+                    wp.update(li, fh, ph >> 16, fl, pl >> 16);
+                    nh = wp.norm_high(); nl = wp.norm_low();
                     last8 = (last8 >> 8) | ((uint64_t)byte << 56);
                     if (SEG) {   // the next Literal command starts from the ring buffer's last 8 bytes and its own block type
                         if (--sc.left == 0u) {
@@ -517,7 +537,8 @@ struct WordWindow {
 
 template <bool HIGH, int MM, bool MIX, int CACHE>
 __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb, int li, int rbase,
-                                                  uint32_t ctx, uint64_t last8, uint32_t hi_nib, uint64_t& S, Weights& w) {
+                                                  uint32_t ctx, uint64_t last8, uint32_t hi_nib, uint64_t& S, int mix_rate,
+                                                  uint32_t& wfreqs, uint32_t& wpmix) {
     const RowSel rs = select_rows<HIGH, MM>(g, lv.mix, ctx, last8, hi_nib);
     RowRef sref, cref;
     int st = tb.load(rs.stride_row, sref, HIGH);
@@ -526,7 +547,7 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const Ld
     if (MIX) {
         cm = tb.load(rs.cm_row, cref, HIGH);
         cmax = row_bcast<15>(cm); smax = row_bcast<15>(st);
-        cv = average_rows(cm, st, cmax, smax, w.norm);
+        cv = average_rows(cm, st, cmax, smax, mix_rate);
     } else {
         cv = ((MM < 0 || MM == 2) && rs.is_default) ? 4 * (li + 1) : st;
     }
@@ -548,8 +569,8 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const Ld
         uint32_t ds = scaled_div(st, smax, biased_rcp15(smax));
         int dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
         uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
-        uint32_t freqs = (uint32_t)row_gather((int)ff, rbase, sym);
-        weights_update(w, (int)(short)(freqs & 0xffffu), (int)(short)(freqs >> 16), (int)(short)freq);
+        wfreqs = (uint32_t)row_gather((int)ff, rbase, sym);
+        wpmix = freq;
         cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
         tb.store(cref, cm);
     }
@@ -603,7 +624,8 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
         ww.nwords = b.in_sizes[s] >> 2;
         ww.start(li);
         init_table(tb, g.total_rows, li);
-        Weights wh = {1, 1, 1 << 14}, wl = {1, 1, 1 << 14};
+        WeightsPair wp; wp.init();
+        int nh = 1 << 14, nl = 1 << 14;     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
         uint64_t last8 = 0;
         uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
         SegCursor sc;
@@ -632,9 +654,12 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
                         if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + prev];
                         // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
                         if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li, rbase);
-                        const uint32_t hi = decode_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, SA, wh);
+                        uint32_t fh = 0, fl = 0, ph = 0, pl = 0;
+                        const uint32_t hi = decode_nibble<true, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, 0u, SA, nh, fh, ph);
                         if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li, rbase);
-                        const uint32_t lo = decode_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, SB, wl);
+                        const uint32_t lo = decode_nibble<false, MM, MIX, CACHE>(g, lv, tb, li, rbase, ctx, last8, hi, SB, nl, fl, pl);
+                        wp.update(li, fh, ph, fl, pl);
+                        nh = wp.norm_high(); nl = wp.norm_low();
                         const uint32_t byte = (hi << 4) | lo;
                         last8 = (last8 >> 8) | ((uint64_t)byte << 56);
                         if (SEG) {
@@ -758,7 +783,7 @@ typedef void (*LitKernel)(const LitBatch);
         }                                                                                                    \
     }                                                                                                        \
     static LitKernel pick_mode_##KERNEL(int cache_mode, bool seg, int mm, bool ctxc, bool mix) {             \
-        if (seg) return pick_##KERNEL<2, true>(mm, ctxc, mix);   /* segment lists: built for the default cache organisation only */ \
+        if (seg) return cache_mode == 2 ? pick_##KERNEL<2, true>(mm, ctxc, mix) : pick_##KERNEL<0, true>(mm, ctxc, mix);   /* segment lists: default cache organisation or none */ \
         switch (cache_mode) {                                                                                \
         case 1: return pick_##KERNEL<1, false>(mm, ctxc, mix);                                               \
         case 2: return pick_##KERNEL<2, false>(mm, ctxc, mix);                                               \
@@ -782,7 +807,7 @@ uint32_t lit_lds_bytes(const LitBatch& b) {
 hipError_t launch_model_encode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
     const LitBatch& b = b_in;
     const int mm = effective_mm(b.geom.mm_uniform);
-    if (b.segs && b.cache_mode != 2u) return hipErrorInvalidValue;
+    if (b.segs && b.cache_mode != 2u && b.cache_mode != 0u) return hipErrorInvalidValue;
     LitKernel k = pick_mode_lit_model_encode_kernel((int)b.cache_mode, b.segs != nullptr, mm, b.geom.ctx_const >= 0, mix);
     const uint32_t lds = lit_lds_bytes(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -804,7 +829,7 @@ hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
 hipError_t launch_decode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
     const LitBatch& b = b_in;
     const int mm = effective_mm(b.geom.mm_uniform);
-    if (b.segs && b.cache_mode != 2u) return hipErrorInvalidValue;
+    if (b.segs && b.cache_mode != 2u && b.cache_mode != 0u) return hipErrorInvalidValue;
     LitKernel k = pick_mode_lit_decode_kernel((int)b.cache_mode, b.segs != nullptr, mm, b.geom.ctx_const >= 0, mix);
     const uint32_t lds = lit_lds_bytes(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

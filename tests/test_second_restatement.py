@@ -1,0 +1,80 @@
+"""the C oracle against a second restatement of the same Rust (tests/ref_restatement.py, pure Python,
+written from the .rs files alone), nibble by nibble -- (symbol, start, freq) of every coded nibble, the LIT-coder bytes, and
+the decode direction -- on the golden corpus and on random configurations that reach every mixing value, prediction mode,
+block type, speed and the mixing / non-mixing paths."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+import ref_restatement as rr
+
+PALETTE = [(0, 1024), (2, 1024), (1, 128), (1, 16384), (2, 2048), (4, 1024), (8, 8192), (16, 48), (16, 8192), (32, 4096), (64, 16384),
+           (128, 256), (128, 16384), (512, 16384), (1664, 16384), (0x10, 0x2000)]      # probability/interface.rs:303-328
+
+
+def to_rr(cfg):
+    return dict(context_map=bytes(cfg.literal_context_map), mixing_mask=bytes(cfg.mixing_mask), prediction_mode=cfg.prediction_mode,
+                btype=cfg.btype, mixing_param=cfg.context_mixing, speeds=[(s.inc, s.lim) for s in cfg.literal_adaptation])
+
+
+def check(cfg, data):
+    coded, trace = po.lit_encode(cfg, data, trace=True)
+    got, gtrace = rr.encode_stream(to_rr(cfg), bytes(data))
+    tr = [tuple(int(v) for v in row) for row in trace]
+    assert gtrace == tr, next((i, a, b) for i, (a, b) in enumerate(zip(gtrace, tr)) if a != b)
+    assert got == coded.tobytes()
+    assert rr.decode_stream(to_rr(cfg), got, len(data)) == bytes(data)
+    assert (po.lit_decode(cfg, np.frombuffer(got, dtype=np.uint8), len(data)) == data).all()
+
+
+def test_benchmark_configs_on_corpus(corpus):
+    for cfg in (po.config_simple(), po.config_context_mixing()):
+        check(cfg, corpus[1000:1000 + 6000])
+        check(cfg, corpus[200000:200000 + 3000])
+
+
+def test_chunk_boundary(corpus):
+    """more than 65 536 symbols: the LIFO chunk flush, the 16-byte state reload and the a/b swap at the seam"""
+    data = np.concatenate([corpus[:30000], corpus[100000:103000]])      # 66 000 nibbles
+    check(po.config_simple(), data)
+
+
+def test_brotli_derived_configuration(corpus):
+    import workload
+    for btype in (0, 1):
+        for mixing in (0, 2):
+            cfg = workload.brotli_derived_config(po.LitConfig(), btype, mixing)
+            check(cfg, corpus[5000:5000 + 2500])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_configurations(seed, corpus):
+    rng = np.random.default_rng(1234 + seed)
+    for trial in range(40):
+        cfg = po.LitConfig()
+        nctx = int(rng.choice([1, 4, 64, 256]))
+        cmap = rng.integers(0, nctx, size=po.MAX_CMAP, dtype=np.uint8) if nctx > 1 else np.zeros(po.MAX_CMAP, np.uint8)
+        ctypes.memmove(cfg.literal_context_map, cmap.ctypes.data, cmap.size)
+        if rng.random() < 0.3:
+            mix = np.full(po.NUM_MIXING, int(rng.integers(0, 9)), dtype=np.uint8)
+        else:
+            mix = rng.integers(0, 9, size=po.NUM_MIXING, dtype=np.uint8)
+        ctypes.memmove(cfg.mixing_mask, mix.ctypes.data, mix.size)
+        cfg.prediction_mode = int(rng.integers(0, 4))
+        cfg.btype = int(rng.integers(0, 4))
+        cfg.context_mixing = int(rng.choice([0, 1, 2, 2, 5, 14]))
+        for i in range(4):
+            inc, lim = PALETTE[int(rng.integers(0, len(PALETTE)))]
+            cfg.literal_adaptation[i].inc = inc; cfg.literal_adaptation[i].lim = lim
+        n = int(rng.integers(1, 260))
+        kind = trial % 4
+        if kind == 0:
+            data = rng.integers(0, 256, size=n, dtype=np.uint8)
+        elif kind == 1:
+            data = np.full(n, int(rng.integers(0, 256)), dtype=np.uint8)
+        else:
+            o = int(rng.integers(0, corpus.size - n))
+            data = corpus[o:o + n].copy()
+        check(cfg, data)
