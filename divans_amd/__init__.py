@@ -110,6 +110,8 @@ def load_library():
     L.divans_gpu_lit_model_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
+    L.divans_gpu_selftest_cdf_ops.argtypes = [vp, vp, u32, vp]
+    L.divans_gpu_selftest_rans_pairs.argtypes = [vp, vp, u32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.divans_gpu_codec_set_block_types.argtypes = [vp, u32]
     L.divans_gpu_lit_encode_segments_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, vp, u64, vp, vp]
     L.divans_gpu_lit_decode_segments_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, u32]
@@ -140,6 +142,7 @@ def exported_symbols():
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
+        "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs",
     ]
 
 
@@ -299,6 +302,21 @@ class LiteralCodec:
         st = ctypes.c_uint32(0)
         _check(self._lib.divans_gpu_codec_status(self._h, ctypes.byref(st)), "divans_gpu_codec_status")
         return int(st.value)
+
+    def selftest_cdf_ops(self, ops):
+        """ops: (n, 4) uint32 script (include/divans_gpu.h) -> (n, 16) int32 records"""
+        ops = np.ascontiguousarray(ops, dtype=np.uint32).reshape(-1, 4)
+        out = np.zeros((ops.shape[0], 16), dtype=np.int32)
+        _check(self._lib.divans_gpu_selftest_cdf_ops(self._h, ops.ctypes.data, ops.shape[0], out.ctypes.data), "divans_gpu_selftest_cdf_ops")
+        return out
+
+    def selftest_rans_pairs(self, pairs):
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+        cap = encode_bound(pairs.size // 2) + 64
+        out = np.empty(cap, dtype=np.uint8); n = ctypes.c_size_t(0)
+        _check(self._lib.divans_gpu_selftest_rans_pairs(self._h, pairs.ctypes.data, pairs.size, out.ctypes.data, cap, ctypes.byref(n)),
+               "divans_gpu_selftest_rans_pairs")
+        return out[:n.value].copy()
 
     def selftest_division(self):
         m = ctypes.c_uint64(0)

@@ -626,6 +626,58 @@ extern "C" int divans_gpu_selftest_division(divans_gpu_codec* c, uint64_t* misma
     return 0;
 }
 
+// Test entry points: the device primitives in isolation (tests/test_gpu_reference_unit_tests.py ports the reference's
+// own unit tests onto them).
+extern "C" int divans_gpu_selftest_cdf_ops(divans_gpu_codec* c, const uint32_t* ops, uint32_t n_ops, int32_t* out) {
+    if (!c || !ops || !out || n_ops == 0) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t* d_ops = nullptr; int32_t* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_ops, (size_t)n_ops * 16u));
+    if (hipMalloc(&d_out, (size_t)n_ops * 64u) != hipSuccess) { (void)hipFree(d_ops); return fail(DIVANS_GPU_ENOMEM, "hipMalloc failed"); }
+    hipError_t e = hipMemcpyAsync(d_ops, ops, (size_t)n_ops * 16u, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_selftest_cdf_ops(d_ops, n_ops, d_out, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n_ops * 64u, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_ops); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(DIVANS_GPU_EHIP, hipGetErrorString(e));
+    return 0;
+}
+
+// The rANS pass alone on caller-supplied (start | freq << 16) pairs of ONE stream (n_pairs even, oldest first): what
+// ANSEncoder::put_start_freq + flush_chunk produce (ans.rs:287-378), chunk after chunk.
+extern "C" int divans_gpu_selftest_rans_pairs(divans_gpu_codec* c, const uint32_t* pairs, uint32_t n_pairs, uint8_t* out, size_t cap, size_t* out_len) {
+    if (!c || !pairs || !out || !out_len || (n_pairs & 1u)) return fail(DIVANS_GPU_EINVAL, "bad argument (the pair count must be even)");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t len = n_pairs / 2u;
+    const uint64_t slot = divans_gpu_lit_encode_bound(len);
+    uint32_t* d_sf = nullptr; uint8_t* d_out = nullptr; uint64_t* d_off = nullptr; uint32_t* d_sz = nullptr;
+    hipError_t e = hipMalloc(&d_sf, (size_t)n_pairs * 4u + 64u);
+    if (e == hipSuccess) e = hipMalloc(&d_out, slot + 64u);
+    if (e == hipSuccess) e = hipMalloc(&d_off, 8);
+    if (e == hipSuccess) e = hipMalloc(&d_sz, 4);
+    uint64_t off = 0; uint32_t sz = 0; uint32_t status = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sf, pairs, (size_t)n_pairs * 4u, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_status, 0, 4, c->stream);
+    if (e == hipSuccess) {
+        RansBatch r;
+        std::memset(&r, 0, sizeof(r));
+        r.sf = d_sf; r.n_streams = 1; r.stream_len = len; r.max_stream_len = len; r.in_sizes = nullptr;
+        r.out = d_out; r.out_slot = slot; r.out_offsets = d_off; r.out_sizes = d_sz; r.status = c->d_status;
+        e = launch_rans_encode(r, c->stream);   // scratch == null: the one-lane-per-stream kernel, any number of chunks
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&off, d_off, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&sz, d_sz, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&status, c->d_status, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && sz <= cap) e = hipMemcpy(out, d_out + off, sz, hipMemcpyDeviceToHost);
+    (void)hipFree(d_sf); (void)hipFree(d_out); (void)hipFree(d_off); (void)hipFree(d_sz);
+    if (e != hipSuccess) return fail(DIVANS_GPU_EHIP, hipGetErrorString(e));
+    if (status & LIT_STATUS_BAD_MODEL) { (void)hipMemsetAsync(c->d_status, 0, 4, c->stream); return fail(DIVANS_GPU_EINVAL, "invalid (start,freq) pair"); }
+    if (sz > cap) return fail(DIVANS_GPU_ECAP, "output buffer too small");
+    *out_len = sz;
+    return 0;
+}
+
 // ---- host-memory convenience wrappers ----------------------------------------------------------
 extern "C" int divans_gpu_lit_encode_host(divans_gpu_codec* c, const uint8_t* in, uint32_t stream_len, uint32_t n_streams,
                                           uint8_t* out_packed, size_t out_cap, uint64_t* out_offsets, uint32_t* out_sizes,

@@ -94,6 +94,7 @@ hipError_t launch_decode_p8(const LitBatch& b, uint32_t blocks, hipStream_t st);
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
                        uint64_t* dst_off, uint64_t* total, hipStream_t st);
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);
+hipError_t launch_selftest_cdf_ops(const uint32_t* d_ops, uint32_t n, int32_t* d_out, hipStream_t st);
 
 }  // namespace divans_hip
 #endif

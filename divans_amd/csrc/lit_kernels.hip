@@ -764,6 +764,41 @@ __global__ void selftest_division_kernel(unsigned long long* mismatches) {
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// The CDF / Weights primitives the coding kernels are built from, driven by a script of operations on two rows held
+// one entry per lane -- the GPU side of the reference's own CDF unit tests (probability/common_tests.rs:152-185
+// operation_test_helper compares two CDF implementations after every blend and at five mixing rates; here the second
+// implementation is the CPU restatement, compared on the host).  Every op writes one 16-entry record.
+__global__ __launch_bounds__(64) void cdf_ops_selftest_kernel(const u32x4* ops, uint32_t n, int32_t* out) {
+    const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48;
+    int c0 = 4 * (li + 1), c1 = 4 * (li + 1);
+    Weights w = {1, 1, 1 << 14};
+    for (uint32_t k = 0; k < n; ++k) {
+        const u32x4 op = ops[k];
+        int rec = 0;
+        switch (op.x) {
+        case 0: c0 = blend_row(c0, li, (int)op.y, (int)op.z, (int)op.w); rec = c0; break;                  // cdf0.blend(sym, Speed(inc, lim))
+        case 1: c1 = blend_row(c1, li, (int)op.y, (int)op.z, (int)op.w); rec = c1; break;                  // cdf1.blend
+        case 2: rec = average_rows(c0, c1, row_bcast<15>(c0), row_bcast<15>(c1), (int)op.y); break;       // cdf0.average(cdf1, mix_rate)
+        case 3: case 4: {                                                                                   // sym_to_start_and_freq / cdf_offset_to_sym_start_and_freq on cdf0
+            const int mx = row_bcast<15>(c0);
+            const int sym = op.x == 3 ? (int)op.y : search_symbol(c0, op.y & 0x7fffu, rbase);
+            const uint32_t d = scaled_div(c0, mx, biased_rcp15(mx));
+            const int dprev = row_prev_or_zero((int)d);
+            const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
+            const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
+            rec = li == 0 ? (int)(packed & 0xffffu) : (li == 1 ? (int)(packed >> 16) : (li == 2 ? sym : 0));
+            break;
+        }
+        case 5: weights_update(w, (int)(short)op.y, (int)(short)op.z, (int)(short)op.w);                  // Weights::update([p0, p1], weighted)
+                rec = li == 0 ? w.w0 : (li == 1 ? w.w1 : (li == 2 ? w.norm : 0)); break;
+        case 6: c0 = 4 * (li + 1); c1 = 4 * (li + 1); w.w0 = 1; w.w1 = 1; w.norm = 1 << 14; rec = c0; break;
+        case 7: c0 = blend_row_known_max(c0, li, (int)op.y, (int)op.z, (int)op.w, row_bcast<15>(c0)); rec = c0; break;   // the variant the pipelined paths use
+        default: break;
+        }
+        if (lane < 16) out[(size_t)k * 16u + (uint32_t)li] = rec;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch helpers (called from capi.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -842,6 +877,10 @@ hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint
     uint32_t blocks = (n + 3) / 4;
     blocks = blocks > 2048 ? 2048 : (blocks ? blocks : 1);
     hipLaunchKernelGGL(pack_copy_kernel, dim3(blocks), dim3(256), 0, st, slots, src_off, sizes, n, packed, dst_off);
+    return hipGetLastError();
+}
+hipError_t launch_selftest_cdf_ops(const uint32_t* d_ops, uint32_t n, int32_t* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(cdf_ops_selftest_kernel, dim3(1), dim3(64), 0, st, (const u32x4*)d_ops, n, d_out);
     return hipGetLastError();
 }
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st) {

@@ -172,6 +172,16 @@ int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, ui
  * returns the number of mismatches over every (cdf<<15)/max with 1<=max<32768, 0<=cdf<=max. */
 int divans_gpu_selftest_division(divans_gpu_codec *c, uint64_t *mismatches);
 
+/* Test entry points: device primitives in isolation, so that the reference's own unit tests can be run against them.
+ * cdf_ops: a script of n_ops operations {kind, a, b, c} (4 x u32 each) on two CDF rows and one Weights object, one
+ *   16 x i32 record per operation in `out`:  0/1 blend row 0/1 (a = symbol, b = inc, c = lim) -> the row;
+ *   2 row0.average(row1, a) -> the mixed row;  3 sym_to_start_and_freq(row0, a) / 4 cdf_offset_to_sym_start_and_freq(row0, a)
+ *   -> {start, freq, sym};  5 Weights::update([a, b], c) -> {w0, w1, normalized_weight as u16};  6 reset;  7 = 0 through
+ *   the blend variant of the pipelined paths.
+ * rans_pairs: the LIFO rANS pass on n_pairs (even) caller-supplied (start | freq << 16) words of one stream. */
+int divans_gpu_selftest_cdf_ops(divans_gpu_codec *c, const uint32_t *ops, uint32_t n_ops, int32_t *out);
+int divans_gpu_selftest_rans_pairs(divans_gpu_codec *c, const uint32_t *pairs, uint32_t n_pairs, uint8_t *out, size_t cap, size_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif
