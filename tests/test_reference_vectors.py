@@ -47,10 +47,8 @@ def _case(path, shuffle384):
 
 def _demux(container):
     s0 = np.empty(container.size, np.uint8); s1 = np.empty(container.size, np.uint8)
-    n0 = ctypes.c_size_t(0); n1 = ctypes.c_size_t(0); used = ctypes.c_size_t(0)
+    n0 = ctypes.c_size_t(s0.size); n1 = ctypes.c_size_t(s1.size); used = ctypes.c_size_t(0)   # in: capacities, out: lengths
     L = po.lib()
-    L.orc_mux_demux.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
-                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     body = np.ascontiguousarray(container[16:])
     assert L.orc_mux_demux(body.ctypes.data, body.size, s0.ctypes.data, ctypes.byref(n0), s1.ctypes.data, ctypes.byref(n1), ctypes.byref(used)) == 0
     return s0[:n0.value].copy(), s1[:n1.value].copy()
