@@ -28,7 +28,8 @@ struct DivansCompressorState {
     bool started = false;        // CompressorState::OptionStage -> constructed compressor (ffi/compressor.rs:212-236)
     bool failed = false;
     int header_sent = 0;         // bytes of the 16-byte header already handed out (write_header, divans_compressor.rs:150-174)
-    std::vector<uint8_t> input;  // RawToCmdState buffers input until flush (raw_to_cmd/mod.rs:55-104)
+    std::vector<uint8_t> input;  // everything the caller has handed over (RawToCmdState buffers it in its ring, raw_to_cmd/mod.rs:55-104)
+    std::vector<size_t> call_inputs;   // bytes per divans_encode call: decides when the ring fills and commands are emitted
     bool built = false;
     std::vector<uint8_t> stream; // complete container, produced at the first flush
     size_t cursor = 0;
@@ -120,6 +121,7 @@ DivansResult divans_encode(struct DivansCompressorState* s, const uint8_t* in, s
         if (s->header_sent < 16) return DIVANS_NEEDS_MORE_OUTPUT;
     }
     if (in_size > *in_off) s->input.insert(s->input.end(), in + *in_off, in + in_size);
+    s->call_inputs.push_back(in_size - *in_off);
     *in_off = in_size;
     return DIVANS_NEEDS_MORE_INPUT;
 }
@@ -138,7 +140,8 @@ DivansResult divans_encode_flush(struct DivansCompressorState* s, uint8_t* out, 
         // The Mux slicing depends on the room the caller gives each call (src/mux.rs:445-476); replay it with this
         // call's buffer size, which callers keep constant (c/example.c: BUF_SIZE).
         const size_t call_buffer = out_size ? out_size : 65536;
-        if (divans_host::build_container(s->opt, s->input.data(), s->input.size(), call_buffer, 0, s->stream) != 0) {
+        if (s->call_inputs.empty()) s->call_inputs.push_back(0);   // flush without any encode call: the header still goes out first
+        if (divans_host::build_container(s->opt, s->input.data(), s->input.size(), call_buffer, 0, s->stream, &s->call_inputs) != 0) {
             s->failed = true;
             return DIVANS_FAILURE;
         }

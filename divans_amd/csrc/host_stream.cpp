@@ -555,11 +555,65 @@ int lit_config_from_prediction_mode(const StreamOptions& opt, const PredictionMo
     return 0;
 }
 
+// ---------------------------------------------------------------- when the internal compressor emits which command
+// RawToCmdState (raw_to_cmd/mod.rs:32-181) buffers the caller's bytes in a ring of 2^window bytes and hands out commands
+// only when the ring is full or at flush.  `decode` / `output` are its two ring indices; the byte counts of the Literal
+// commands fall out of how they chase each other (first lap 2^w bytes, second 2^w - 1, then pairs of k-2 and 2^w-k+1).
+// Where the reference would emit ring bytes it never refilled (input ending inside the span a lap first writes at the end
+// of the ring: the index is reset regardless, :70-72), only the bytes actually written are emitted.
+struct RingEvents {
+    enum Kind { PredictionMode, Literal, NewCall };
+    struct Event { Kind kind; size_t len; };
+    std::vector<Event> events;
+    size_t ring, decode = 0, output = 0, fresh_tail = 0;
+    bool header_done = false;
+    explicit RingEvents(size_t ring_bytes) : ring(ring_bytes) {}
+    void literal(size_t len) { if (len) events.push_back({Literal, len}); }
+    void flush() {                                       // RawToCmdState::flush
+        if (!header_done) { header_done = true; events.push_back({PredictionMode, 0}); }
+        if (decode < output) {
+            literal(fresh_tail); fresh_tail = 0;
+            if (decode == ring) decode = 0;
+            output = 0;
+        }
+        if (decode != output) { literal(decode - output); output = decode; }
+    }
+    void feed(size_t bytes) {                            // one divans_encode call: DivansCompressor::encode looping over stream()
+        while (true) {
+            if (decode >= output) {
+                const size_t k = std::min(ring - decode, bytes);
+                bytes -= k; decode += k;
+                if (output != 0) { fresh_tail = decode - output; decode = 0; }
+            }
+            if (decode < output) {
+                const size_t k = std::min(output - 1 - decode, bytes);
+                bytes -= k; decode += k;
+            }
+            const bool full = decode == ring || decode + 1 == output;
+            if (!full) break;
+            flush();
+            if (bytes == 0) break;
+        }
+    }
+};
+
 int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
-                    std::vector<uint8_t>& out) {
+                    std::vector<uint8_t>& out, const std::vector<size_t>* call_inputs) {
     out.clear();
     const int w = std::min(24, std::max(10, opt.window_size));
     const size_t ring = (size_t)1 << w;
+    RingEvents plan(ring);
+    {
+        size_t left = n, calls = call_inputs ? call_inputs->size() : 1;
+        for (size_t k = 0; k < calls; ++k) {               // every encode call brings a fresh output buffer; the first also carries the header
+            const size_t m = std::min(left, call_inputs ? (*call_inputs)[k] : n);
+            if (k) plan.events.push_back({RingEvents::NewCall, 0});
+            plan.feed(m); left -= m;
+        }
+        if (left) return DIVANS_GPU_EINVAL;
+        plan.events.push_back({RingEvents::NewCall, 0});   // the flush calls
+        plan.flush();                                      // an empty input still flushes a PredictionMode command
+    }
     CommandModel model(opt);
     RansEncoder cmd;
     NibbleCoder nc; nc.enc = &cmd;
@@ -602,17 +656,20 @@ int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, si
         uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         size_t done = 0;
         while (done < 16) { const size_t room = sink.room(), k = std::min<size_t>(16 - done, room); std::memcpy(sink.reserve(k), hdr + done, k); sink.commit(k, k); done += k; }
-        sink.new_call();   // encode() returned NeedsMoreInput; everything below happens in flush() calls
     }
     size_t cmd_drained = 0, lit_drained = 0, lit_avail = 0;
     uint64_t lit_syms = 0; size_t chunk_idx = 0;
     auto drain_cmd = [&]() { drain(mux, sink, 0, cmd.out, cmd.out.size(), cmd_drained); };
     auto drain_lit = [&]() { drain(mux, sink, 1, lit, lit_avail, lit_drained); };
     nc.before = drain_cmd;
-    model.command_type(nc, 7);
-    if (!model.prediction_mode(nc, &pm)) return DIVANS_GPU_EINVAL;
-    for (size_t pos = 0; pos < n; pos += ring) {
-        const size_t len = std::min(ring, n - pos);
+    for (const RingEvents::Event& ev : plan.events) {
+        if (ev.kind == RingEvents::NewCall) { sink.new_call(); continue; }
+        if (ev.kind == RingEvents::PredictionMode) {
+            model.command_type(nc, 7);
+            if (!model.prediction_mode(nc, &pm)) return DIVANS_GPU_EINVAL;
+            continue;
+        }
+        const size_t len = ev.len;
         model.command_type(nc, 3);
         uint32_t len_out;
         if (!model.literal_length(nc, (uint32_t)len, len_out)) return DIVANS_GPU_EINVAL;

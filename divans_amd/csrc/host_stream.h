@@ -36,8 +36,11 @@ uint8_t speed_to_f8(int16_t v);           // probability/interface.rs:566-575
 // (src/divans_compressor.rs:276-426 + src/raw_to_cmd/mod.rs:105-181), `call_buffer` = size of the output buffer
 // the caller hands to each flush call (the Mux slicing depends on it, src/mux.rs:445-476).
 // Literal bytes are coded on GPU `device`.  Returns 0 or a DIVANS_GPU_E* code.
+// `call_inputs`: bytes the caller handed to each divans_encode call (null: all in one call) -- the internal compressor emits
+// commands when its 2^window ring fills (raw_to_cmd/mod.rs:83), i.e. inside those calls, and what the Mux has sliced by then
+// depends on it.
 int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
-                    std::vector<uint8_t>& out);
+                    std::vector<uint8_t>& out, const std::vector<size_t>* call_inputs = nullptr);
 
 enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
 // Decodes a complete container (header .. "ans~").  PARSE_NEED_MORE when `n` bytes do not yet hold the whole stream.

@@ -164,6 +164,8 @@ typedef struct {
     uint8_t force_stride;            /* StrideSelection 0..8, 9 = UseBrotliRec */
     int has_literal_adaptation; orc_speed literal_adaptation[4];
     size_t call_buffer_size;         /* size of the output buffer the caller hands to each encode/flush call */
+    const size_t *call_inputs;       /* bytes the caller passes to each divans_encode call (NULL: all of them in one call);   */
+    size_t n_call_inputs;            /*   decides when the ring buffer fills and commands are emitted, raw_to_cmd/mod.rs:55-104 */
 } orc_stream_options;
 void orc_stream_options_default(orc_stream_options *o);
 
@@ -182,7 +184,8 @@ typedef struct {                     /* what the codec's own PredictionModeConte
     const uint8_t *literal_context_map;  /* 16384 */
     const uint8_t *mixing_values;        /* 8192 */
 } orc_prediction_mode_result;
-enum { ORC_CMD_PREDICTION_MODE = 7, ORC_CMD_BLOCK_SWITCH_LITERAL = 4, ORC_CMD_LITERAL = 3 };
+enum { ORC_CMD_PREDICTION_MODE = 7, ORC_CMD_BLOCK_SWITCH_LITERAL = 4, ORC_CMD_LITERAL = 3,
+       ORC_CMD_NEW_CALL = 100 /* not a command: the current encode()/flush() call returns, the next one brings a fresh output buffer */ };
 typedef struct {
     int kind;
     orc_prediction_mode pm;

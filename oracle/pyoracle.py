@@ -31,7 +31,8 @@ class LitConfig(ctypes.Structure):
 class StreamOptions(ctypes.Structure):
     _fields_ = [("window_size", ctypes.c_int), ("dynamic_context_mixing", ctypes.c_uint8), ("prior_depth", ctypes.c_uint8),
                 ("use_context_map", ctypes.c_int), ("force_stride", ctypes.c_uint8), ("has_literal_adaptation", ctypes.c_int),
-                ("literal_adaptation", Speed * 4), ("call_buffer_size", ctypes.c_size_t)]
+                ("literal_adaptation", Speed * 4), ("call_buffer_size", ctypes.c_size_t),
+                ("call_inputs", ctypes.c_void_p), ("n_call_inputs", ctypes.c_size_t)]
 
 
 class PredictionMode(ctypes.Structure):
@@ -194,10 +195,14 @@ def stream_options(**kw):
     return o
 
 
-def stream_compress_raw(data, opts=None):
-    """the literal-only internal compressor (use_brotli = UseInternalCommandSelection)"""
+def stream_compress_raw(data, opts=None, call_inputs=None):
+    """the literal-only internal compressor (use_brotli = UseInternalCommandSelection); `call_inputs` = bytes handed to each
+    divans_encode call (default: all in one call)"""
     opts = opts or stream_options()
     data = np.ascontiguousarray(data, dtype=np.uint8)
+    if call_inputs is not None:
+        ci = np.ascontiguousarray(call_inputs, dtype=np.uint64)
+        opts.call_inputs = ci.ctypes.data; opts.n_call_inputs = ci.size
     cap = 2 * data.size + 65536
     out = np.empty(cap, dtype=np.uint8)
     r = lib().orc_stream_compress_raw(ctypes.byref(opts), data.ctypes.data, data.size, out.ctypes.data, cap)

@@ -600,6 +600,8 @@ static size_t stream_compress_impl(const orc_stream_options *o, const orc_stream
             code_block_switch_literal(c, &cc, drain_cmd_cb, &e, cm->btype, cm->stride, &btype, &stride);
             cfg->btype = btype;
             orc_lit_state_reconfigure(ls, cfg);
+        } else if (cm->kind == ORC_CMD_NEW_CALL) {
+            e.out.call_used = 0;
         } else if (cm->kind == ORC_CMD_LITERAL) {
             if (cm->len == 0) { bad = 1; break; }
             code_command_type(c, &cc, drain_cmd_cb, &e, 3);
@@ -640,31 +642,85 @@ size_t orc_stream_compress(const orc_stream_options *o, const orc_stream_command
     return stream_compress_impl(o, cmds, n_cmds, out, cap, 0);   /* encode_commands(): header and commands share the call */
 }
 
-/* The literal-only internal compressor (use_brotli = UseInternalCommandSelection): raw_to_cmd/mod.rs:105-181
- * emits [PredictionMode][Literal per ring-buffer span].  Input shorter than the ring arrives as one Literal. */
+/* The literal-only internal compressor (use_brotli = UseInternalCommandSelection).
+ * RawToCmdState (raw_to_cmd/mod.rs:55-181) copies the caller's bytes into a 2^window ring and emits commands only when the
+ * ring is full (stream, :83) or at flush: first [PredictionMode], then Literal commands over the ring spans it has not
+ * handed out yet.  The spans follow the ring's index dance, restated literally below: the first lap is 2^w bytes, the
+ * second 2^w - 1, lap k >= 3 is two commands of k-2 and 2^w-k+1 bytes.  One deviation: when the input ends inside the
+ * few bytes a lap first writes at the END of the ring, the reference resets its write index anyway (:70-72) and later
+ * emits the whole tail span, stale bytes included (its round trip then fails); only the fresh bytes are emitted here. */
+typedef struct { size_t ring, dec, outi, tail_fresh, emitted; int has_header; orc_stream_command *cmds; size_t n; const uint8_t *in;
+                 orc_prediction_mode pm; } raw_sim;
+
+static void raw_sim_literal(raw_sim *r, size_t len) {
+    if (!len) return;
+    orc_stream_command *c = &r->cmds[r->n++];
+    memset(c, 0, sizeof(*c));
+    c->kind = ORC_CMD_LITERAL; c->data = r->in + r->emitted; c->len = len;
+    r->emitted += len;
+}
+static void raw_sim_flush(raw_sim *r) {             /* RawToCmdState::flush, :105-181 */
+    if (!r->has_header) {
+        r->has_header = 1;
+        orc_stream_command *c = &r->cmds[r->n++];
+        memset(c, 0, sizeof(*c));
+        c->kind = ORC_CMD_PREDICTION_MODE; c->pm = r->pm;
+    }
+    if (r->dec < r->outi) {
+        raw_sim_literal(r, r->tail_fresh);         /* reference: ring.len() - output_index bytes */
+        r->tail_fresh = 0;
+        if (r->dec == r->ring) r->dec = 0;
+        r->outi = 0;
+    }
+    if (r->dec != r->outi) { raw_sim_literal(r, r->dec - r->outi); r->outi = r->dec; }
+}
+static void raw_sim_stream(raw_sim *r, size_t *pos, size_t call_end) {   /* DivansCompressor::encode loop over RawToCmdState::stream */
+    for (;;) {
+        if (r->dec >= r->outi) {
+            size_t mc = r->ring - r->dec < call_end - *pos ? r->ring - r->dec : call_end - *pos;
+            *pos += mc; r->dec += mc;
+            if (r->outi != 0) { r->tail_fresh = r->dec - r->outi; r->dec = 0; }
+        }
+        if (r->dec < r->outi) {
+            size_t mc = r->outi - 1 - r->dec < call_end - *pos ? r->outi - 1 - r->dec : call_end - *pos;
+            *pos += mc; r->dec += mc;
+        }
+        if (r->dec == r->ring || r->dec + 1 == r->outi) {     /* ring_buffer_full */
+            raw_sim_flush(r);
+            if (*pos != call_end) continue;
+        }
+        break;
+    }
+}
+
 size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, size_t n, uint8_t *out, size_t cap) {
     int w = o->window_size < 10 ? 10 : (o->window_size > 24 ? 24 : o->window_size);
-    size_t ring = (size_t)1 << w;
-    size_t nlit = n ? (n + ring - 1) / ring : 0;
-    orc_stream_command *cmds = (orc_stream_command *)calloc(nlit + 1, sizeof(orc_stream_command));
+    raw_sim r;
+    memset(&r, 0, sizeof(r));
+    r.ring = (size_t)1 << w; r.in = in;
+    size_t ncalls = o->call_inputs ? o->n_call_inputs : 1;
+    r.cmds = (orc_stream_command *)calloc(2 * (n / (r.ring - 1) + 2) + ncalls + 8, sizeof(orc_stream_command));
     static uint8_t cmap[64], dmap[4], mixing[ORC_NUM_MIXING_VALUES];
     for (int i = 0; i < 64; ++i) cmap[i] = (uint8_t)(i & 0x3f);
     for (int i = 0; i < 4; ++i) dmap[i] = (uint8_t)(i & 3);
     memset(mixing, 4, sizeof(mixing));
-    cmds[0].kind = ORC_CMD_PREDICTION_MODE;
-    cmds[0].pm.prediction_mode = 0;
-    cmds[0].pm.literal_context_map = cmap; cmds[0].pm.n_literal_context_map = 64;
-    cmds[0].pm.distance_context_map = dmap; cmds[0].pm.n_distance_context_map = 4;
-    cmds[0].pm.mixing_values = mixing; cmds[0].pm.has_context_speeds = 1;
-    for (size_t i = 0; i < nlit; ++i) {
-        cmds[1 + i].kind = ORC_CMD_LITERAL;
-        cmds[1 + i].data = in + i * ring;
-        cmds[1 + i].len = (i + 1 < nlit) ? ring : n - i * ring;
+    r.pm.prediction_mode = 0;
+    r.pm.literal_context_map = cmap; r.pm.n_literal_context_map = 64;
+    r.pm.distance_context_map = dmap; r.pm.n_distance_context_map = 4;
+    r.pm.mixing_values = mixing; r.pm.has_context_speeds = 1;
+    size_t pos = 0;
+    for (size_t k = 0; k < ncalls; ++k) {            /* every divans_encode call starts with a fresh output buffer; the first also carries the header */
+        size_t m = o->call_inputs ? o->call_inputs[k] : n;
+        if (m > n - pos) m = n - pos;
+        if (k) r.cmds[r.n++].kind = ORC_CMD_NEW_CALL;
+        raw_sim_stream(&r, &pos, pos + m);
     }
-    /* an empty input still flushes a PredictionMode command (has_produced_header, raw_to_cmd/mod.rs:114-143) */
-    size_t r = stream_compress_impl(o, cmds, nlit + 1, out, cap, 1);
-    free(cmds);
-    return r;
+    /* divans_encode_flush: an empty input still flushes a PredictionMode command (has_produced_header, :114-143) */
+    r.cmds[r.n++].kind = ORC_CMD_NEW_CALL;
+    raw_sim_flush(&r);
+    size_t ret = (pos == n && r.emitted == n) ? stream_compress_impl(o, r.cmds, r.n, out, cap, 0) : (size_t)-1;
+    free(r.cmds);
+    return ret;
 }
 
 /* ------------------------------------------------------------------ decoder */

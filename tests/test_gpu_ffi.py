@@ -36,7 +36,8 @@ def _lib():
     return L
 
 
-def ffi_compress(data, options, buf_size=65536):
+def ffi_compress(data, options, buf_size=65536, feed=None):
+    """c/example.c's loop; `feed` = bytes of input offered per divans_encode call (default: everything that is left)"""
     L = _lib()
     st = L.divans_new_compressor()
     for sel, val in options:
@@ -47,7 +48,8 @@ def ffi_compress(data, options, buf_size=65536):
     off = 0
     while off < data.size:
         ro = ctypes.c_size_t(0); wo = ctypes.c_size_t(0)
-        r = L.divans_encode(st, data.ctypes.data + off, data.size - off, ctypes.byref(ro), buf.ctypes.data, buf_size, ctypes.byref(wo))
+        give = data.size - off if feed is None else min(feed, data.size - off)
+        r = L.divans_encode(st, data.ctypes.data + off, give, ctypes.byref(ro), buf.ctypes.data, buf_size, ctypes.byref(wo))
         assert r != 3
         off += ro.value; out += buf[:wo.value].tobytes()
     while True:
@@ -227,3 +229,25 @@ def test_reference_example_c_unmodified(args, env, tmp_path, corpus):
     corpus[:100000].tofile(src)
     r = subprocess.run([REF_EXAMPLE] + args + [str(src)], capture_output=True, text=True, env=e, timeout=300)
     assert r.returncode == 0 and "File length 100000 reduced to" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_inputs_larger_than_the_window_follow_the_ring_buffer(corpus):
+    """the internal compressor emits commands when its 2^window ring fills, inside the divans_encode calls
+    (raw_to_cmd/mod.rs:55-104), so for inputs beyond the window the Literal spans (2^w, 2^w - 1, then k-2 / 2^w-k+1 pairs) and the
+    Mux slices depend on the caller's call pattern.  10 MiB at window 16 with 4 KiB buffers, whole-input and 4 KiB-chunked feeding,
+    byte-identical to the oracle's container and decodable in both directions."""
+    import workload
+    data = workload.make_blocks(corpus, 7, 160).reshape(-1)                 # 10 MiB
+    for feed in (None, 4096):
+        coded = ffi_compress(data, [(5, 0), (2, 16)], buf_size=4096, feed=feed)
+        calls = [data.size] if feed is None else [feed] * (data.size // feed)
+        ref = po.stream_compress_raw(data, po.stream_options(window_size=16, call_buffer_size=4096), call_inputs=calls)
+        assert coded.size == ref.size and (coded == ref).all()
+    assert (ffi_decompress(coded, data.size, buf_size=4096, feed=4096) == data).all()
+    assert (po.stream_decompress(coded, data.size) == data).all()
+    # the odd spans around the second and third lap of a 1 KiB ring
+    for n in (1023, 1024, 1025, 2047, 2048, 3070, 3071, 3072, 5000):
+        d = corpus[:n]
+        coded = ffi_compress(d, [(5, 0), (2, 10)], buf_size=777)
+        assert (coded == po.stream_compress_raw(d, po.stream_options(window_size=10, call_buffer_size=777), call_inputs=[n])).all()
+        assert (ffi_decompress(coded, n) == d).all()
