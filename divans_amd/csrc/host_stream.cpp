@@ -597,99 +597,95 @@ struct RingEvents {
     }
 };
 
-int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
-                    std::vector<uint8_t>& out, const std::vector<size_t>* call_inputs) {
-    out.clear();
-    const int w = std::min(24, std::max(10, opt.window_size));
-    const size_t ring = (size_t)1 << w;
-    RingEvents plan(ring);
-    {
-        size_t left = n, calls = call_inputs ? call_inputs->size() : 1;
-        for (size_t k = 0; k < calls; ++k) {               // every encode call brings a fresh output buffer; the first also carries the header
-            const size_t m = std::min(left, call_inputs ? (*call_inputs)[k] : n);
-            if (k) plan.events.push_back({RingEvents::NewCall, 0});
-            plan.feed(m); left -= m;
-        }
-        if (left) return DIVANS_GPU_EINVAL;
-        plan.events.push_back({RingEvents::NewCall, 0});   // the flush calls
-        plan.flush();                                      // an empty input still flushes a PredictionMode command
-    }
-    CommandModel model(opt);
-    RansEncoder cmd;
-    NibbleCoder nc; nc.enc = &cmd;
-    // the command list of the literal-only internal compressor, raw_to_cmd/mod.rs:105-181
+// The default PredictionMode of the internal compressor, raw_to_cmd/mod.rs:115-143
+static PredictionModeIn internal_prediction_mode() {
     PredictionModeIn pm;
     pm.literal_context_map.resize(64); for (int i = 0; i < 64; ++i) pm.literal_context_map[i] = (uint8_t)(i & 0x3f);
     pm.distance_context_map = {0, 1, 2, 3};
     pm.mixing_values.assign(DIVANS_GPU_NUM_MIXING_VALUES, 4);
     pm.has_context_speeds = true;
+    return pm;
+}
 
-    // 1. the literal stream on the GPU (all Literal commands share one LIT coder and one set of priors).
-    // Its configuration is a function of the PredictionMode command alone, so a scratch model codes that command
-    // once to learn it; the real CMD stream is produced in step 2 in event order.
-    std::vector<uint8_t> lit; std::vector<uint32_t> chunk_bytes;
-    if (n) {
-        if (n > 0x7fffffffu) return DIVANS_GPU_EINVAL;
-        CommandModel probe(opt);
-        RansEncoder scratch;
-        NibbleCoder pn; pn.enc = &scratch;
-        probe.command_type(pn, 7);
-        if (!probe.prediction_mode(pn, &pm)) return DIVANS_GPU_EINVAL;
-        auto cfg = std::make_unique<divans_lit_config>();
-        probe.fill_lit_config(*cfg, 0);
-        GpuCodecHandle h;
-        int rc = h.acquire(*cfg, device, (uint32_t)n);
-        if (rc) return rc;
-        const uint32_t max_chunks = (uint32_t)((2 * n + 65535) / 65536);
-        lit.resize(divans_gpu_lit_encode_bound(n) + 64);
-        chunk_bytes.assign(max_chunks, 0);
-        uint64_t off = 0; uint32_t size = 0; size_t total = 0;
-        rc = divans_gpu_lit_encode_host_chunks(h.c, input, (uint32_t)n, 1, lit.data(), lit.size(), &off, &size, &total,
-                                               chunk_bytes.data(), max_chunks);
-        if (rc) return rc;
-        lit.resize(size);
+// ---- phase A: everything about a stream that does not need its LIT-coder bytes -------------------------------------
+// For literal-only streams the CMD coder sees only lengths and options, never the data: its bytes, and the order in
+// which coder bytes become available to the Mux, can be worked out while the GPU is still coding the literals
+// (the reference overlaps the same two halves with a worker thread, threading.rs:88-100).
+int plan_stream(const StreamOptions& opt, size_t n, const std::vector<size_t>* call_inputs, StreamPlan& plan) {
+    plan = StreamPlan();
+    if (n > 0x7fffffffu) return DIVANS_GPU_EINVAL;
+    plan.n = n;
+    plan.window = std::min(24, std::max(10, opt.window_size));
+    RingEvents ring((size_t)1 << plan.window);
+    {
+        size_t left = n, calls = call_inputs ? call_inputs->size() : 1;
+        for (size_t k = 0; k < calls; ++k) {               // every encode call brings a fresh output buffer; the first also carries the header
+            const size_t m = std::min(left, call_inputs ? (*call_inputs)[k] : n);
+            if (k) ring.events.push_back({RingEvents::NewCall, 0});
+            ring.feed(m); left -= m;
+        }
+        if (left) return DIVANS_GPU_EINVAL;
+        ring.events.push_back({RingEvents::NewCall, 0});   // the flush calls
+        ring.flush();                                      // an empty input still flushes a PredictionMode command
     }
-    // 2. replay the encoder's event sequence through the Mux
-    Mux mux;
-    CallSink sink(out, call_buffer);
-    {   // header in the first encode() call, divans_compressor.rs:126-131,150-174
-        uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        size_t done = 0;
-        while (done < 16) { const size_t room = sink.room(), k = std::min<size_t>(16 - done, room); std::memcpy(sink.reserve(k), hdr + done, k); sink.commit(k, k); done += k; }
-    }
-    size_t cmd_drained = 0, lit_drained = 0, lit_avail = 0;
-    uint64_t lit_syms = 0; size_t chunk_idx = 0;
-    auto drain_cmd = [&]() { drain(mux, sink, 0, cmd.out, cmd.out.size(), cmd_drained); };
-    auto drain_lit = [&]() { drain(mux, sink, 1, lit, lit_avail, lit_drained); };
-    nc.before = drain_cmd;
-    for (const RingEvents::Event& ev : plan.events) {
-        if (ev.kind == RingEvents::NewCall) { sink.new_call(); continue; }
+    const PredictionModeIn pm = internal_prediction_mode();
+    CommandModel model(opt);
+    RansEncoder cmd;
+    NibbleCoder nc; nc.enc = &cmd;
+    size_t cmd_logged = 0;
+    // drain_or_fill_internal_buffer_cmd runs before every CMD nibble; it only does something when the coder has new bytes
+    nc.before = [&]() { if (cmd.out.size() != cmd_logged) { cmd_logged = cmd.out.size(); plan.steps.push_back({StreamPlan::CmdAvail, (uint32_t)cmd_logged}); } };
+    uint64_t lit_syms = 0; uint32_t chunk_idx = 0;
+    for (const RingEvents::Event& ev : ring.events) {
+        if (ev.kind == RingEvents::NewCall) { plan.steps.push_back({StreamPlan::NewCall, 0}); continue; }
         if (ev.kind == RingEvents::PredictionMode) {
             model.command_type(nc, 7);
             if (!model.prediction_mode(nc, &pm)) return DIVANS_GPU_EINVAL;
+            model.fill_lit_config(plan.cfg, 0);
             continue;
         }
-        const size_t len = ev.len;
         model.command_type(nc, 3);
         uint32_t len_out;
-        if (!model.literal_length(nc, (uint32_t)len, len_out)) return DIVANS_GPU_EINVAL;
-        drain_lit();
+        if (!model.literal_length(nc, (uint32_t)ev.len, len_out)) return DIVANS_GPU_EINVAL;
         // every 65 536th LIT symbol flushes a chunk, drained right after that nibble (literal.rs:309-315,368-374)
-        uint64_t end_syms = lit_syms + 2 * (uint64_t)len;
+        const uint64_t end_syms = lit_syms + 2 * (uint64_t)ev.len;
         while ((lit_syms / 65536 + 1) * 65536 <= end_syms) {
             lit_syms = (lit_syms / 65536 + 1) * 65536;
-            lit_avail += chunk_bytes[chunk_idx++];
-            drain_lit();
+            plan.steps.push_back({StreamPlan::LitChunk, chunk_idx++});
         }
         lit_syms = end_syms;
     }
-    // DivansCodec::flush, codec/mod.rs:424-554
+    // DivansCodec::flush, codec/mod.rs:424-554: EOF nibble, EncodedShutdownNode, ShutdownCoder(0), ShutdownCoder(1), CoderBufferDrain
     model.command_type(nc, 0xf);
-    drain_cmd(); drain_lit();                       // EncodedShutdownNode
-    cmd.flush();                                    // ShutdownCoder(0)
-    if (chunk_idx < chunk_bytes.size()) lit_avail += chunk_bytes[chunk_idx++];   // ShutdownCoder(1): the partial last chunk
-    drain_cmd(); drain_lit();                       // CoderBufferDrain
-    if (cmd.failed || lit_avail != lit.size()) return DIVANS_GPU_EINVAL;
+    nc.before();
+    cmd.flush();
+    nc.before();
+    if (lit_syms % 65536) plan.steps.push_back({StreamPlan::LitChunk, chunk_idx++});   // the partial last chunk
+    plan.lit_chunks = chunk_idx;
+    if (cmd.failed) return DIVANS_GPU_EINVAL;
+    plan.cmd.swap(cmd.out);
+    return 0;
+}
+
+// ---- phase B: header, Mux replay in event order, EOF marker, CRC trailer --------------------------------------------
+int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_size, const uint32_t* chunk_bytes, size_t call_buffer,
+                       std::vector<uint8_t>& out) {
+    out.clear();
+    Mux mux;
+    CallSink sink(out, call_buffer);
+    {   // header in the first encode() call, divans_compressor.rs:126-131,150-174
+        uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)plan.window, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        size_t done = 0;
+        while (done < 16) { const size_t room = sink.room(), k = std::min<size_t>(16 - done, room); std::memcpy(sink.reserve(k), hdr + done, k); sink.commit(k, k); done += k; }
+    }
+    std::vector<uint8_t> lit_copy(lit, lit + lit_size);
+    size_t cmd_drained = 0, lit_drained = 0, lit_avail = 0;
+    for (const StreamPlan::Step& st : plan.steps) {
+        if (st.kind == StreamPlan::NewCall) sink.new_call();
+        else if (st.kind == StreamPlan::CmdAvail) drain(mux, sink, 0, plan.cmd, st.value, cmd_drained);
+        else { lit_avail += chunk_bytes[st.value]; if (lit_avail > lit_size) return DIVANS_GPU_EINVAL; drain(mux, sink, 1, lit_copy, lit_avail, lit_drained); }
+    }
+    if (lit_avail != lit_size || cmd_drained != plan.cmd.size()) return DIVANS_GPU_EINVAL;
     while (mux.eof != 3) {                          // MuxDrain
         const size_t room = sink.room();
         uint8_t* p = sink.reserve(room);
@@ -700,6 +696,28 @@ int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, si
     const uint8_t tr[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
     out.insert(out.end(), tr, tr + 8);
     return 0;
+}
+
+int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
+                    std::vector<uint8_t>& out, const std::vector<size_t>* call_inputs) {
+    out.clear();
+    StreamPlan plan;
+    int rc = plan_stream(opt, n, call_inputs, plan);
+    if (rc) return rc;
+    // every literal byte on the GPU (all Literal commands share one LIT coder and one set of priors)
+    std::vector<uint8_t> lit; std::vector<uint32_t> chunk_bytes(std::max<uint32_t>(plan.lit_chunks, 1u), 0u);
+    if (n) {
+        GpuCodecHandle h;
+        rc = h.acquire(plan.cfg, device, (uint32_t)n);
+        if (rc) return rc;
+        lit.resize(divans_gpu_lit_encode_bound(n) + 64);
+        uint64_t off = 0; uint32_t size = 0; size_t total = 0;
+        rc = divans_gpu_lit_encode_host_chunks(h.c, input, (uint32_t)n, 1, lit.data(), lit.size(), &off, &size, &total,
+                                               chunk_bytes.data(), (uint32_t)chunk_bytes.size());
+        if (rc) return rc;
+        lit.resize(size);
+    }
+    return assemble_container(plan, lit.data(), lit.size(), chunk_bytes.data(), call_buffer, out);
 }
 
 ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,

@@ -42,6 +42,21 @@ uint8_t speed_to_f8(int16_t v);           // probability/interface.rs:566-575
 int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
                     std::vector<uint8_t>& out, const std::vector<size_t>* call_inputs = nullptr);
 
+// A stream split into the half that needs no literal data (CMD coder bytes, the order in which coder bytes reach the Mux)
+// and the half that does (assemble_container): the first runs on host threads while the GPU codes the literals.
+struct StreamPlan {
+    enum Kind : uint8_t { CmdAvail, LitChunk, NewCall };
+    struct Step { Kind kind; uint32_t value; };   // CmdAvail: CMD bytes available so far; LitChunk: chunk index whose bytes arrive; NewCall: fresh caller buffer
+    size_t n = 0; int window = 22;
+    divans_lit_config cfg;                        // what the LIT coder runs under (from the stream's PredictionMode)
+    std::vector<uint8_t> cmd;
+    std::vector<Step> steps;
+    uint32_t lit_chunks = 0;                      // 65 536-symbol chunks of the LIT stream
+};
+int plan_stream(const StreamOptions& opt, size_t n, const std::vector<size_t>* call_inputs, StreamPlan& plan);
+int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_size, const uint32_t* chunk_bytes, size_t call_buffer,
+                       std::vector<uint8_t>& out);
+
 enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
 // Decodes a complete container (header .. "ans~").  PARSE_NEED_MORE when `n` bytes do not yet hold the whole stream.
 // `max_output` bounds the decoded size the stream may claim (literal lengths come from the stream itself).

@@ -102,7 +102,7 @@ def test_operation_test_helper_on_the_device_primitives(codec):
         ops.append((2, rate, 0, 0))
     got = run_both(codec, ops)
     # assert_cdf_similar(average(.., all), cdf0) / (average(.., 0), cdf1): within max0*max1/160 after cross-scaling (common_tests.rs:128-150)
-    r0, r1 = got[len(ops) - 7], got[29]
+    r0, r1 = got[len(ops) - 6], got[29]
     for rec, ref in ((got[-1], r0), (got[-2], r1)):
         m0, m1 = int(rec[15]), int(ref[15])
         assert all(abs(int(rec[i]) * m1 - int(ref[i]) * m0) < m0 * m1 // 160 for i in range(16))
