@@ -58,6 +58,18 @@ class IrOptions(ctypes.Structure):
                 ("literal_adaptation", Speed * 4)]
 
 
+class BatchOptions(ctypes.Structure):
+    """divans_batch_options (include/divans_batch.h)."""
+    _fields_ = [("window_size", ctypes.c_int32), ("dynamic_context_mixing", ctypes.c_uint8), ("use_context_map", ctypes.c_uint8),
+                ("force_stride", ctypes.c_uint8), ("has_prior_depth", ctypes.c_uint8), ("prior_depth", ctypes.c_uint8),
+                ("has_literal_adaptation", ctypes.c_uint8), ("literal_adaptation", Speed * 4), ("call_buffer_size", ctypes.c_uint32),
+                ("device", ctypes.c_int32), ("host_threads", ctypes.c_int32), ("skip_crc", ctypes.c_uint8)]
+
+
+class BatchTiming(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_double), ("gpu_ms", ctypes.c_double), ("host_overlapped_ms", ctypes.c_double), ("host_serial_ms", ctypes.c_double)]
+
+
 class GpuInfo(ctypes.Structure):
     _fields_ = [
         ("rows_per_stream", ctypes.c_uint32), ("resident_groups", ctypes.c_uint32),
@@ -116,6 +128,11 @@ def load_library():
     L.divans_gpu_lit_encode_segments_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, vp, u64, vp, vp]
     L.divans_gpu_lit_decode_segments_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, u32]
     sz = ctypes.c_size_t
+    L.divans_batch_options_default.argtypes = [ctypes.POINTER(BatchOptions)]
+    L.divans_batch_options_default.restype = None
+    L.divans_batch_compress_bound.argtypes = [sz]; L.divans_batch_compress_bound.restype = sz
+    L.divans_batch_compress.argtypes = [ctypes.POINTER(BatchOptions), vp, vp, sz, vp, sz, vp, vp, ctypes.POINTER(BatchTiming)]
+    L.divans_batch_decompress.argtypes = [ctypes.POINTER(BatchOptions), vp, vp, sz, vp, sz, vp, vp, ctypes.POINTER(BatchTiming)]
     L.divans_ir_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]
     L.divans_ir_free.argtypes = [vp]
     L.divans_ir_free.restype = None
@@ -142,8 +159,13 @@ def exported_symbols():
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
-        "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs",
+        "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
     ]
+
+
+def exported_batch_symbols():
+    """Entry points include/divans_batch.h declares."""
+    return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress"]
 
 
 def exported_ir_symbols():
@@ -416,3 +438,47 @@ class LiteralCodec:
 
 def build_extension(force=False):
     return _build.build(force=force)
+
+
+def batch_options(**kw):
+    o = BatchOptions()
+    load_library().divans_batch_options_default(ctypes.byref(o))
+    for key, val in kw.items():
+        if key == "literal_adaptation":
+            o.has_literal_adaptation = 1
+            for i, (inc, lim) in enumerate(val):
+                o.literal_adaptation[i].inc = inc; o.literal_adaptation[i].lim = lim
+        elif key == "prior_depth":
+            o.has_prior_depth = 1; o.prior_depth = val
+        else:
+            setattr(o, key, val)
+    return o
+
+
+def _batch_call(fn, what, options, items, cap):
+    L = load_library()
+    items = [np.ascontiguousarray(x, dtype=np.uint8) for x in items]
+    n = len(items)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[x.ctypes.data for x in items])
+    sizes = (ctypes.c_size_t * max(n, 1))(*[x.size for x in items])
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    offs = (ctypes.c_size_t * max(n, 1))(); osz = (ctypes.c_size_t * max(n, 1))()
+    t = BatchTiming()
+    _check(fn(ctypes.byref(options), ptrs, sizes, n, out.ctypes.data, cap, offs, osz, ctypes.byref(t)), what)
+    res = [out[offs[i]:offs[i] + osz[i]].copy() for i in range(n)]
+    return res, dict(total_ms=t.total_ms, gpu_ms=t.gpu_ms, host_overlapped_ms=t.host_overlapped_ms, host_serial_ms=t.host_serial_ms)
+
+
+def batch_compress(inputs, options=None):
+    """inputs: list of uint8 arrays -> (list of complete .divans containers, timing dict).  LIT coders on the GPU, CMD coders and framing
+    on host threads, overlapped (include/divans_batch.h)."""
+    L = load_library()
+    options = options or batch_options()
+    cap = sum(int(L.divans_batch_compress_bound(int(np.asarray(x).size))) for x in inputs) + 64
+    return _batch_call(L.divans_batch_compress, "divans_batch_compress", options, inputs, cap)
+
+
+def batch_decompress(containers, total_out, options=None):
+    L = load_library()
+    options = options or batch_options()
+    return _batch_call(L.divans_batch_decompress, "divans_batch_decompress", options, containers, int(total_out) + 64)

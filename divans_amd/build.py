@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdivans_hip.so")
-SOURCES = ["lit_kernels.hip", "lit_kernels_p8.hip", "lit_bucket.hip", "capi.cpp", "host_stream.cpp", "ffi.cpp", "ir.cpp"]
+SOURCES = ["lit_kernels.hip", "lit_kernels_p8.hip", "lit_bucket.hip", "capi.cpp", "host_stream.cpp", "ffi.cpp", "ir.cpp", "batch.cpp"]
 
 
 def hipcc():
@@ -21,7 +21,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", h) for h in ("divans_gpu.h", "divans_ffi.h", "divans_ir.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", h) for h in ("divans_gpu.h", "divans_ffi.h", "divans_ir.h", "divans_batch.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

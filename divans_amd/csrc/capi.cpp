@@ -496,6 +496,15 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     return 0;
 }
 
+extern "C" int divans_gpu_lit_encode_batch_chunks(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
+                                                  const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                                                  uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes,
+                                                  uint32_t* d_chunk_bytes, uint32_t max_chunks) {
+    if (!d_chunk_bytes || max_chunks < (2u * (uint64_t)stream_len + 65535u) / 65536u) return fail(DIVANS_GPU_EINVAL, "max_chunks too small");
+    return encode_batch_impl(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, d_out, out_slot, d_out_offsets, d_out_sizes,
+                             d_chunk_bytes, max_chunks);
+}
+
 extern "C" int divans_gpu_lit_encode_segments_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                                                     const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                                                     const uint32_t* d_seg_begin, const divans_lit_segment* d_segs,

@@ -720,9 +720,9 @@ int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, si
     return assemble_container(plan, lit.data(), lit.size(), chunk_bytes.data(), call_buffer, out);
 }
 
-ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,
-                            size_t max_output) {
-    out.clear();
+// Host half of decoding: framing, CRC, CMD coder.  Leaves the LIT coder's bytes, the decoded size and its configuration.
+ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed) {
+    ps = ParsedStream();
     if (n < 16) return PARSE_NEED_MORE;
     if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f) return PARSE_CORRUPT;   // divans_decompressor.rs:38-52
     if (in[5] < 10 || in[5] >= 25) return PARSE_CORRUPT;
@@ -743,14 +743,13 @@ ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int devi
     NibbleCoder nc; nc.dec = &cd;
     uint8_t btype = 0; bool have_pm = false, seen_literal = false;
     uint64_t total = 0;
-    auto cfg = std::make_unique<divans_lit_config>();
     for (;;) {
         const int code = model.command_type(nc, 0);
         if (cd.starved) return PARSE_CORRUPT;
         if (code == 0xf) break;
         if (code == 7) {
             // a second PredictionMode after literal bytes would change the literal coder's tables mid-stream:
-            // the batch kernels code one configuration per stream
+            // the literal-only path codes one configuration per stream
             if (seen_literal) return PARSE_UNSUPPORTED;
             if (!model.prediction_mode(nc, nullptr)) return PARSE_CORRUPT;
             have_pm = true;
@@ -769,22 +768,32 @@ ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int devi
         } else return PARSE_UNSUPPORTED;   // Copy / Dict / command- and distance- block switches
         if (cd.starved) return PARSE_CORRUPT;
     }
-    if (total == 0) return PARSE_OK;
-    if (have_pm) model.fill_lit_config(*cfg, btype);
+    ps.total = (size_t)total;
+    if (have_pm) model.fill_lit_config(ps.cfg, btype);
     else {   // LiteralBookKeeping::new defaults, codec/interface.rs:244-262
-        std::memset(cfg.get(), 0, sizeof(*cfg));
-        cfg->btype = btype;
-        for (auto& s : cfg->literal_adaptation) s = divans_speed{0x10, 0x2000};
+        std::memset(&ps.cfg, 0, sizeof(ps.cfg));
+        ps.cfg.btype = btype;
+        for (auto& s : ps.cfg.literal_adaptation) s = divans_speed{0x10, 0x2000};
     }
-    GpuCodecHandle h;
-    if (h.acquire(*cfg, device, (uint32_t)total)) return PARSE_GPU_ERROR;
     // the kernels read whole 32-bit words; LIT streams are 16 + 4k bytes per chunk by construction
-    std::vector<uint8_t> lit(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
-    if (lit.size() % 4) return PARSE_CORRUPT;
-    lit.resize(lit.size() + 64, 0);
-    const uint64_t off = 0; const uint32_t size = (uint32_t)(lit.size() - 64);
-    out.resize(total);
-    const int drc = divans_gpu_lit_decode_host(h.c, lit.data(), &off, &size, 1, out.data(), (uint32_t)total);
+    ps.lit.assign(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
+    if (ps.lit.size() % 4) return PARSE_CORRUPT;
+    if (total == 0 && !ps.lit.empty()) return PARSE_CORRUPT;
+    return PARSE_OK;
+}
+
+ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,
+                            size_t max_output) {
+    out.clear();
+    ParsedStream ps;
+    const ParseStatus st = parse_container_host(in, n, skip_crc, max_output, ps, consumed);
+    if (st != PARSE_OK || ps.total == 0) return st;
+    GpuCodecHandle h;
+    if (h.acquire(ps.cfg, device, (uint32_t)ps.total)) return PARSE_GPU_ERROR;
+    const uint64_t off = 0; const uint32_t size = (uint32_t)ps.lit.size();
+    ps.lit.resize(ps.lit.size() + 64, 0);
+    out.resize(ps.total);
+    const int drc = divans_gpu_lit_decode_host(h.c, ps.lit.data(), &off, &size, 1, out.data(), (uint32_t)ps.total);
     if (drc == DIVANS_GPU_ECORRUPT) { out.clear(); return PARSE_CORRUPT; }   // short / corrupt / mismatched LIT stream
     if (drc) return PARSE_GPU_ERROR;
     return PARSE_OK;

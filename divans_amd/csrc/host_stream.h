@@ -63,6 +63,10 @@ enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_U
 ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,
                             size_t max_output = (size_t)1 << 30);
 
+struct ParsedStream { divans_lit_config cfg; size_t total = 0; std::vector<uint8_t> lit; };
+// The host half of parse_container: framing + CRC + CMD coder; `ps` gets the LIT-coder bytes, the decoded size and the LIT configuration.
+ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed);
+
 uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n);   // src/codec/crc32.rs
 
 }  // namespace divans_host

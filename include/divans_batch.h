@@ -1,0 +1,61 @@
+/*
+ * divans_batch.h -- many complete .divans streams per call, with the two halves of a stream overlapped the way the
+ * reference's two-thread decoder overlaps them (src/parallel_decompressor.rs:55-141, src/threading.rs:88-100: a worker
+ * thread decodes the CMD stream while the main thread decodes the LIT stream): here the LIT coder of EVERY stream of the
+ * batch runs on the GPU in one launch sequence while host threads run the CMD coders (command types, PredictionMode,
+ * literal lengths, src/codec/mod.rs:652-792) and the Mux / header / CRC framing (src/mux.rs, src/codec/mod.rs:409-560).
+ * SURVEY.md section 8 row f4.  Streams are literal-only (the internal command selection, raw_to_cmd/mod.rs:105-181); every
+ * container is byte-identical to what divans_encode / divans_encode_flush of include/divans_ffi.h produce for the same
+ * input handed over in one divans_encode call.
+ */
+#ifndef DIVANS_BATCH_H_
+#define DIVANS_BATCH_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#include "divans_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct divans_batch_options {      /* DivansCompressorOptions fields the internal compressor reads, src/interface.rs:444-484 */
+    int32_t window_size;                   /* default 22 */
+    uint8_t dynamic_context_mixing;        /* default 1 */
+    uint8_t use_context_map;               /* default 1 */
+    uint8_t force_stride;                  /* 0..8, 9 = UseBrotliRec (default) */
+    uint8_t has_prior_depth, prior_depth;
+    uint8_t has_literal_adaptation;
+    divans_speed literal_adaptation[4];
+    uint32_t call_buffer_size;             /* output buffer a per-stream caller would pass to each call (Mux slicing); default 65536 */
+    int32_t device;                        /* HIP device */
+    int32_t host_threads;                  /* threads for the CMD coders and the framing; 0 = hardware concurrency */
+    uint8_t skip_crc;                      /* decompress only */
+} divans_batch_options;
+void divans_batch_options_default(divans_batch_options *o);
+
+typedef struct divans_batch_timing {       /* milliseconds, wall clock */
+    double total_ms;
+    double gpu_ms;            /* first copy in .. last copy out, as seen from the host (includes launch and copies) */
+    double host_overlapped_ms;/* host work done while the GPU was busy: CMD coders (compress) / container parsing (decompress) */
+    double host_serial_ms;    /* host work that had to wait for the GPU: Mux replay + framing (compress), output copies (decompress) */
+} divans_batch_timing;
+
+/* upper bound of the container size for an n-byte input */
+size_t divans_batch_compress_bound(size_t n);
+
+/* n_streams inputs -> n_streams containers written back to back into `out` (out_offsets[i], out_sizes[i]); `timing` may be NULL.
+ * 0 on success, a DIVANS_GPU_E* code otherwise (divans_gpu_last_error()). */
+int divans_batch_compress(const divans_batch_options *opt, const uint8_t *const *inputs, const size_t *sizes, size_t n_streams,
+                          uint8_t *out, size_t out_cap, size_t *out_offsets, size_t *out_sizes, divans_batch_timing *timing);
+
+/* n_streams complete containers -> their payloads back to back in `out`.  Streams whose PredictionMode / block type differ
+ * are grouped and decoded group by group.  Returns DIVANS_GPU_ECORRUPT when a container fails its CRC, framing or the LIT
+ * decoder's integrity check (out_sizes[i] of the first bad stream is set to (size_t)-1). */
+int divans_batch_decompress(const divans_batch_options *opt, const uint8_t *const *containers, const size_t *sizes, size_t n_streams,
+                            uint8_t *out, size_t out_cap, size_t *out_offsets, size_t *out_sizes, divans_batch_timing *timing);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

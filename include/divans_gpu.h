@@ -76,6 +76,13 @@ int divans_gpu_lit_encode_batch(divans_gpu_codec *c, const uint8_t *d_in, const 
                                 const uint32_t *d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                                 uint8_t *d_out, uint64_t out_slot, uint64_t *d_out_offsets, uint32_t *d_out_sizes);
 
+/* As divans_gpu_lit_encode_batch, additionally d_chunk_bytes[i * max_chunks + k] = coded bytes of the k-th 65 536-symbol
+ * chunk of stream i (the unit ANSEncoder hands to the Mux, src/ans.rs:331-378; callers zero the array first). */
+int divans_gpu_lit_encode_batch_chunks(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets,
+                                       const uint32_t *d_in_sizes, uint32_t stream_len, uint32_t n_streams,
+                                       uint8_t *d_out, uint64_t out_slot, uint64_t *d_out_offsets, uint32_t *d_out_sizes,
+                                       uint32_t *d_chunk_bytes, uint32_t max_chunks);
+
 /* Encoder pass 1 only: the adaptive model's output before entropy coding.  d_pairs receives, for stream i at
  * [i * 2 * M, i * 2 * M + 2 * len_i) with M = the codec's max_stream_len rounded up to even, one word
  * (start | freq << 16) per nibble in coding order (high nibble first) -- what ANSEncoder::put_start_freq is handed,

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Informational: complete-container rate of the batch ABI (include/divans_batch.h) from and to HOST memory, with the
+host/GPU overlap it achieves.  Never the bench `value`."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import divans_amd as da
+import workload
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+corpus = workload.load_corpus()
+blocks = workload.make_blocks(corpus, 0, n)
+inputs = [blocks[i] for i in range(n)]
+for mixing in (0, 2):
+    opts = da.batch_options(dynamic_context_mixing=mixing, use_context_map=0 if mixing == 0 else 1, force_stride=1 if mixing == 0 else 0, host_threads=threads)
+    da.batch_compress(inputs[:64], opts)          # warm-up (module load, allocations)
+    t0 = time.time(); cont, tc = da.batch_compress(inputs, opts); wall_c = time.time() - t0
+    t0 = time.time(); back, td = da.batch_decompress(cont, n * 65536, opts); wall_d = time.time() - t0
+    ok = all((back[i] == inputs[i]).all() for i in range(0, n, max(1, n // 64)))
+    raw = n * 65536
+    print(json.dumps({"streams": n, "dynamic_context_mixing": mixing, "round_trip_ok": ok, "container_bytes": int(sum(c.size for c in cont)),
+                      "compress": {k: round(v, 2) for k, v in tc.items()}, "decompress": {k: round(v, 2) for k, v in td.items()},
+                      "compress_MBps": round(raw / 1e6 / (tc["total_ms"] / 1e3), 1), "decompress_MBps": round(raw / 1e6 / (td["total_ms"] / 1e3), 1),
+                      "python_wall_s": [round(wall_c, 2), round(wall_d, 2)]}))

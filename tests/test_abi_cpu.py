@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(L, sym), sym
     # the reference's per-stream ABI (c/divans/ffi.h) and the IR host layer
-    for header, expect in (("divans_ffi.h", None), ("divans_ir.h", set(da.exported_ir_symbols()))):
+    for header, expect in (("divans_ffi.h", None), ("divans_ir.h", set(da.exported_ir_symbols())), ("divans_batch.h", set(da.exported_batch_symbols()))):
         decl = _declared(header)
         if expect is not None:
             assert set(decl) == expect
