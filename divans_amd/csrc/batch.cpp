@@ -194,7 +194,8 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     StreamGuard stream; HIP_OR_FAIL(hipStreamCreate(&stream.s));
     // Pipeline over slices of the batch: while the GPU decodes the LIT streams of slice k, host threads parse slice k + 1
     // (framing, CRC, CMD coder -> decoded sizes and LIT configuration, which the GPU launch needs).
-    const size_t n_slices = std::min<size_t>(4, n_streams);
+    // a slice should still fill the persistent decode grid (28 672 streams on MI355X): small batches are one slice
+    const size_t n_slices = std::max<size_t>(1, std::min<size_t>(4, n_streams / 16384));
     std::vector<divans_host::ParsedStream> parsed(n_streams);
     std::vector<int> status(n_streams, 0);
     double host_overlapped = 0, host_serial = 0, gpu_ms = 0;
