@@ -39,7 +39,7 @@ def _i64(v):
     return v - (1 << 64) if v >= (1 << 63) else v
 
 
-def device_blocks(torch, corpus_t, first, count, block_len, chunk=2048):
+def device_blocks(torch, corpus_t, first, count, block_len, chunk=8192):
     """tests/workload.make_blocks on the GPU (same bytes): block i = corpus[o_i : o_i + L], o_i = (i * 4099) mod
     (len - L), then L // 100 bytes XORed with a non-zero value, positions / values from xorshift64* seeded
     0x9E3779B97F4A7C15 ^ i.  int64 arithmetic wraps like uint64; logical right shifts are masked."""
@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per stream, 8 or 16 (tuning)")
     ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
+    ap.add_argument("--host-data", action="store_true", help="build the input with tests/workload.py on the host instead of on the GPU (same bytes; "
+                    "keeps the tens of thousands of small torch kernels of the GPU generator out of profiler runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--diag-data", choices=["corpus", "zeros", "random", "repeat1k"], default="corpus",
@@ -392,6 +394,11 @@ def main():
             mg = {"scatter_ms": round(sharding.max_over_ranks(scatter_s, dev) * 1e3, 3)}
             if rank != 0:
                 full = None
+        elif args.host_data:
+            d_in = torch.empty((N, L), dtype=torch.uint8, device=dev)
+            for c0 in range(0, N, 2048):
+                c1 = min(N, c0 + 2048)
+                d_in[c0:c1].copy_(torch.from_numpy(workload.make_blocks(corpus, first + c0, c1 - c0, block_len=L)))
         else:
             d_in = device_blocks(torch, corpus_t, first, N, L)
         # the GPU generator must be the committed workload (tests/workload.py), byte for byte

@@ -9,12 +9,14 @@ cd /tmp && export TMPDIR=/tmp
 run_config () {
   local CFG=$1; shift
   local FULL=$1; shift
-  local ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline"
+  local ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --host-data"
   local OUT=$REPO/gpurun_out/prof_$TAG/$CFG
   mkdir -p $OUT
   echo "python bench.py $ARGS" > $OUT/cmd.txt
+  if [ "${SKIP_TRACE:-0}" != "1" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $REPO/bench.py $ARGS > $OUT/bench_traced.json 2> $OUT/trace.log
   find $OUT/trace -name '*kernel_stats*' -exec cp {} $OUT/kernel_stats.csv \;
+  fi
   pmc_pass () {
     local name=$1; shift
     timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/pmc_$name -o pmc -- python $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.log
@@ -58,5 +60,7 @@ PY
 run_config simple 1
 run_config mixing 0
 run_config decode_only 0
+if [ "${SKIP_BENCH:-0}" != "1" ]; then
 cd $REPO && python bench.py > gpurun_out/prof_$TAG/bench_line.json 2> gpurun_out/prof_$TAG/bench_line.err
 tail -c 600 gpurun_out/prof_$TAG/bench_line.json
+fi
