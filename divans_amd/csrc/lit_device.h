@@ -24,6 +24,10 @@ __device__ __forceinline__ int row_bcast(int v) {
 __device__ __forceinline__ int row_prev_or_zero(int v) {
     return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR1, 0xf, 0xf, true);
 }
+// value of the next lane in the row, 0 for the last lane
+__device__ __forceinline__ int row_next_or_zero(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+}
 // value of lane (row_base + idx) -- idx is row-uniform but not compile-time
 __device__ __forceinline__ int row_gather(int v, int row_base_lane, int idx) {
     return __builtin_amdgcn_ds_bpermute((row_base_lane + idx) << 2, v);

@@ -217,6 +217,28 @@ struct WeightsPair {
     }
 };
 
+// Mixing paths: (start | freq << 16) of `sym` under the mixed row p, plus the frequencies of `sym` under the context-map row
+// and the stride row alone (wfreqs = cm freq | stride freq << 16, the Weights update's model_probs, literal.rs:236-239).
+// That is six quotients -- entries sym and sym-1 of three rows, each by its own row total (probability/interface.rs:97-108)
+// -- and they go through ONE division pass instead of three 16-entry ones: lanes 0/1 of the row take p, lanes 2/3 cm,
+// lanes 4/5 the stride row; even lanes entry sym, odd lanes entry sym-1 (0 when sym == 0).
+__device__ __forceinline__ uint32_t mixed_start_freq(int p, int cm, int st, int pmax, int cmax, int smax, int li, int rbase, int sym,
+                                                     uint32_t& wfreqs) {
+    const uint32_t pc = (uint32_t)p | ((uint32_t)cm << 16);
+    const int src = (rbase + sym - (li & 1)) << 2;
+    const uint32_t g_pc = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pc);
+    const uint32_t g_st = (uint32_t)__builtin_amdgcn_ds_bpermute(src, st);
+    const int which = li >> 1;
+    int num = which == 0 ? (int)(g_pc & 0xffffu) : (which == 1 ? (int)(g_pc >> 16) : (int)g_st);
+    num = ((li & 1) != 0 && sym == 0) ? 0 : num;
+    const int den = which == 0 ? pmax : (which == 1 ? cmax : smax);
+    const uint32_t q = scaled_div(num, den, biased_rcp15(den));
+    const int f = (int)q - row_next_or_zero((int)q) - 1;          // even lanes: freq of their row's entry
+    const uint32_t start = (uint32_t)row_bcast<1>((int)q) + 1u, freq = (uint32_t)row_bcast<0>(f);
+    wfreqs = ((uint32_t)row_bcast<2>(f) & 0xffffu) | ((uint32_t)row_bcast<4>(f) << 16);
+    return start | (freq << 16);
+}
+
 template <bool HIGH, int MM, bool MIX, int CACHE>
 __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const LdsView& lv, const Table<CACHE>& tb, int li, int rbase,
                                                  uint32_t ctx, uint64_t last8, uint32_t hi_nib, int sym, int mix_rate, uint32_t& wfreqs) {
@@ -229,14 +251,7 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
         int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
         int p = average_rows(cm, st, cmax, smax, mix_rate);
         int pmax = row_bcast<15>(p);
-        uint32_t dp = scaled_div(p, pmax, biased_rcp15(pmax));
-        uint32_t dc = scaled_div(cm, cmax, biased_rcp15(cmax));
-        uint32_t ds = scaled_div(st, smax, biased_rcp15(smax));
-        int dpp = row_prev_or_zero((int)dp), dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
-        uint32_t sf = (uint32_t)(dpp + 1) | ((uint32_t)((int)dp - dpp - 1) << 16);
-        uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
-        packed = (uint32_t)row_gather((int)sf, rbase, sym);
-        wfreqs = (uint32_t)row_gather((int)ff, rbase, sym);
+        packed = mixed_start_freq(p, cm, st, pmax, cmax, smax, li, rbase, sym, wfreqs);
         cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
         tb.store(cref, cm);
     } else {
@@ -557,19 +572,18 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const Ld
     const int rescaled = (int)((uint32_t)__umul24(slot, (uint32_t)mx) >> 15);
     const unsigned long long ge = __ballot(rescaled >= cv);
     const int sym = __popc((uint32_t)(ge >> rbase) & 0x7fffu);
-    const uint32_t d = scaled_div(cv, mx, biased_rcp15(mx));
-    const int dprev = row_prev_or_zero((int)d);
-    const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
-    const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
+    uint32_t packed;
+    if (MIX) packed = mixed_start_freq(cv, cm, st, mx, cmax, smax, li, rbase, sym, wfreqs);
+    else {
+        const uint32_t d = scaled_div(cv, mx, biased_rcp15(mx));
+        const int dprev = row_prev_or_zero((int)d);
+        const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
+        packed = (uint32_t)row_gather((int)sf, rbase, sym);
+    }
     const uint32_t start = packed & 0xffffu, freq = packed >> 16;
     // helper_advance_sym ans.rs:238: x = freq * (state >> 15) + (state & mask) - start
     S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;
     if (MIX) {
-        uint32_t dc = scaled_div(cm, cmax, biased_rcp15(cmax));
-        uint32_t ds = scaled_div(st, smax, biased_rcp15(smax));
-        int dcp = row_prev_or_zero((int)dc), dsp = row_prev_or_zero((int)ds);
-        uint32_t ff = ((uint32_t)((int)dc - dcp - 1) & 0xffffu) | ((uint32_t)((int)ds - dsp - 1) << 16);
-        wfreqs = (uint32_t)row_gather((int)ff, rbase, sym);
         wpmix = freq;
         cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
         tb.store(cref, cm);
