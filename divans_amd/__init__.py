@@ -119,6 +119,7 @@ def load_library():
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_lane_layout.argtypes = [vp, u32]
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
+    L.divans_gpu_codec_set_bucket_batch.argtypes = [vp, u32]
     L.divans_gpu_lit_model_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
@@ -156,7 +157,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_lit_model_batch",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
@@ -304,8 +305,12 @@ class LiteralCodec:
         _check(self._lib.divans_gpu_codec_set_geometry(self._h, int(blocks), cr), "set_geometry")
 
     def set_encode_path(self, path):
-        """0 automatic, 1 streaming model kernel, 2 bucketed model pass (order-1 configurations only)."""
+        """0 automatic, 1 streaming model kernel, 2 bucketed model pass (mixing value 4 everywhere, streams <= 64 KiB)."""
         _check(self._lib.divans_gpu_codec_set_encode_path(self._h, int(path)), "set_encode_path")
+
+    def set_bucket_batch(self, streams):
+        """streams per launch sequence of the bucketed two-model pass (tuning / test knob)"""
+        _check(self._lib.divans_gpu_codec_set_bucket_batch(self._h, int(streams)), "set_bucket_batch")
 
     def set_lane_layout(self, lanes_per_stream):
         _check(self._lib.divans_gpu_codec_set_lane_layout(self._h, int(lanes_per_stream)), "set_lane_layout")

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdivans_hip.so")
-SOURCES = ["lit_kernels.hip", "lit_kernels_p8.hip", "lit_bucket.hip", "capi.cpp", "host_stream.cpp", "ffi.cpp", "ir.cpp", "batch.cpp"]
+SOURCES = ["lit_kernels.hip", "lit_kernels_p8.hip", "lit_bucket.hip", "lit_bucket_mix.hip", "capi.cpp", "host_stream.cpp", "ffi.cpp", "ir.cpp", "batch.cpp"]
 
 
 def hipcc():

@@ -109,6 +109,8 @@ struct divans_gpu_codec {
     uint32_t* d_status = nullptr;
     // bucketed encoder model pass (lit_bucket.hip)
     bool bucket_ok = false;       // the configuration allows it: order-1, no context map, no mixing, streams <= 64 KiB
+    bool bucket_mix_ok = false;   // two-model configuration the bucketed pass of lit_bucket_mix.hip covers
+    uint32_t bucket_mix_batch = 32768;   // streams per launch sequence of that pass
     uint32_t encode_path = 0;     // 0 automatic (bucketed when bucket_ok), 1 streaming kernels, 2 bucketed
     uint8_t* d_bk = nullptr;      size_t bk_bytes = 0; uint32_t bk_streams = 0;
     uint8_t* d_rs = nullptr;      size_t rs_bytes = 0;
@@ -255,6 +257,8 @@ static void configure_from_geometry(divans_gpu_codec* c) {
         c->blocks = c->num_cus * std::max(1u, std::min(7u, fit));
     }
     c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && c->geom.ctx_const >= 0 && c->max_stream_len <= 65536u;
+    // both models' rows depend on (prev, ctx, high nibble) only when every mixing value is 4 (stride 1, literal.rs:184-192)
+    c->bucket_mix_ok = c->mix && c->geom.mm_uniform == 4 && c->geom.n_btypes == 1u && c->max_stream_len <= 65536u;
 }
 
 extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c);
@@ -305,13 +309,18 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
 }
 
 static uint32_t bucket_pieces(const divans_gpu_codec* c) { return (c->max_stream_len + 8191u) / 8192u; }
+// Optional pad (a multiple of 16 elements) between the stream slots of the bucketed passes' work arrays.  Measured: breaking
+// the power-of-two stride changes nothing (profiles/r02c), so it stays 0.
+constexpr uint32_t BUCKET_SLOT_PAD = 0;
+static uint32_t bucket_slot(const divans_gpu_codec* c) { return bucket_pieces(c) * 8192u + BUCKET_SLOT_PAD; }
+static bool use_bucket_mix(const divans_gpu_codec* c) { return c->bucket_mix_ok && c->encode_path != 1u; }
 static bool use_bucket(const divans_gpu_codec* c) { return c->bucket_ok && c->encode_path != 1u; }   // task ids are stream * 256 + byte in 32 bits: callers keep n_streams < 2^24
 
 // one allocation carved into the five work arrays of BucketBatch
 static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b) {
-    const size_t pl = (size_t)bucket_pieces(c) * 8192u;
+    const size_t pl = bucket_slot(c);
     const size_t n = n_streams;
-    const size_t sz_sfs = n * pl * 8u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 3u * 4u, sz_inv = n * pl * 2u, sz_sorted = n * pl;
+    const size_t sz_sfs = n * pl * 8u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 6u * 4u, sz_inv = n * pl * 2u, sz_sorted = n * pl;
     const size_t need = sz_sfs + sz_desc + sz_tasks + sz_inv + sz_sorted + 256u;
     if (need > c->bk_bytes) {
         if (c->d_bk) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_bk)); c->d_bk = nullptr; c->bk_bytes = 0; }
@@ -328,6 +337,29 @@ static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b
     return 0;
 }
 
+static int ensure_bucket_mix(divans_gpu_codec* c, uint32_t n_streams, MixBucketBatch& b) {
+    const size_t pl = bucket_slot(c);
+    const size_t n = n_streams;
+    const size_t sz_rec = n * pl * 8u, sz_pos = n * ((size_t)c->max_stream_len + BUCKET_SLOT_PAD) * 8u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 6u * 4u,
+                 sz_inv = n * pl * 2u, sz_sorted = n * pl * 2u;
+    const size_t need = 256u + 2u * sz_rec + 4u * sz_pos + sz_desc + sz_tasks + sz_inv + sz_sorted;
+    if (need > c->bk_bytes) {
+        if (c->d_bk) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_bk)); c->d_bk = nullptr; c->bk_bytes = 0; }
+        if (hipMalloc(&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed two-model encoder work arrays) failed");
+        c->bk_bytes = need;
+    }
+    uint8_t* p = c->d_bk;
+    b.counters = (uint32_t*)p; p += 256;
+    b.rec_high = (bk_u32x2*)p; p += sz_rec;
+    b.rec_low = (bk_u32x2*)p; p += sz_rec;
+    for (int i = 0; i < 4; ++i) { b.pos[i] = (bk_u32x2*)p; p += sz_pos; }
+    b.desc = (uint32_t*)p; p += sz_desc;
+    b.tasks = (uint32_t*)p; p += sz_tasks;
+    b.inv = (uint16_t*)p; p += sz_inv;
+    b.sorted = (uint16_t*)p;
+    return 0;
+}
+
 // Scratch of the chunk-parallel rANS pass: one chunk bound per stream plus a size word.  After the bucketed model pass
 // its sorted-order pair array is dead (bucket_unsort_kernel has read it) and is reused; otherwise a separate allocation.
 static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, RansBatch& r) {
@@ -335,7 +367,7 @@ static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, RansBatc
     const size_t need = (size_t)n_streams * stride + (size_t)n_streams * 4u + 64u;
     uint8_t* base = nullptr;
     if (use_bucket(c) && c->d_bk) {
-        const size_t pl = (size_t)bucket_pieces(c) * 8192u;
+        const size_t pl = bucket_slot(c);
         if ((size_t)n_streams * pl * 8u >= need && c->bk_bytes >= 256u + need) base = c->d_bk + 256;   // BucketBatch::sfs, see ensure_bucket
     }
     if (!base) {
@@ -372,9 +404,16 @@ extern "C" int divans_gpu_codec_set_block_types(divans_gpu_codec* c, uint32_t n_
 extern "C" int divans_gpu_codec_set_encode_path(divans_gpu_codec* c, uint32_t path) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (path > 2u) return fail(DIVANS_GPU_EINVAL, "path must be 0 (automatic), 1 (streaming) or 2 (bucketed)");
-    if (path == 2u && !c->bucket_ok)
-        return fail(DIVANS_GPU_EINVAL, "the bucketed encoder needs an order-1 configuration without context map or mixing and streams of at most 65536 bytes");
+    if (path == 2u && !c->bucket_ok && !c->bucket_mix_ok)
+        return fail(DIVANS_GPU_EINVAL, "the bucketed encoder needs mixing value 4 everywhere, streams of at most 65536 bytes and either no context map and no mixing or dynamic mixing with one literal block type");
     c->encode_path = path;
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_set_bucket_batch(divans_gpu_codec* c, uint32_t streams) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (streams == 0 || streams >= (1u << 24)) return fail(DIVANS_GPU_EINVAL, "bucket batch must be in [1, 2^24)");
+    c->bucket_mix_batch = streams;
     return 0;
 }
 
@@ -431,10 +470,33 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
         rc = ensure_bucket(c, n_streams, k); if (rc) return rc;
         k.in = d_in; k.in_offsets = d_in_offsets; k.in_sizes = d_in_sizes;
         k.n_streams = n_streams; k.stream_len = stream_len; k.max_stream_len = c->max_stream_len;
-        k.pieces = bucket_pieces(c);
+        k.pieces = bucket_pieces(c); k.slot = bucket_slot(c); k.sf_stride = 2u * c->max_stream_len;
         k.sf = c->d_sf; k.inc = c->geom.inc0; k.lim = c->geom.lim0;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         HIP_TRY(launch_bucket_model(k, c->num_cus * 4u, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        return 0;
+    }
+    if (use_bucket_mix(c) && !d_segs) {
+        MixBucketBatch k;
+        std::memset(&k, 0, sizeof(k));
+        // as many streams per launch sequence as the device has room for: a bucket is a serial chain, and the longest
+        // ones (half a stream under one context) only stop dominating a sequence when it holds streams by the ten thousand
+        uint32_t sub = std::min(n_streams, c->bucket_mix_batch);
+        while ((rc = ensure_bucket_mix(c, sub, k)) == DIVANS_GPU_ENOMEM && sub > 1024u) { (void)hipGetLastError(); sub = (sub + 1u) / 2u; }
+        if (rc) return rc;
+        k.blob = c->d_blob; k.stream_len = stream_len; k.max_stream_len = c->max_stream_len; k.pieces = bucket_pieces(c);
+        k.slot = bucket_slot(c); k.pos_stride = c->max_stream_len + BUCKET_SLOT_PAD;
+        k.inc0 = c->geom.inc0; k.lim0 = c->geom.lim0; k.inc2 = c->geom.inc2; k.lim2 = c->geom.lim2; k.inc3 = c->geom.inc3; k.lim3 = c->geom.lim3;
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        for (uint32_t s0 = 0; s0 < n_streams; s0 += sub) {
+            k.n_streams = std::min(sub, n_streams - s0);
+            k.in = d_in_offsets ? d_in : d_in + (size_t)s0 * stream_len;
+            k.in_offsets = d_in_offsets ? d_in_offsets + s0 : nullptr;
+            k.in_sizes = d_in_sizes ? d_in_sizes + s0 : nullptr;
+            k.sf = c->d_sf + (size_t)s0 * 2u * c->max_stream_len;
+            HIP_TRY(launch_bucket_mix_model(k, c->num_cus, c->stream));
+        }
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         return 0;
     }

@@ -12,22 +12,9 @@
 //   4. bucket_unsort_kernel  puts the (start,freq) pairs back into position order for the rANS pass.
 // The arithmetic per nibble is the same as everywhere else (probability/interface.rs:97-108, frequentist_cdf.rs:74-85).
 // The decoder cannot do this (it learns the bytes one at a time) and keeps the streaming kernels.
-#include "lit_device.h"
+#include "lit_bucket_dev.h"
 
 namespace divans_hip {
-
-constexpr uint32_t BK_PIECE = 8192;          // positions sorted together
-constexpr uint32_t BK_SORT_THREADS = 256;
-constexpr uint32_t BK_LANE_DWORDS = 148;     // 17 rows x 8 dwords + 8 descriptors, padded: 16-byte aligned and the
-                                             // 64 lanes' b128 accesses at equal offsets cover all 32 banks
-constexpr uint32_t BK_DESC_DW = 136;
-constexpr uint32_t BK_TAB_DW = 64 * BK_LANE_DWORDS;
-constexpr uint32_t BK_VALID = 1u << 31;
-constexpr uint32_t BK_WINDOW = 256;          // tasks a wave reserves per atomic
-
-__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
 
 // ---------------------------------------------------------------------------------------------
 // 1. per (stream, piece): sorted[slot] = byte, inv[pos] = slot, desc[stream][prev][piece] = start | count << 16
@@ -45,7 +32,7 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const Buck
     const uint32_t base = piece * BK_PIECE;
     if (base >= len) { *desc = 0u; return; }
     const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
-    const size_t pl = (size_t)b.pieces * BK_PIECE;
+    const size_t pl = b.slot;
     for (uint32_t i = tid; i < 1024u; i += BK_SORT_THREADS) (&hist[0][0])[i] = 0u;
     // the piece (and the byte before it: the first key) once into LDS, 16 bytes per lane where alignment allows
     {
@@ -114,10 +101,10 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void bucket_sort_kernel(const Buck
 // 2. task lists by bucket size class, so that the long chains start first
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bucket_tasks_kernel(const BucketBatch b) {
-    __shared__ uint32_t cnt[3], basev[3];
+    __shared__ uint32_t cnt[BK_CLASSES], basev[BK_CLASSES];
     const uint32_t t = blockIdx.x * 1024u + threadIdx.x;      // stream * 256 + prev
     const uint32_t cap = b.n_streams * 256u;
-    if (threadIdx.x < 3u) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < BK_CLASSES) cnt[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t tot = 0;
     if (t < cap) {
@@ -125,10 +112,10 @@ __global__ __launch_bounds__(1024) void bucket_tasks_kernel(const BucketBatch b)
         const u32x4 d0 = d[0], d1 = d[1];
         tot = (d0.x >> 16) + (d0.y >> 16) + (d0.z >> 16) + (d0.w >> 16) + (d1.x >> 16) + (d1.y >> 16) + (d1.z >> 16) + (d1.w >> 16);
     }
-    const int cls = tot == 0u ? -1 : (tot >= 2048u ? 0 : (tot >= 64u ? 1 : 2));
+    const int cls = bk_class_of(tot);
     // slot inside the block: one LDS atomic per wave and class, then one global atomic per block and class
     uint32_t local = 0;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < (int)BK_CLASSES; ++c) {
         const unsigned long long m = __ballot(cls == c);
         if (m == 0ull) continue;
         const int leader = __ffsll((long long)m) - 1;
@@ -138,7 +125,7 @@ __global__ __launch_bounds__(1024) void bucket_tasks_kernel(const BucketBatch b)
         if (cls == c) local = wbase + lanes_below(m);
     }
     __syncthreads();
-    if (threadIdx.x < 3u) basev[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&b.counters[threadIdx.x], cnt[threadIdx.x]) : 0u;
+    if (threadIdx.x < BK_CLASSES) basev[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&b.counters[threadIdx.x], cnt[threadIdx.x]) : 0u;
     __syncthreads();
     if (cls >= 0) b.tasks[(size_t)cls * cap + basev[cls] + local] = t;
 }
@@ -146,41 +133,6 @@ __global__ __launch_bounds__(1024) void bucket_tasks_kernel(const BucketBatch b)
 // ---------------------------------------------------------------------------------------------
 // 3. chains
 // ---------------------------------------------------------------------------------------------
-// One nibble against a row of 8 dwords (16 x u16) in LDS, split into phases so that the two nibbles of a byte
-// (different rows) can be in flight together: read, pack (start | freq << 16), blend, write.
-struct BkRow { u32x4 w0, w1, a0, a1; int chi, cprev; };
-
-__device__ __forceinline__ BkRow bk_read(const uint32_t* row, const uint32_t* tab, uint32_t sym) {
-    BkRow r;
-    r.w0 = *(const u32x4*)row; r.w1 = *(const u32x4*)(row + 4);
-    const uint16_t* r16 = (const uint16_t*)row;
-    r.chi = r16[sym];
-    r.cprev = r16[sym ? sym - 1u : 0u];
-    r.a0 = *(const u32x4*)(tab + sym * 8u); r.a1 = *(const u32x4*)(tab + sym * 8u + 4u);
-    return r;
-}
-__device__ __forceinline__ uint32_t bk_pack(const BkRow& r, uint32_t sym) {     // probability/interface.rs:97-108
-    const int mx = (int)(r.w1.w >> 16);
-    const int clo = sym ? r.cprev : 0;
-    const float rcp = biased_rcp15(mx);
-    const uint32_t dhi = scaled_div(r.chi, mx, rcp), dlo = scaled_div(clo, mx, rcp);
-    return (dlo + 1u) | ((dhi - dlo - 1u) << 16);
-}
-__device__ __forceinline__ void bk_renorm(BkRow& r) {                           // frequentist_cdf.rs:79-84, both halves at once
-    const u32x4 b0 = {1u | (2u << 16), 3u | (4u << 16), 5u | (6u << 16), 7u | (8u << 16)};
-    const u32x4 b1 = {9u | (10u << 16), 11u | (12u << 16), 13u | (14u << 16), 15u | (16u << 16)};
-    const u32x4 t0 = r.w0 + b0, t1 = r.w1 + b1;
-    r.w0 = t0 - ((t0 >> 2) & 0x3fff3fffu);
-    r.w1 = t1 - ((t1 >> 2) & 0x3fff3fffu);
-}
-
-__device__ __forceinline__ void bk_store_quad(u32x4* p, u32x4 v) {     // 8-byte aligned is enough for a global store
-    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void bk_store_pair(u32x2* p, u32x2 v) {
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
-
 __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
     const uint32_t lane = threadIdx.x;
@@ -193,10 +145,10 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
         tab[i] = (2u * k >= sym ? inc : 0u) | (2u * k + 1u >= sym ? inc << 16 : 0u);
     }
     __syncthreads();
-    const size_t pl = (size_t)b.pieces * BK_PIECE;
+    const size_t pl = b.slot;
     const uint32_t cap = b.n_streams * 256u;
-    const uint32_t n0 = b.counters[0], n1 = b.counters[1], n2 = b.counters[2];
-    const uint32_t total = n0 + n1 + n2;
+    BkTaskLists lists; lists.load(b.counters);
+    const uint32_t total = lists.total();
     const u32x4 def0 = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
     const u32x4 def1 = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
 
@@ -207,7 +159,8 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     uint32_t nt_stage = 0, nt_tid = 0;
     u32x4 nd0 = {0u, 0u, 0u, 0u}, nd1 = {0u, 0u, 0u, 0u};
     // wave-uniform task window
-    uint32_t win_cur = 0, win_end = 0, nxt_val = 0;
+    uint32_t win_cur = 0, win_end = 0, nxt_val = 0, nxt_w = 0;
+    const uint32_t long_end = lists.ends[3];     // tasks of at least 2048 positions come first
     bool nxt_pending = false, drained = false;
     // four bytes in flight per lane: requested one loop iteration before they are coded
     uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -218,7 +171,7 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     // vmcnt(3) for a byte requested four steps earlier instead of draining the queue (a visible store next to the
     // loads makes it fall back to vmcnt(0) on this target).  The hidden stores can only make that wait stricter.
 #define BK_OPAQUE(X) asm volatile("" : "+v"(X))
-#define BK_STEP(E, A, PV, PA)                                                                                   \
+#define BK_STEP(E, A, PV, PA, POS)                                                                                 \
     {                                                                                                   \
         BK_OPAQUE(E);  /* keeps the compiler from touching the byte (and waiting for it) before this point */ \
         PA = A;                                                                                         \
@@ -242,7 +195,8 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
             if (adv && more) { left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece; }       \
             if (adv && !more) { has_task = false; fresh_finish = true; }                                \
         }                                                                                               \
-        const bool fetch_ = has_task && left != 0u;                                                     \
+        /* slot idx is only taken by step idx % 4 of a group: the group's four pairs then fill one aligned 32-byte sector */ \
+        const bool fetch_ = has_task && left != 0u && (idx & 3u) == POS;                                \
         const uint8_t* lp = fetch_ ? cur_sorted + (idx & ~3u) : b.sorted;                               \
         const uint32_t nxt_a = fetch_ ? (idx | ((idx & 3u) << 16) | BK_VALID) : 0u;                     \
         idx += fetch_ ? 1u : 0u; left -= fetch_ ? 1u : 0u;                                              \
@@ -255,7 +209,7 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
 #define BK_FOUR(E0, A0, E1, A1, E2, A2, E3, A3)                                                         \
         {                                                                                               \
             u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0; uint32_t pa0, pa1, pa2, pa3;         \
-            BK_STEP(E0, A0, pv0, pa0) BK_STEP(E1, A1, pv1, pa1) BK_STEP(E2, A2, pv2, pa2) BK_STEP(E3, A3, pv3, pa3) \
+            BK_STEP(E0, A0, pv0, pa0, 0u) BK_STEP(E1, A1, pv1, pa1, 1u) BK_STEP(E2, A2, pv2, pa2, 2u) BK_STEP(E3, A3, pv3, pa3, 3u) \
             const uint32_t i0 = pa0 & 0xffffu;                                                          \
             const bool run4 = (pa0 & pa1 & pa2 & pa3 & BK_VALID) && (pa1 & 0xffffu) == i0 + 1u && (pa2 & 0xffffu) == i0 + 2u && (pa3 & 0xffffu) == i0 + 3u; \
             if (run4) {                                                                                 \
@@ -299,22 +253,24 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
                 const uint32_t basev = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_val);
                 nxt_pending = false;
                 if (basev >= total) { drained = true; win_cur = win_end = total; }
-                else { win_cur = basev; win_end = basev + BK_WINDOW < total ? basev + BK_WINDOW : total; }
+                else { win_cur = basev; win_end = basev + nxt_w < total ? basev + nxt_w : total; }
             }
             const uint32_t avail = win_end - win_cur, asked = (uint32_t)__popcll(wm);
             const uint32_t rank = lanes_below(wm);
             if (want) {
                 if (rank < avail) {
                     const uint32_t t = win_cur + rank;
-                    const uint32_t* src = t < n0 ? b.tasks + t : (t < n0 + n1 ? b.tasks + cap + (t - n0) : b.tasks + 2u * (size_t)cap + (t - n0 - n1));
-                    nt_tid = *src;
+                    nt_tid = *lists.at(b.tasks, cap, t);
                     nt_stage = 1u;
                 } else if (drained) exhausted = true;
             }
             win_cur += asked < avail ? asked : avail;
         }
-        if (!nxt_pending && !drained && win_end - win_cur < BK_WINDOW / 2u) {
-            if (lane == 0u) nxt_val = atomicAdd(&b.counters[3], BK_WINDOW);
+        // long buckets are handed out 64 at a time: a wave that reserved 256 of them would run four per lane back to back
+        const uint32_t want_w = win_end < long_end ? 64u : BK_WINDOW;
+        if (!nxt_pending && !drained && win_end - win_cur < want_w / 2u) {
+            nxt_w = want_w;
+            if (lane == 0u) nxt_val = atomicAdd(&b.counters[BK_CLAIM], want_w);
             nxt_pending = true;
         }
         const bool done = !has_task && !bytes_in_flight && nt_stage == 0u && exhausted;
@@ -334,19 +290,27 @@ __global__ __launch_bounds__(1024) void bucket_unsort_kernel(const BucketBatch b
     const uint32_t base = piece * BK_PIECE;
     if (base >= len) return;
     const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
-    const size_t pl = (size_t)b.pieces * BK_PIECE;
+    const size_t pl = b.slot;
     const u32x2* src = b.sfs + (size_t)s * pl + base;
     for (uint32_t i = threadIdx.x; i < n; i += 1024u) buf[i] = __builtin_nontemporal_load(src + i);
     __syncthreads();
     const uint16_t* inv = b.inv + (size_t)s * pl + base;
-    u32x2* dst = (u32x2*)(b.sf + (size_t)s * 2u * b.max_stream_len) + base;
+    u32x2* dst = (u32x2*)(b.sf + (size_t)s * b.sf_stride) + base;
     for (uint32_t i = threadIdx.x; i < n; i += 1024u) dst[i] = buf[inv[i]];
 }
 
 uint32_t bucket_chain_lds_bytes() { return (64u * BK_LANE_DWORDS + 128u) * 4u; }
 
+// steps 2 and 4 on their own, for the two-model pass (lit_bucket_mix.hip) that brings its own sort and chain kernels
+void launch_bucket_tasks(const BucketBatch& b, hipStream_t st) {
+    hipLaunchKernelGGL(bucket_tasks_kernel, dim3((b.n_streams + 3u) / 4u), dim3(1024), 0, st, b);
+}
+void launch_bucket_unsort(const BucketBatch& b, hipStream_t st) {
+    hipLaunchKernelGGL(bucket_unsort_kernel, dim3(b.n_streams * b.pieces), dim3(1024), 0, st, b);
+}
+
 hipError_t launch_bucket_model(const BucketBatch& b, uint32_t chain_blocks, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(b.counters, 0, 16, st);
+    hipError_t e = hipMemsetAsync(b.counters, 0, 64, st);
     if (e != hipSuccess) return e;
     if (b.pieces < 8u) {
         e = hipMemsetAsync(b.desc, 0, (size_t)b.n_streams * 256u * 8u * sizeof(uint32_t), st);

@@ -1,0 +1,404 @@
+// lit_bucket_mix.hip -- bucketed model pass of the ENCODER for the two-model configuration (BASELINE configs[2],
+// reference TestContextMixing, bin/benchmark.rs:156-167): context map on, every mixing value 4, dynamic mixing.
+//
+// Each nibble is coded with the weighted average of two rows (codec/literal.rs:209-241):
+//   stride model   high nibble: row [ctx][prev]      low nibble: row [prev][hi]       blended with literal_adaptation[0]
+//   context model  high nibble: row First[ctx]       low nibble: row Second[hi][ctx]  blended with literal_adaptation[3] / [2]
+// and the weights of the average follow from how well each model did on the symbols before (codec/weights.rs:23-38).
+// A row's CDF depends only on the earlier positions that used the same row -- never on the weights -- so the rows
+// can be walked bucket by bucket exactly as in lit_bucket.hip, once per model:
+//   stride model:  buckets keyed by prev  (up to 8 high rows, one per class of prev_prev that reaches a different ctx, + 16 low rows)
+//   context model: buckets keyed by ctx   (1 high row + 16 low rows)
+// Instead of (start, freq) a chain lane leaves the three raw counts mixing needs: {cdf[sym] | cdf[sym-1] << 16, cdf[15]}.
+// After both models' records are back in position order, mix_weights_kernel runs the only serial part that is left --
+// the per-stream Weights recursion, one lane per (stream, nibble half): average (probability/frequentist_cdf.rs:58-72)
+// of the three entries, the six divisions of sym_to_start_and_freq (probability/interface.rs:97-108), Weights::update.
+#include "lit_bucket_dev.h"
+
+namespace divans_hip {
+
+template <int MODEL> struct MxGeom {
+    static constexpr uint32_t NH = MODEL == 0 ? 8u : 1u;            // high-nibble rows of a bucket
+    static constexpr uint32_t NR = NH + 16u;
+    static constexpr uint32_t DESC_DW = NR * 8u;
+    // rows + 8 descriptors, padded so that the 64 lanes' b128 accesses at equal offsets cover all 32 banks
+    static constexpr uint32_t LANE_DW = MODEL == 0 ? 204u : 148u;
+    static constexpr uint32_t LDS_BYTES = (64u * LANE_DW + 256u) * 4u;
+};
+
+// ---------------------------------------------------------------------------------------------
+// 1. per (stream, piece): sorted[slot] = byte | high-row slot << 8, inv[pos] = slot, desc[stream][key][piece]
+//    MODEL 0 (stride): key = prev.  MODEL 1 (context map): key = ctx (literal.rs:87-117 through the fused table).
+// ---------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(BK_SORT_THREADS) void mix_sort_kernel(const MixBucketBatch b) {
+    __shared__ __attribute__((aligned(16))) uint16_t staging[BK_PIECE];
+    __shared__ __attribute__((aligned(16))) uint8_t piece_in[16 + BK_PIECE];   // piece_in[14], [15] = the two bytes before the piece
+    __shared__ uint16_t kp[BK_PIECE];                                          // key | high-row slot << 8 of every position
+    __shared__ uint32_t hist[4][256];
+    __shared__ uint32_t scan[256];
+    __shared__ uint8_t lut1c[256], ctxf[2048], slot_of[2048];
+    const uint32_t s = blockIdx.x / b.pieces, piece = blockIdx.x % b.pieces;
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
+    const uint8_t* in = b.in + (b.in_offsets ? b.in_offsets[s] : (uint64_t)s * b.stream_len);
+    uint32_t* desc = b.desc + ((size_t)s * 256u + tid) * 8u + piece;
+    const uint32_t base = piece * BK_PIECE;
+    if (base >= len) { *desc = 0u; return; }
+    const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
+    const size_t pl = b.slot;
+    for (uint32_t i = tid; i < 1024u; i += BK_SORT_THREADS) (&hist[0][0])[i] = 0u;
+    lut1c[tid] = b.blob[LIT_BLOB_LUT1CLASS + tid];
+    for (uint32_t i = tid; i < 2048u; i += BK_SORT_THREADS) ctxf[i] = b.blob[LIT_BLOB_CTXF + i];
+    {
+        const uint8_t* src = in + base;
+        if ((((uintptr_t)src) & 15u) == 0u) {
+            for (uint32_t i = tid * 16u; i < n; i += BK_SORT_THREADS * 16u) {
+                if (i + 16u <= n) *(u32x4*)(piece_in + 16u + i) = *(const u32x4*)(src + i);
+                else for (uint32_t k = i; k < n; ++k) piece_in[16u + k] = src[k];
+            }
+        } else {
+            for (uint32_t i = tid; i < n; i += BK_SORT_THREADS) piece_in[16u + i] = src[i];
+        }
+        if (tid == 0u) { piece_in[15] = base ? in[base - 1u] : 0u; piece_in[14] = base ? in[base - 2u] : 0u; }   // last_8_literals starts at zero
+    }
+    __syncthreads();
+    // classes of prev_prev that reach the same context share a high row: slot = the first such class
+    if (MODEL == 0) {
+        for (uint32_t i = tid; i < 2048u; i += BK_SORT_THREADS) {
+            const uint32_t row = i & ~7u; const uint8_t c = ctxf[i];
+            uint32_t k = 0; while (ctxf[row + k] != c) ++k;
+            slot_of[i] = (uint8_t)k;
+        }
+        __syncthreads();
+    }
+    // wave w owns positions [2048 w, 2048 w + 2048) of the piece and visits them in order, 64 at a time
+    for (uint32_t bt = 0; bt < 32u; ++bt) {
+        const uint32_t p = w * 2048u + bt * 64u + lane;
+        if (p < n) {
+            const uint32_t prev = piece_in[15u + p], e = (prev << 3) + lut1c[piece_in[14u + p]];
+            const uint32_t key = MODEL == 0 ? prev : ctxf[e];
+            kp[p] = (uint16_t)(key | (MODEL == 0 ? (uint32_t)slot_of[e] << 8 : 0u));
+            atomicAdd(&hist[w][key], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t c0 = hist[0][tid], c1 = hist[1][tid], c2 = hist[2][tid], c3 = hist[3][tid];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    scan[tid] = tot;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const uint32_t v = tid >= d ? scan[tid - d] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t start = scan[tid] - tot;
+    hist[0][tid] = start; hist[1][tid] = start + c0; hist[2][tid] = start + c0 + c1; hist[3][tid] = start + c0 + c1 + c2;
+    *desc = start | (tot << 16);
+    __syncthreads();
+    uint16_t* inv = b.inv + (size_t)s * pl + base;
+    for (uint32_t bt = 0; bt < 32u; ++bt) {
+        const uint32_t p = w * 2048u + bt * 64u + lane;
+        const bool valid = p < n;
+        const uint32_t k = valid ? kp[p] : 0u;
+        const uint32_t key = k & 0xffu;
+        const uint32_t pay = valid ? (uint32_t)piece_in[16u + p] | (k & 0xff00u) : 0u;
+        unsigned long long same = __ballot(valid);
+        for (uint32_t bit = 0; bit < 8u; ++bit) {
+            const bool set = (key >> bit) & 1u;
+            const unsigned long long bb = __ballot(set);
+            same &= set ? bb : ~bb;
+        }
+        const uint32_t rank = lanes_below(same), cnt = (uint32_t)__popcll(same);
+        if (valid) {
+            const uint32_t off = hist[w][key];
+            staging[off + rank] = (uint16_t)pay;
+            inv[p] = (uint16_t)(off + rank);
+            if (rank == cnt - 1u) hist[w][key] = off + cnt;   // the wave's LDS accesses stay in program order
+        }
+    }
+    __syncthreads();
+    uint16_t* sorted = b.sorted + (size_t)s * pl + base;
+    for (uint32_t i = tid * 8u; i < n; i += BK_SORT_THREADS * 8u) {
+        if (i + 8u <= n) *(u32x4*)(sorted + i) = *(const u32x4*)(staging + i);
+        else for (uint32_t k = i; k < n; ++k) sorted[k] = staging[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. chains: one lane per bucket, rows in LDS, raw counts out.  Same skeleton as bucket_chain_kernel (task window,
+//    eight loads in flight per lane, hidden stores); see there for why it is written the way it is.
+// ---------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(256) void mix_chain_kernel(const MixBucketBatch b) {
+    using G = MxGeom<MODEL>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* my = lds32 + threadIdx.x * G::LANE_DW;
+    uint32_t* mydesc = my + G::DESC_DW;
+    uint32_t* tabh = lds32 + blockDim.x * G::LANE_DW;
+    uint32_t* tabl = tabh + 128u;
+    const uint32_t inch = (uint32_t)(MODEL == 0 ? b.inc0 : b.inc3), incl = (uint32_t)(MODEL == 0 ? b.inc0 : b.inc2);   // literal.rs:320,354 / :242
+    const int limh = MODEL == 0 ? b.lim0 : b.lim3, liml = MODEL == 0 ? b.lim0 : b.lim2;
+    for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) {
+        const uint32_t sym = i >> 3, k = i & 7u;
+        tabh[i] = (2u * k >= sym ? inch : 0u) | (2u * k + 1u >= sym ? inch << 16 : 0u);
+        tabl[i] = (2u * k >= sym ? incl : 0u) | (2u * k + 1u >= sym ? incl << 16 : 0u);
+    }
+    __syncthreads();
+    const size_t pl = b.slot;
+    const uint32_t cap = b.n_streams * 256u;
+    BkTaskLists lists; lists.load(b.counters);
+    const uint32_t total = lists.total();
+    const u32x4 def0 = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
+    const u32x4 def1 = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
+
+    bool has_task = false, fresh_finish = false, exhausted = false;
+    uint32_t piece = 0, left = 0, idx = 0;
+    u32x2* cur_h = b.rec_high; u32x2* cur_l = b.rec_low; const uint16_t* cur_sorted = b.sorted;
+    uint32_t nt_stage = 0, nt_tid = 0;
+    u32x4 nd0 = {0u, 0u, 0u, 0u}, nd1 = {0u, 0u, 0u, 0u};
+    uint32_t win_cur = 0, win_end = 0, nxt_val = 0, nxt_w = 0;
+    const uint32_t long_end = lists.ends[3];     // tasks of at least 2048 positions come first
+    bool nxt_pending = false, drained = false;
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t e4 = 0, e5 = 0, e6 = 0, e7 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+
+#define MX_OPAQUE(X) asm volatile("" : "+v"(X))
+#define MX_STEP(E, A, RH, RL, PA, POS)                                                                      \
+    {                                                                                                   \
+        MX_OPAQUE(E);                                                                                   \
+        PA = A;                                                                                         \
+        if (A & BK_VALID) {                                                                             \
+            const uint32_t pay = E >> ((A >> 12) & 16u);     /* A bit 16: which half of the aligned word */ \
+            const uint32_t hi = (pay >> 4) & 15u, lo = pay & 15u;                                       \
+            uint32_t* rowh = MODEL == 0 ? my + ((pay >> 5) & 0x38u) : my;   /* 8 dwords x slot (bits 8..10) */ \
+            uint32_t* rowl = my + 8u * (G::NH + hi);                                                    \
+            BkRow H = bk_read(rowh, tabh, hi), L = bk_read(rowl, tabl, lo);                             \
+            const u32x2 vh = {(uint32_t)H.chi | (hi ? (uint32_t)H.cprev << 16 : 0u), H.w1.w >> 16};     \
+            const u32x2 vl = {(uint32_t)L.chi | (lo ? (uint32_t)L.cprev << 16 : 0u), L.w1.w >> 16};     \
+            H.w0 += H.a0; H.w1 += H.a1; L.w0 += L.a0; L.w1 += L.a1;   /* frequentist_cdf.rs:75-78 */    \
+            if ((int)(H.w1.w >> 16) >= limh) bk_renorm(H);                                              \
+            if ((int)(L.w1.w >> 16) >= liml) bk_renorm(L);                                              \
+            *(u32x4*)rowh = H.w0; *(u32x4*)(rowh + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
+            RH = vh; RL = vl;                                                                           \
+        }                                                                                               \
+        {                                                                                               \
+            const bool adv = has_task && left == 0u, more = piece < b.pieces;                           \
+            const uint32_t d = mydesc[piece & 7u];                                                      \
+            if (adv && more) { left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece; }       \
+            if (adv && !more) { has_task = false; fresh_finish = true; }                                \
+        }                                                                                               \
+        /* slot idx is only taken by step idx % 4 of a group: the group's records then start on a 32-byte boundary */ \
+        const bool fetch_ = has_task && left != 0u && (idx & 3u) == POS;                                \
+        const uint16_t* lp = fetch_ ? cur_sorted + (idx & ~1u) : b.sorted;                              \
+        const uint32_t nxt_a = fetch_ ? (idx | ((idx & 1u) << 16) | BK_VALID) : 0u;                     \
+        idx += fetch_ ? 1u : 0u; left -= fetch_ ? 1u : 0u;                                              \
+        E = *(const uint32_t*)lp; A = nxt_a;                                                            \
+    }
+
+    for (;;) {
+#define MX_FOUR(E0, A0, E1, A1, E2, A2, E3, A3)                                                         \
+        {                                                                                               \
+            u32x2 h0 = {0u, 0u}, h1 = h0, h2 = h0, h3 = h0, l0 = h0, l1 = h0, l2 = h0, l3 = h0;         \
+            uint32_t pa0, pa1, pa2, pa3;                                                                \
+            MX_STEP(E0, A0, h0, l0, pa0, 0u) MX_STEP(E1, A1, h1, l1, pa1, 1u) MX_STEP(E2, A2, h2, l2, pa2, 2u) MX_STEP(E3, A3, h3, l3, pa3, 3u) \
+            const uint32_t i0 = pa0 & 0xffffu;                                                          \
+            const bool run4 = (pa0 & pa1 & pa2 & pa3 & BK_VALID) && (pa1 & 0xffffu) == i0 + 1u && (pa2 & 0xffffu) == i0 + 2u && (pa3 & 0xffffu) == i0 + 3u; \
+            if (run4) {                                                                                 \
+                const u32x4 ha = {h0.x, h0.y, h1.x, h1.y}, hb = {h2.x, h2.y, h3.x, h3.y};               \
+                const u32x4 la = {l0.x, l0.y, l1.x, l1.y}, lb = {l2.x, l2.y, l3.x, l3.y};               \
+                bk_store_quad((u32x4*)(cur_h + i0), ha); bk_store_quad((u32x4*)(cur_h + i0 + 2u), hb); \
+                bk_store_quad((u32x4*)(cur_l + i0), la); bk_store_quad((u32x4*)(cur_l + i0 + 2u), lb); \
+            } else {                                                                                    \
+                if (pa0 & BK_VALID) { bk_store_pair(cur_h + i0, h0); bk_store_pair(cur_l + i0, l0); }   \
+                if (pa1 & BK_VALID) { bk_store_pair(cur_h + (pa1 & 0xffffu), h1); bk_store_pair(cur_l + (pa1 & 0xffffu), l1); } \
+                if (pa2 & BK_VALID) { bk_store_pair(cur_h + (pa2 & 0xffffu), h2); bk_store_pair(cur_l + (pa2 & 0xffffu), l2); } \
+                if (pa3 & BK_VALID) { bk_store_pair(cur_h + (pa3 & 0xffffu), h3); bk_store_pair(cur_l + (pa3 & 0xffffu), l3); } \
+            }                                                                                           \
+        }
+        MX_FOUR(e0, a0, e1, a1, e2, a2, e3, a3)
+        MX_FOUR(e4, a4, e5, a5, e6, a6, e7, a7)
+#undef MX_FOUR
+        const bool bytes_in_flight = fresh_finish;
+        if (!has_task) {
+            if (fresh_finish) fresh_finish = false;
+            else if (nt_stage == 3u) {
+                MX_OPAQUE(nd0); MX_OPAQUE(nd1);
+                *(u32x4*)mydesc = nd0; *(u32x4*)(mydesc + 4) = nd1;
+                for (uint32_t r = 0; r < G::NR; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
+                const size_t slot = (size_t)(nt_tid >> 8) * pl;
+                cur_h = b.rec_high + slot; cur_l = b.rec_low + slot; cur_sorted = b.sorted + slot;
+                piece = 0u; left = 0u; has_task = true; nt_stage = 0u;
+            }
+        }
+        const bool want = nt_stage == 0u && !exhausted;
+        if (nt_stage == 2u) nt_stage = 3u;
+        else if (nt_stage == 1u) {
+            MX_OPAQUE(nt_tid);
+            const u32x4* dp = (const u32x4*)(b.desc + (size_t)nt_tid * 8u);
+            nd0 = dp[0]; nd1 = dp[1];
+            nt_stage = 2u;
+        }
+        const unsigned long long wm = __ballot(want);
+        if (wm) {
+            if (win_cur == win_end && nxt_pending) {
+                MX_OPAQUE(nxt_val);
+                const uint32_t basev = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_val);
+                nxt_pending = false;
+                if (basev >= total) { drained = true; win_cur = win_end = total; }
+                else { win_cur = basev; win_end = basev + nxt_w < total ? basev + nxt_w : total; }
+            }
+            const uint32_t avail = win_end - win_cur, asked = (uint32_t)__popcll(wm);
+            const uint32_t rank = lanes_below(wm);
+            if (want) {
+                if (rank < avail) {
+                    const uint32_t t = win_cur + rank;
+                    nt_tid = *lists.at(b.tasks, cap, t);
+                    nt_stage = 1u;
+                } else if (drained) exhausted = true;
+            }
+            win_cur += asked < avail ? asked : avail;
+        }
+        // long buckets are handed out 64 at a time: a wave that reserved 256 of them would run four per lane back to back
+        const uint32_t want_w = win_end < long_end ? 64u : BK_WINDOW;
+        if (!nxt_pending && !drained && win_end - win_cur < want_w / 2u) {
+            nxt_w = want_w;
+            if (lane == 0u) nxt_val = atomicAdd(&b.counters[BK_CLAIM], want_w);
+            nxt_pending = true;
+        }
+        const bool done = !has_task && !bytes_in_flight && nt_stage == 0u && exhausted;
+        if (__ballot(!done) == 0ull) break;
+    }
+#undef MX_STEP
+#undef MX_OPAQUE
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5. the Weights recursion: one lane per (stream, nibble half).  model_weights[1] belongs to the high nibbles and
+//    model_weights[0] to the low nibbles (literal.rs:230), so the two halves of a stream are independent.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix_nibble(Weights& w, uint32_t st_x, uint32_t st_max, uint32_t cm_x, uint32_t cm_max) {
+    const int mix_rate = w.norm;
+    const int cm_s = (int)(cm_x & 0xffffu), cm_p = (int)(cm_x >> 16), st_s = (int)(st_x & 0xffffu), st_p = (int)(st_x >> 16);
+    const int cmax = (int)cm_max, smax = (int)st_max;
+    const int p_s = average_rows(cm_s, st_s, cmax, smax, mix_rate);       // frequentist_cdf.rs:58-72, entry sym
+    const int p_p = average_rows(cm_p, st_p, cmax, smax, mix_rate);       //   entry sym-1 (0 | 0 -> 0 when sym == 0)
+    const int pmax = average_rows(cmax, smax, cmax, smax, mix_rate);      //   entry 15
+    const float rp = biased_rcp15(pmax), rc = biased_rcp15(cmax), rs = biased_rcp15(smax);
+    const uint32_t qp = scaled_div(p_p, pmax, rp);
+    const uint32_t freq = scaled_div(p_s, pmax, rp) - qp - 1u;            // probability/interface.rs:97-108
+    const uint32_t fcm = scaled_div(cm_s, cmax, rc) - scaled_div(cm_p, cmax, rc) - 1u;
+    const uint32_t fst = scaled_div(st_s, smax, rs) - scaled_div(st_p, smax, rs) - 1u;
+    weights_update(w, (int)(short)fcm, (int)(short)fst, (int)(short)freq);   // literal.rs:236-239
+    return (qp + 1u) | (freq << 16);
+}
+
+// One wave = 32 streams x 2 halves.  The records of a stream are contiguous in memory, so the wave fetches them
+// together -- every 16-byte load instruction covers 128-byte runs of eight streams -- into LDS, 16 positions at a time,
+// double-buffered; each lane then reads its own stream's records from LDS, and the (start, freq) pairs go back out the
+// same way (a lane-per-stream walk straight over global memory costs one 16-byte request per lane and load).
+constexpr uint32_t MW_CHUNK = 16;                       // positions per LDS buffer
+constexpr uint32_t MW_IN_STRIDE = 4u * MW_CHUNK * 8u + 16u;   // bytes per stream: 4 planes x 16 records, padded against bank conflicts
+constexpr uint32_t MW_OUT_STRIDE = 2u * MW_CHUNK * 4u + 16u;
+constexpr uint32_t MW_IN_BYTES = 32u * MW_IN_STRIDE;
+
+__global__ __launch_bounds__(64) void mix_weights_kernel(const MixBucketBatch b) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_in[2u * MW_IN_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_out[32u * MW_OUT_STRIDE];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s0 = blockIdx.x * 32u;
+    // consumer role: stream s0 + lane / 2, nibble half lane & 1
+    const uint32_t cs = s0 + (lane >> 1), half = lane & 1u;
+    const uint32_t len = cs < b.n_streams ? (b.in_sizes ? b.in_sizes[cs] : b.stream_len) : 0u;
+    // mover role: stream s0 + 8 i + lane / 8 of load i, records 2 (lane & 7), 2 (lane & 7) + 1 of the chunk
+    const uint32_t mq = lane & 7u, mj = lane >> 3;
+    const uint32_t chunks = (b.stream_len + MW_CHUNK - 1u) / MW_CHUNK;     // stream_len = the longest stream of the batch
+    Weights w; w.w0 = 1; w.w1 = 1; w.norm = 1 << 14;               // weights.rs:15-21
+    u32x4 r[16];
+#define MW_FETCH(C)                                                                                     \
+    _Pragma("unroll") for (uint32_t i = 0; i < 16u; ++i) {                                              \
+        const uint32_t plane = i >> 2, j = (i & 3u) * 8u + mj;                                          \
+        const uint32_t p = (C) * MW_CHUNK + 2u * mq;                                                    \
+        const bool ok = s0 + j < b.n_streams && p < b.max_stream_len;                                   \
+        const u32x2* src = b.pos[plane] + (ok ? (size_t)(s0 + j) * b.pos_stride + p : 0u);          \
+        r[i] = __builtin_nontemporal_load((const u32x4*)src);                                           \
+    }
+#define MW_STAGE(BUF)                                                                                   \
+    _Pragma("unroll") for (uint32_t i = 0; i < 16u; ++i) {                                              \
+        const uint32_t plane = i >> 2, j = (i & 3u) * 8u + mj;                                          \
+        *(u32x4*)(lds_in + (BUF) * MW_IN_BYTES + j * MW_IN_STRIDE + plane * (MW_CHUNK * 8u) + mq * 16u) = r[i]; \
+    }
+    if (chunks == 0u) return;
+    MW_FETCH(0u)
+    MW_STAGE(0u)
+    __syncthreads();
+    for (uint32_t c = 0; c < chunks; ++c) {
+        const uint32_t buf = c & 1u;
+        if (c + 1u < chunks) { MW_FETCH(c + 1u) }
+        const uint8_t* mine = lds_in + buf * MW_IN_BYTES + (lane >> 1) * MW_IN_STRIDE + half * (MW_CHUNK * 8u);
+        uint32_t* outp = (uint32_t*)(lds_out + (lane >> 1) * MW_OUT_STRIDE) + half;
+        const uint32_t p0 = c * MW_CHUNK;
+#pragma unroll
+        for (uint32_t k = 0; k < MW_CHUNK / 2u; ++k) {
+            const u32x4 st = *(const u32x4*)(mine + k * 16u), cm = *(const u32x4*)(mine + 2u * (MW_CHUNK * 8u) + k * 16u);
+            const uint32_t p = p0 + 2u * k;
+            if (p < len) outp[4u * k] = mix_nibble(w, st.x, st.y, cm.x, cm.y);
+            if (p + 1u < len) outp[4u * k + 2u] = mix_nibble(w, st.z, st.w, cm.z, cm.w);
+        }
+        __syncthreads();
+        // pairs out: load-shaped again, 16 bytes = both nibbles of two positions per lane
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const uint32_t j = i * 8u + mj, p = p0 + 2u * mq;
+            const uint32_t slen = s0 + j < b.n_streams ? (b.in_sizes ? b.in_sizes[s0 + j] : b.stream_len) : 0u;
+            if (p < slen)   // an odd stream's last quad carries one stale pair: it stays inside the (even) slot and is never read
+                *(u32x4*)(b.sf + 2u * ((size_t)(s0 + j) * b.max_stream_len + p)) = *(const u32x4*)(lds_out + j * MW_OUT_STRIDE + mq * 16u);
+        }
+        if (c + 1u < chunks) { MW_STAGE(buf ^ 1u) }
+        __syncthreads();
+    }
+#undef MW_FETCH
+#undef MW_STAGE
+}
+
+hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hipStream_t st) {
+    BucketBatch v;                       // the view the shared task-list and unsort kernels take
+    v.in = b.in; v.in_offsets = b.in_offsets; v.in_sizes = b.in_sizes;
+    v.n_streams = b.n_streams; v.stream_len = b.stream_len; v.max_stream_len = b.max_stream_len; v.pieces = b.pieces;
+    v.slot = b.slot; v.sf_stride = 2u * b.pos_stride;
+    v.sorted = nullptr; v.inv = b.inv; v.desc = b.desc; v.sfs = nullptr; v.sf = nullptr; v.tasks = b.tasks; v.counters = b.counters;
+    v.inc = 0; v.lim = 0;
+    for (int model = 0; model < 2; ++model) {
+        hipError_t e = hipMemsetAsync(b.counters, 0, 64, st);
+        if (e != hipSuccess) return e;
+        if (b.pieces < 8u) {
+            e = hipMemsetAsync(b.desc, 0, (size_t)b.n_streams * 256u * 8u * sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+        }
+        if (model == 0) {
+            hipLaunchKernelGGL(mix_sort_kernel<0>, dim3(b.n_streams * b.pieces), dim3(BK_SORT_THREADS), 0, st, b);
+            launch_bucket_tasks(v, st);
+            { const uint32_t wv = getenv("MIXW0") ? atoi(getenv("MIXW0")) : 3u, wg = getenv("MIXG0") ? atoi(getenv("MIXG0")) : 1u;
+              const uint32_t lds = (64u * wg * MxGeom<0>::LANE_DW + 256u) * 4u;
+              (void)hipFuncSetAttribute((const void*)mix_chain_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+              hipLaunchKernelGGL(mix_chain_kernel<0>, dim3(num_cus * wv / wg), dim3(64 * wg), lds, st, b); }
+        } else {
+            hipLaunchKernelGGL(mix_sort_kernel<1>, dim3(b.n_streams * b.pieces), dim3(BK_SORT_THREADS), 0, st, b);
+            launch_bucket_tasks(v, st);
+            { const uint32_t wv = getenv("MIXW1") ? atoi(getenv("MIXW1")) : 4u, wg = getenv("MIXG1") ? atoi(getenv("MIXG1")) : 1u;
+              const uint32_t lds = (64u * wg * MxGeom<1>::LANE_DW + 256u) * 4u;
+              (void)hipFuncSetAttribute((const void*)mix_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+              hipLaunchKernelGGL(mix_chain_kernel<1>, dim3(num_cus * wv / wg), dim3(64 * wg), lds, st, b); }
+        }
+        v.sfs = b.rec_high; v.sf = (uint32_t*)b.pos[2 * model];
+        launch_bucket_unsort(v, st);
+        v.sfs = b.rec_low; v.sf = (uint32_t*)b.pos[2 * model + 1];
+        launch_bucket_unsort(v, st);
+    }
+    hipLaunchKernelGGL(mix_weights_kernel, dim3((b.n_streams + 31u) / 32u), dim3(64), 0, st, b);
+    return hipGetLastError();
+}
+
+}  // namespace divans_hip

@@ -55,6 +55,55 @@ __device__ __forceinline__ uint32_t scaled_div(int c, int d, float rcp_lo) {
     return r >= d ? q + 1u : q;
 }
 
+// frequentist_cdf.rs:58-72: self = cm row, other = stride row.  Every factor is below 2^15 (and the shifted products
+// stay below 2^15, see the bound on `sh`), so the full-rate 24-bit multiplies give the same 32-bit results as `*`.
+__device__ __forceinline__ int average_rows(int cm, int st, int cmax, int smax, int mix_rate) {
+    const uint32_t prod = __umul24((uint32_t)cmax, (uint32_t)smax);
+    int lz = __clz((int)prod);
+    lz = lz > 17 ? 17 : lz;
+    const int sh = 17 - lz;
+    const uint32_t inv = (uint32_t)((1 << 15) - mix_rate);
+    const uint32_t rs = __umul24((uint32_t)cm, (uint32_t)smax) >> sh;
+    const uint32_t ro = __umul24((uint32_t)st, (uint32_t)cmax) >> sh;
+    return (int)(__umul24(rs, (uint32_t)mix_rate) + __umul24(ro, inv) + 1u) >> 15;
+}
+
+struct Weights { int w0, w1; int norm; };  // weights.rs:4-8 (norm = normalized_weight as u16)
+
+// weights.rs:110-133 in 32 bits.  error = 2^15 - pmix and prob_i - pmix are below 2^16 in magnitude, so the reference's
+// i64 product error * efficacy is (error * (prob_i - pmix)) << 15 with a factor that fits an int; its arithmetic shift by
+// lg = bit length of pmix * (2^15 - pmix) (< 2^28) and the wrapping i32 add are then one left or right shift of that int.
+__device__ __forceinline__ int new_weight(int prob_i, int pmix, int error, int lg, int wi) {
+    const int prod = error * (prob_i - pmix);
+    const int l = 15 - lg;
+    const int adj = l >= 0 ? (int)((uint32_t)prod << (l & 31)) : (prod >> ((-l) & 31));
+    const int nw = (int)((uint32_t)wi + (uint32_t)adj);
+    return nw > 1 ? nw : 1;
+}
+
+// weights.rs:23-38 + normalize_weights :64-80 + compute_normalized_weight :54-62
+__device__ __forceinline__ void weights_update(Weights& w, int p_cm, int p_stride, int pmix) {
+    if (((w.w0 | w.w1) & 0x7f000000) != 0) {
+        int lz0 = __clz(w.w0), lz1 = __clz(w.w1);
+        int ilog = 32 - (lz0 < lz1 ? lz0 : lz1);
+        if (ilog >= 24) { w.w0 >>= (ilog - 24); w.w1 >>= (ilog - 24); }
+    }
+    const int error = (1 << 15) - pmix;
+    const uint32_t geo = (uint32_t)(pmix * error);                 // full_model_sum_p1 * full_model_sum_p0, below 2^28
+    const int lg = geo ? 32 - __clz((int)geo) : 0;
+    const int n0 = new_weight(p_cm, pmix, error, lg, w.w0);
+    const int n1 = new_weight(p_stride, pmix, error, lg, w.w1);
+    w.w0 = n0; w.w1 = n1;
+    const uint32_t total = (uint32_t)n0 + (uint32_t)n1;            // both in [1, 2^31): the i64 sum fits 32 bits
+    int shift = 24 - __clz((int)total);                            // 56 - leading_zeros of the i64
+    shift = shift < 0 ? 0 : shift;
+    const uint32_t t8 = (total >> shift) & 0xffu;
+    const uint32_t num = ((uint32_t)(n0 >> shift) << 8) & 0xffffu;
+    // fast_divide_16bit_by_8bit == exact '/' (make_div_lut.rs:11-23); RECIPROCAL8[0] == 0
+    const uint32_t q = t8 ? exact_div(num, t8, __builtin_amdgcn_rcpf((float)t8)) : 0u;
+    w.norm = (int)((q << 7) & 0xffffu);
+}
+
 struct RowSel {
     uint32_t stride_row;   // row index inside the stream's table
     uint32_t cm_row;       // context-map row (mixing only)

@@ -74,16 +74,42 @@ struct BucketBatch {
     const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
     uint32_t n_streams, stream_len, max_stream_len;
     uint32_t pieces;            // 8 KiB pieces per stream slot = ceil(max_stream_len / 8192), at most 8
+    uint32_t slot;              // elements per stream in sorted / inv / sfs: pieces * 8192 (+ an optional pad)
+    uint32_t sf_stride;         // u32 elements per stream in sf
     uint8_t* sorted;            // [n_streams][pieces * 8192] literal bytes, every piece ordered by (previous byte, position)
     uint16_t* inv;              // [n_streams][pieces * 8192] slot of a position inside its sorted piece
     uint32_t* desc;             // [n_streams][256 previous-byte values][8 pieces] first slot | count << 16
     bk_u32x2* sfs;              // [n_streams][pieces * 8192] (high, low) start|freq<<16 pairs in sorted order
     uint32_t* sf;               // [n_streams][2 * max_stream_len] the same pairs in position order (what rans_encode_kernel reads)
-    uint32_t* tasks;            // [3 size classes][n_streams * 256] stream * 256 + previous byte
-    uint32_t* counters;         // [0..2] tasks per class, [3] next unclaimed task
+    uint32_t* tasks;            // [6 size classes][n_streams * 256] stream * 256 + previous byte
+    uint32_t* counters;         // [0..5] tasks per class, [8] next unclaimed task
     int32_t inc, lim;           // literal_adaptation[0]
 };
 hipError_t launch_bucket_model(const BucketBatch& b, uint32_t chain_blocks, hipStream_t st);
+void launch_bucket_tasks(const BucketBatch& b, hipStream_t st);
+void launch_bucket_unsort(const BucketBatch& b, hipStream_t st);
+
+// Bucketed encoder model pass for the two-model configuration (lit_bucket_mix.hip): context map on, every mixing value 4
+// (stride 1), dynamic mixing (context_mixing >= 2), one literal block type, no segment lists, streams <= 64 KiB.
+struct MixBucketBatch {
+    const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
+    uint32_t n_streams, stream_len, max_stream_len;
+    uint32_t pieces;            // 8 KiB pieces per stream slot, at most 8
+    uint32_t slot;              // elements per stream in sorted / inv / rec_high / rec_low (see BucketBatch::slot)
+    uint32_t pos_stride;        // elements per stream in pos[]
+    const uint8_t* blob;        // configuration tables (LIT_BLOB_LUT1CLASS, LIT_BLOB_CTXF of the one block type)
+    uint16_t* sorted;           // [n_streams][pieces * 8192] byte | high-row slot << 8, every piece ordered by (key, position)
+    uint16_t* inv;              // [n_streams][pieces * 8192] slot of a position inside its sorted piece
+    uint32_t* desc;             // [n_streams][256 keys][8 pieces] first slot | count << 16
+    uint32_t* tasks;            // [6 size classes][n_streams * 256]
+    uint32_t* counters;
+    bk_u32x2* rec_high;         // [n_streams][pieces * 8192] sorted order: {cdf[sym] | cdf[sym-1] << 16, cdf[15]} of the high nibble's row
+    bk_u32x2* rec_low;          //   ... of the low nibble's row, both BEFORE the row is blended with the symbol
+    bk_u32x2* pos[4];           // the same records in position order [n_streams][max_stream_len]: stride high, stride low, cm high, cm low
+    uint32_t* sf;               // [n_streams][2 * max_stream_len] what rans_encode_kernel reads
+    int32_t inc0, lim0, inc2, lim2, inc3, lim3;   // literal_adaptation[0] (stride rows), [2] (cm low), [3] (cm high)
+};
+hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hipStream_t st);
 
 uint32_t lit_lds_bytes(const LitBatch& b);
 hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);

@@ -166,11 +166,15 @@ int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t
  * 8 (two entries per lane; non-mixing configurations only) */
 int divans_gpu_codec_set_lane_layout(divans_gpu_codec *c, uint32_t lanes_per_stream);
 /* Encoder model pass: 0 = automatic, 1 = streaming kernels (one walk per stream against its CDF table in HBM),
- * 2 = bucketed (positions grouped by previous byte, one lane per bucket, rows in LDS; lit_bucket.hip).  The bucketed
- * pass exists for order-1 configurations without context map or mixing (divans_lit_config_simple) and streams of at
- * most 65536 bytes, where it is what "automatic" picks; asking for it elsewhere is DIVANS_GPU_EINVAL.  Both produce
- * the same bytes. */
+ * 2 = bucketed (positions grouped by the byte / context that selects their rows, one lane per bucket, rows in LDS;
+ * lit_bucket.hip, lit_bucket_mix.hip).  The bucketed pass exists for configurations whose every mixing value is 4
+ * (stride 1) and streams of at most 65536 bytes: without context map and mixing (divans_lit_config_simple), or with a
+ * context map and dynamic mixing for one literal block type (divans_lit_config_context_mixing).  There it is what
+ * "automatic" picks; asking for it elsewhere is DIVANS_GPU_EINVAL.  Both produce the same bytes. */
 int divans_gpu_codec_set_encode_path(divans_gpu_codec *c, uint32_t path);
+/* Streams the bucketed two-model pass takes per launch sequence (default 32768, halved until its work arrays -- 3.4 MB
+ * per 64 KiB stream -- fit the device).  A tuning / test knob: the coded bytes do not depend on it. */
+int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
 
 /* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */
 int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, uint32_t low_rows);

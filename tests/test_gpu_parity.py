@@ -21,6 +21,8 @@ def _oracle_cfg(cfg_name):
 def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0, split=None, lanes=None, encode_path=None):
     n, L = blocks.shape
     da, codec = _codec(cfg_name, max(L, 1))
+    if encode_path is None and (cache_rows is not None or split is not None):
+        encode_path = 1          # the row caches belong to the streaming kernels: keep their encoder in the comparison
     if encode_path is not None:
         codec.set_encode_path(encode_path)
     if lanes is not None:
@@ -246,10 +248,11 @@ def test_unsupported_speed_is_rejected():
         da.LiteralCodec(g, 1024)
 
 
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
 @pytest.mark.parametrize("encode_path", [1, 2])
 @pytest.mark.parametrize("length", [1, 2, 63, 64, 65, 8191, 8192, 8193, 16385, 40000, 65535, 65536])
-def test_encode_paths_bit_exact(encode_path, length, corpus, shuffle384):
-    # streaming model kernel (1) and bucketed model pass (2, what "automatic" picks for this configuration)
+def test_encode_paths_bit_exact(cfg_name, encode_path, length, corpus, shuffle384):
+    # streaming model kernel (1) and bucketed model pass (2, what "automatic" picks for these configurations)
     # must both reproduce the oracle's bytes; lengths straddle the 8 KiB sort pieces and the 32 KiB ANS chunks
     blocks = workload.make_blocks(corpus, 40, 70, block_len=length, perturb_per_block=length // 100)
     if length >= 64:
@@ -257,10 +260,36 @@ def test_encode_paths_bit_exact(encode_path, length, corpus, shuffle384):
         blocks[4] = np.random.default_rng(length).integers(0, 256, length, dtype=np.uint8)
         blocks[5] = 0
         blocks[6] = np.resize(np.frombuffer(b"ab", dtype=np.uint8), length)   # two buckets own every position
-    _compare("simple", blocks, encode_path=encode_path)
+    _compare(cfg_name, blocks, encode_path=encode_path)
 
 
-@pytest.mark.parametrize("cfg_name,encode_path", [("simple", 1), ("simple", 2), ("mixing", 1)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_bucketed_two_model_pass_over_prediction_modes(mode, corpus, random_then_unicode):
+    # the two-model bucketed pass keys its high-nibble rows by (prev, class of prev_prev -> context): every prediction
+    # mode (LSB6 / MSB6 / UTF8 / SIGN luts: 1, 1, 4 and 8 classes), random context maps, palette speeds, any block type
+    import divans_amd as da
+    rng = np.random.default_rng(700 + mode)
+    speeds = [(16, 8192), (64, 16384), (2, 1024), (128, 16384)]
+    L = 20000
+    blocks = np.stack([corpus[3000:3000 + L], random_then_unicode[100000:100000 + L], random_then_unicode[200000:200000 + L],
+                       np.resize(np.frombuffer(b"abcabcabd", dtype=np.uint8), L), rng.integers(0, 256, L, dtype=np.uint8)])
+    for _ in range(2):
+        g, o = _random_config(rng, da, 2, mode, [4], speeds)
+        codec = da.LiteralCodec(g, L)
+        codec.set_encode_path(2)
+        packed, offs, sizes = codec.encode_host(blocks, L)
+        for i in range(blocks.shape[0]):
+            ref = po.lit_encode(o, blocks[i])
+            got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
+            assert got.size == ref.size and (got == ref).all(), (mode, i)
+        codec.set_encode_path(1)
+        packed1, offs1, sizes1 = codec.encode_host(blocks, L)
+        assert (sizes == sizes1).all() and (packed == packed1).all()
+        assert (codec.decode_host(packed, offs, sizes, L) == blocks).all()
+        codec.close()
+
+
+@pytest.mark.parametrize("cfg_name,encode_path", [("simple", 1), ("simple", 2), ("mixing", 1), ("mixing", 2)])
 def test_model_pass_matches_oracle_trace(cfg_name, encode_path, corpus, shuffle384):
     # the (start, freq) pair of every nibble, straight out of the model pass on a fresh codec (nothing stale to hide
     # behind), against the oracle's put_start_freq trace
@@ -299,16 +328,53 @@ def test_bucketed_encoder_many_streams(corpus):
     codec.close()
 
 
-def test_bucketed_encoder_only_where_it_applies():
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_bucketed_encoder_many_streams_both_paths_agree(cfg_name, corpus):
+    # ragged lengths, more streams than one launch sequence of the two-model pass takes at once (set to 8192 here)
+    import torch
     import divans_amd as da
-    codec = da.LiteralCodec(da.config_context_mixing(), 4096)
+    dev = torch.device("cuda", 0)
+    n, L = 20000, 600
+    blocks = workload.make_blocks(corpus, 11, n, block_len=L)
+    lens = (np.arange(n) * 37 % (L + 1)).astype(np.int32)
+    lens[:4] = [0, 1, L, L - 1]
+    starts = np.arange(n, dtype=np.int64) * L
+    d_in = torch.from_numpy(np.concatenate([blocks.reshape(-1), np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(starts).to(dev); d_sz = torch.from_numpy(lens).to(dev)
+    codec = da.LiteralCodec(da.config_simple() if cfg_name == "simple" else da.config_context_mixing(), L)
+    codec.set_bucket_batch(8192)
+    got = []
+    for path in (2, 1):
+        codec.set_encode_path(path)
+        outs = codec.alloc_encode_outputs(n)
+        codec.encode_batch(d_in, n, L, outs, in_offsets=d_off, in_sizes=d_sz)
+        torch.cuda.synchronize()
+        got.append((outs["offsets"].cpu().numpy(), outs["sizes"].cpu().numpy(), outs["out"].cpu().numpy()))
+    (o2, s2, b2), (o1, s1, b1) = got
+    assert (s2 == s1).all()
+    for i in range(n):
+        assert (b2[o2[i]:o2[i] + s2[i]] == b1[o1[i]:o1[i] + s1[i]]).all(), i
+    ocfg = _oracle_cfg(cfg_name)
+    for i in list(range(0, n, 499)) + [8191, 8192, 16383, 16384, n - 1]:
+        ref = po.lit_encode(ocfg, blocks[i][:lens[i]])
+        assert s2[i] == ref.size and (b2[o2[i]:o2[i] + s2[i]] == ref).all(), i
+    codec.close()
+
+
+def test_bucketed_encoder_only_where_it_applies():
+    import ctypes
+    import divans_amd as da
+    g = da.config_context_mixing()
+    ctypes.memset(g.mixing_mask, 5, 8192)                   # stride 2: rows are no longer a function of (prev, ctx, high nibble)
+    codec = da.LiteralCodec(g, 4096)
     with pytest.raises(da.DivansGpuError):
         codec.set_encode_path(2)
     codec.close()
-    codec = da.LiteralCodec(da.config_simple(), 100000)     # streams longer than 8 pieces: streaming kernels only
-    with pytest.raises(da.DivansGpuError):
-        codec.set_encode_path(2)
-    codec.close()
+    for cfg in (da.config_simple(), da.config_context_mixing()):
+        codec = da.LiteralCodec(cfg, 100000)                # streams longer than 8 pieces: streaming kernels only
+        with pytest.raises(da.DivansGpuError):
+            codec.set_encode_path(2)
+        codec.close()
 
 
 @pytest.mark.parametrize("lanes", [8, 16])
