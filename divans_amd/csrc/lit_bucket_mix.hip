@@ -17,6 +17,11 @@
 
 namespace divans_hip {
 
+// Chain waves per CU.  The stride model's 24 rows per lane allow three; the context model's 17 would allow four, but three
+// are faster (30.9 vs 35.7 ms per 32 768 streams, two: 32.2): with 16 bytes of records leaving per lane and step the
+// waves of a CU queue up behind its vector-memory path (TA busy 80 %), and a fourth wave only lengthens the queue.
+constexpr uint32_t MX_CHAIN_WAVES = 3;
+
 template <int MODEL> struct MxGeom {
     static constexpr uint32_t NH = MODEL == 0 ? 8u : 1u;            // high-nibble rows of a bucket
     static constexpr uint32_t NR = NH + 16u;
@@ -131,17 +136,17 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void mix_sort_kernel(const MixBuck
 //    eight loads in flight per lane, hidden stores); see there for why it is written the way it is.
 // ---------------------------------------------------------------------------------------------
 template <int MODEL>
-__global__ __launch_bounds__(256) void mix_chain_kernel(const MixBucketBatch b) {
+__global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
     using G = MxGeom<MODEL>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t* my = lds32 + threadIdx.x * G::LANE_DW;
+    const uint32_t lane = threadIdx.x;
+    uint32_t* my = lds32 + lane * G::LANE_DW;
     uint32_t* mydesc = my + G::DESC_DW;
-    uint32_t* tabh = lds32 + blockDim.x * G::LANE_DW;
+    uint32_t* tabh = lds32 + 64u * G::LANE_DW;
     uint32_t* tabl = tabh + 128u;
     const uint32_t inch = (uint32_t)(MODEL == 0 ? b.inc0 : b.inc3), incl = (uint32_t)(MODEL == 0 ? b.inc0 : b.inc2);   // literal.rs:320,354 / :242
     const int limh = MODEL == 0 ? b.lim0 : b.lim3, liml = MODEL == 0 ? b.lim0 : b.lim2;
-    for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) {
+    for (uint32_t i = lane; i < 128u; i += 64u) {
         const uint32_t sym = i >> 3, k = i & 7u;
         tabh[i] = (2u * k >= sym ? inch : 0u) | (2u * k + 1u >= sym ? inch << 16 : 0u);
         tabl[i] = (2u * k >= sym ? incl : 0u) | (2u * k + 1u >= sym ? incl << 16 : 0u);
@@ -380,17 +385,11 @@ hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hi
         if (model == 0) {
             hipLaunchKernelGGL(mix_sort_kernel<0>, dim3(b.n_streams * b.pieces), dim3(BK_SORT_THREADS), 0, st, b);
             launch_bucket_tasks(v, st);
-            { const uint32_t wv = getenv("MIXW0") ? atoi(getenv("MIXW0")) : 3u, wg = getenv("MIXG0") ? atoi(getenv("MIXG0")) : 1u;
-              const uint32_t lds = (64u * wg * MxGeom<0>::LANE_DW + 256u) * 4u;
-              (void)hipFuncSetAttribute((const void*)mix_chain_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-              hipLaunchKernelGGL(mix_chain_kernel<0>, dim3(num_cus * wv / wg), dim3(64 * wg), lds, st, b); }
+            hipLaunchKernelGGL(mix_chain_kernel<0>, dim3(num_cus * MX_CHAIN_WAVES), dim3(64), MxGeom<0>::LDS_BYTES, st, b);
         } else {
             hipLaunchKernelGGL(mix_sort_kernel<1>, dim3(b.n_streams * b.pieces), dim3(BK_SORT_THREADS), 0, st, b);
             launch_bucket_tasks(v, st);
-            { const uint32_t wv = getenv("MIXW1") ? atoi(getenv("MIXW1")) : 4u, wg = getenv("MIXG1") ? atoi(getenv("MIXG1")) : 1u;
-              const uint32_t lds = (64u * wg * MxGeom<1>::LANE_DW + 256u) * 4u;
-              (void)hipFuncSetAttribute((const void*)mix_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-              hipLaunchKernelGGL(mix_chain_kernel<1>, dim3(num_cus * wv / wg), dim3(64 * wg), lds, st, b); }
+            hipLaunchKernelGGL(mix_chain_kernel<1>, dim3(num_cus * MX_CHAIN_WAVES), dim3(64), MxGeom<1>::LDS_BYTES, st, b);
         }
         v.sfs = b.rec_high; v.sf = (uint32_t*)b.pos[2 * model];
         launch_bucket_unsort(v, st);
