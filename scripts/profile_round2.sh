@@ -58,7 +58,7 @@ PY
   rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_tcc $OUT/pmc_ea $OUT/pmc_sq $OUT/pmc_sq2
 }
 run_config simple 1
-run_config mixing 0
+run_config mixing 1
 run_config decode_only 0
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
 cd $REPO && python bench.py > gpurun_out/prof_$TAG/bench_line.json 2> gpurun_out/prof_$TAG/bench_line.err
