@@ -120,6 +120,12 @@ def load_library():
     L.divans_gpu_codec_set_lane_layout.argtypes = [vp, u32]
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
     L.divans_gpu_codec_set_bucket_batch.argtypes = [vp, u32]
+    L.divans_gpu_lit_encode_host_pipelined.argtypes = [vp, vp, u32, u32, vp, ctypes.c_size_t, vp, vp, ctypes.POINTER(ctypes.c_size_t), u32]
+    L.divans_gpu_lit_decode_host_pipelined.argtypes = [vp, vp, vp, vp, u32, vp, u32, u32]
+    L.divans_gpu_host_alloc.argtypes = [ctypes.c_size_t]
+    L.divans_gpu_host_alloc.restype = vp
+    L.divans_gpu_host_free.argtypes = [vp]
+    L.divans_gpu_host_free.restype = None
     L.divans_gpu_lit_model_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
@@ -161,6 +167,7 @@ def exported_symbols():
         "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
+        "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
     ]
 
 
@@ -430,6 +437,34 @@ class LiteralCodec:
                "divans_gpu_lit_encode_host")
         return out[:total.value].copy(), offs, sizes
 
+    def encode_host_pipelined(self, data, stream_len, slice_streams=0, out=None):
+        """encode_host through the copy / code / copy pipeline; `data` and `out` should be page-locked (pinned_empty)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        n = data.size // stream_len
+        assert n * stream_len == data.size
+        cap = encode_bound(stream_len) * n + 64
+        if out is None:
+            out = np.empty(cap, dtype=np.uint8)   # a caller's `out` may be smaller: DIVANS_GPU_ECAP if the packed streams do not fit
+        offs = np.empty(n, dtype=np.uint64)
+        sizes = np.empty(n, dtype=np.uint32)
+        total = ctypes.c_size_t(0)
+        _check(self._lib.divans_gpu_lit_encode_host_pipelined(self._h, data.ctypes.data, int(stream_len), n, out.ctypes.data, out.size,
+                                                              offs.ctypes.data, sizes.ctypes.data, ctypes.byref(total), int(slice_streams)),
+               "divans_gpu_lit_encode_host_pipelined")
+        return out[:total.value], offs, sizes
+
+    def decode_host_pipelined(self, packed, offsets, sizes, stream_len, slice_streams=0, out=None):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        n = offsets.size
+        if out is None:
+            out = np.empty(max(n * stream_len, 1), dtype=np.uint8)
+        _check(self._lib.divans_gpu_lit_decode_host_pipelined(self._h, packed.ctypes.data, offsets.ctypes.data, sizes.ctypes.data,
+                                                              n, out.ctypes.data, int(stream_len), int(slice_streams)),
+               "divans_gpu_lit_decode_host_pipelined")
+        return out[:n * stream_len].reshape(n, stream_len) if stream_len else out[:0].reshape(n, 0)
+
     def decode_host(self, packed, offsets, sizes, stream_len):
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -439,6 +474,28 @@ class LiteralCodec:
         _check(self._lib.divans_gpu_lit_decode_host(self._h, packed.ctypes.data, offsets.ctypes.data, sizes.ctypes.data,
                                                     n, out.ctypes.data, int(stream_len)), "divans_gpu_lit_decode_host")
         return out[:n * stream_len].reshape(n, stream_len) if stream_len else out[:0].reshape(n, 0)
+
+
+class PinnedBuffer:
+    """Page-locked host memory from divans_gpu_host_alloc as a numpy uint8 array (`.array`); freed by close() / GC."""
+    def __init__(self, nbytes):
+        self._lib = load_library()
+        self._p = self._lib.divans_gpu_host_alloc(int(nbytes))
+        if not self._p:
+            raise DivansGpuError("divans_gpu_host_alloc failed")
+        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * int(nbytes)).from_address(self._p))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.divans_gpu_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def build_extension(force=False):

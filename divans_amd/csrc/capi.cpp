@@ -117,6 +117,10 @@ struct divans_gpu_codec {
     void* host_scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device buffers of the host-buffer entry points, grow-only
     size_t host_scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // chunk-parallel rANS scratch when the bucket arrays are not there to reuse
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // pipelined host-buffer entry points: copy-in / copy-out streams, per-slice events, pinned per-slice totals
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev_in, ev_done;
+    uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;
     float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
     bool timing_pending_enc = false, timing_pending_dec = false;
 };
@@ -305,6 +309,11 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     for (void* q : c->host_scratch) if (q) (void)hipFree(q);
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_in) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_done) if (e) (void)hipEventDestroy(e);
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
     delete c;
 }
 
@@ -849,3 +858,151 @@ extern "C" int divans_gpu_lit_decode_host(divans_gpu_codec* c, const uint8_t* in
     }
     return 0;
 }
+
+// ---- pipelined host-buffer entry points ------------------------------------------------------------
+// The batch is cut into slices of `slice_streams` streams; slice i+1 travels to the device and slice i-1 back to the host
+// while slice i is coded.  Copies only overlap when the caller's buffers are page-locked (divans_gpu_host_alloc,
+// hipHostMalloc, hipHostRegister); with pageable memory the calls are correct but the runtime serialises the copies.
+extern "C" void* divans_gpu_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); (void)fail(DIVANS_GPU_ENOMEM, "hipHostMalloc failed"); return nullptr; }
+    return p;
+}
+extern "C" void divans_gpu_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+static int ensure_pipeline(divans_gpu_codec* c, uint32_t slices) {
+    if (!c->s_in) HIP_TRY(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    if (!c->s_out) HIP_TRY(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    while (c->ev_in.size() < slices) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_in.push_back(e); }
+    while (c->ev_done.size() < slices) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_done.push_back(e); }
+    if (c->h_totals_cap < 2u * slices) {
+        if (c->h_totals) HIP_TRY(hipHostFree(c->h_totals));
+        c->h_totals = nullptr; c->h_totals_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->h_totals, sizeof(uint64_t) * 2u * slices, hipHostMallocDefault));
+        c->h_totals_cap = 2u * slices;
+    }
+    return 0;
+}
+
+static uint32_t default_slice(const divans_gpu_codec* c, uint32_t n_streams, uint32_t slice_streams) {
+    // a slice should keep the persistent decode grid full; four slices are enough to hide the copies
+    if (slice_streams == 0) slice_streams = std::max<uint32_t>(resident_groups(c), (n_streams + 3u) / 4u);
+    return std::min(slice_streams, n_streams);
+}
+
+extern "C" int divans_gpu_lit_encode_host_pipelined(divans_gpu_codec* c, const uint8_t* in, uint32_t stream_len, uint32_t n_streams,
+                                                    uint8_t* out_packed, size_t out_cap, uint64_t* out_offsets, uint32_t* out_sizes,
+                                                    size_t* out_total, uint32_t slice_streams) {
+    if (!c || !in || !out_packed || !out_offsets || !out_sizes || !out_total) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (n_streams == 0) { *out_total = 0; return 0; }
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t S = default_slice(c, n_streams, slice_streams);
+    const uint32_t slices = (n_streams + S - 1u) / S;
+    const uint64_t slot = divans_gpu_lit_encode_bound(stream_len);
+    uint8_t *d_in = nullptr, *d_slots = nullptr, *d_packed = nullptr;
+    uint64_t *d_off = nullptr, *d_poff = nullptr, *d_total = nullptr; uint32_t* d_sz = nullptr;
+    int rc = 0;
+    if ((rc = ensure_pipeline(c, slices))) return rc;
+    if ((rc = host_scratch(c, 0, (size_t)stream_len * n_streams + 64, &d_in))) return rc;
+    if ((rc = host_scratch(c, 1, slot * S + 64, &d_slots))) return rc;                       // one slice of right-aligned slots
+    if ((rc = host_scratch(c, 2, slot * n_streams + 64, &d_packed))) return rc;              // every slice's packed bytes, slice i at i * S * slot
+    if ((rc = host_scratch(c, 3, sizeof(uint64_t) * n_streams, &d_off))) return rc;
+    if ((rc = host_scratch(c, 4, sizeof(uint64_t) * n_streams, &d_poff))) return rc;
+    if ((rc = host_scratch(c, 5, sizeof(uint64_t) * slices, &d_total))) return rc;
+    if ((rc = host_scratch(c, 6, sizeof(uint32_t) * n_streams, &d_sz))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // earlier work on the codec's stream may still read the staging buffers
+    for (uint32_t i = 0; i < slices; ++i) {
+        const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
+        HIP_TRY(hipMemcpyAsync(d_in + (size_t)s0 * stream_len, in + (size_t)s0 * stream_len, (size_t)ns * stream_len, hipMemcpyHostToDevice, c->s_in));
+        HIP_TRY(hipEventRecord(c->ev_in[i], c->s_in));
+    }
+    for (uint32_t i = 0; i < slices; ++i) {
+        const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[i], 0));
+        rc = encode_batch_impl(c, d_in + (size_t)s0 * stream_len, nullptr, nullptr, stream_len, ns, d_slots, slot, d_off + s0, d_sz + s0, nullptr, 0);
+        if (rc) return rc;
+        rc = divans_gpu_pack_streams(c, d_slots, d_off + s0, d_sz + s0, ns, d_packed + (size_t)s0 * slot, d_poff + s0, d_total + i);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&c->h_totals[i], d_total + i, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_done[i], c->stream));
+    }
+    // sizes / offsets of a slice are small; they follow their slice's bytes on the copy-out stream
+    uint64_t base = 0;
+    std::vector<uint64_t> bases(slices);
+    for (uint32_t i = 0; i < slices; ++i) {
+        const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
+        HIP_TRY(hipEventSynchronize(c->ev_done[i]));
+        const uint64_t total = c->h_totals[i];
+        if (base + total > out_cap) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); return fail(DIVANS_GPU_ECAP, "out_cap too small for the packed streams"); }
+        bases[i] = base;
+        HIP_TRY(hipMemcpyAsync(out_packed + base, d_packed + (size_t)s0 * slot, total, hipMemcpyDeviceToHost, c->s_out));
+        HIP_TRY(hipMemcpyAsync(out_offsets + s0, d_poff + s0, sizeof(uint64_t) * ns, hipMemcpyDeviceToHost, c->s_out));
+        HIP_TRY(hipMemcpyAsync(out_sizes + s0, d_sz + s0, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, c->s_out));
+        base += total;
+    }
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, c->d_status, sizeof(status), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->s_out));
+    if (status) { (void)hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream); return fail(DIVANS_GPU_EINVAL, "model produced an invalid (start,freq): unsupported speed/CDF state"); }
+    for (uint32_t i = 1; i < slices; ++i) {            // slice-local packed offsets -> offsets in out_packed
+        const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
+        for (uint32_t k = 0; k < ns; ++k) out_offsets[s0 + k] += bases[i];
+    }
+    *out_total = base;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_decode_host_pipelined(divans_gpu_codec* c, const uint8_t* in_packed, const uint64_t* in_offsets,
+                                                    const uint32_t* in_sizes, uint32_t n_streams, uint8_t* out, uint32_t stream_len,
+                                                    uint32_t slice_streams) {
+    if (!c || !in_packed || !in_offsets || !in_sizes || !out) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (n_streams == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t total = 0; bool ordered = true;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (in_offsets[i] % 4) return fail(DIVANS_GPU_EINVAL, "coded streams must start 4-byte aligned");
+        if (in_offsets[i] < total) ordered = false;             // a slice's bytes must be one range of the input
+        total = std::max<size_t>(total, in_offsets[i] + in_sizes[i]);
+    }
+    if (!ordered) return divans_gpu_lit_decode_host(c, in_packed, in_offsets, in_sizes, n_streams, out, stream_len);
+    const uint32_t S = default_slice(c, n_streams, slice_streams);
+    const uint32_t slices = (n_streams + S - 1u) / S;
+    uint8_t *d_in = nullptr, *d_out = nullptr; uint64_t* d_off = nullptr; uint32_t* d_sz = nullptr;
+    int rc = 0;
+    if ((rc = ensure_pipeline(c, slices))) return rc;
+    if ((rc = host_scratch(c, 0, total + 128, &d_in))) return rc;
+    if ((rc = host_scratch(c, 1, (size_t)stream_len * n_streams + 64, &d_out))) return rc;
+    if ((rc = host_scratch(c, 3, sizeof(uint64_t) * n_streams, &d_off))) return rc;
+    if ((rc = host_scratch(c, 6, sizeof(uint32_t) * n_streams, &d_sz))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(d_off, in_offsets, sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice, c->s_in));
+    HIP_TRY(hipMemcpyAsync(d_sz, in_sizes, sizeof(uint32_t) * n_streams, hipMemcpyHostToDevice, c->s_in));
+    for (uint32_t i = 0; i < slices; ++i) {
+        const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
+        const size_t lo = in_offsets[s0], hi = in_offsets[s0 + ns - 1u] + in_sizes[s0 + ns - 1u];
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(d_in + lo, in_packed + lo, hi - lo, hipMemcpyHostToDevice, c->s_in));
+        HIP_TRY(hipEventRecord(c->ev_in[i], c->s_in));
+    }
+    for (uint32_t i = 0; i < slices; ++i) {
+        const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[i], 0));
+        rc = divans_gpu_lit_decode_batch(c, d_in, d_off + s0, d_sz + s0, ns, d_out + (size_t)s0 * stream_len, nullptr, nullptr, stream_len);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_done[i], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->s_out, c->ev_done[i], 0));
+        HIP_TRY(hipMemcpyAsync(out + (size_t)s0 * stream_len, d_out + (size_t)s0 * stream_len, (size_t)ns * stream_len, hipMemcpyDeviceToHost, c->s_out));
+    }
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, c->d_status, sizeof(status), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->s_out));
+    if (status & LIT_STATUS_BAD_STREAM) {
+        (void)hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream);
+        return fail(DIVANS_GPU_ECORRUPT, "a coded stream is truncated, corrupt or was coded under another configuration (final rANS states / word count mismatch)");
+    }
+    return 0;
+}
+

@@ -149,6 +149,22 @@ int divans_gpu_lit_encode_host_chunks(divans_gpu_codec *c, const uint8_t *in, ui
 int divans_gpu_lit_decode_host(divans_gpu_codec *c, const uint8_t *in_packed, const uint64_t *in_offsets,
                                const uint32_t *in_sizes, uint32_t n_streams, uint8_t *out, uint32_t stream_len);
 
+/* The same through a three-stage pipeline: the batch is cut into slices of `slice_streams` streams (0 = automatic: at
+ * least the persistent grid's worth, at most a quarter of the batch) and slice i+1 travels to the device / slice i-1 back
+ * while slice i is coded.  Results are identical to the wrappers above.  The copies only overlap with the kernels when
+ * the caller's buffers are page-locked (divans_gpu_host_alloc below, hipHostMalloc or hipHostRegister); pageable memory
+ * works but the runtime then serialises the copies.  The decode variant wants the coded streams in offset order (what the
+ * encode wrappers produce) and otherwise falls back to divans_gpu_lit_decode_host. */
+int divans_gpu_lit_encode_host_pipelined(divans_gpu_codec *c, const uint8_t *in, uint32_t stream_len, uint32_t n_streams,
+                                         uint8_t *out_packed, size_t out_cap, uint64_t *out_offsets, uint32_t *out_sizes,
+                                         size_t *out_total, uint32_t slice_streams);
+int divans_gpu_lit_decode_host_pipelined(divans_gpu_codec *c, const uint8_t *in_packed, const uint64_t *in_offsets,
+                                         const uint32_t *in_sizes, uint32_t n_streams, uint8_t *out, uint32_t stream_len,
+                                         uint32_t slice_streams);
+/* page-locked host memory for the wrappers above (hipHostMalloc / hipHostFree); NULL on failure */
+void *divans_gpu_host_alloc(size_t bytes);
+void divans_gpu_host_free(void *p);
+
 /* Introspection for benchmarks/tests. */
 typedef struct divans_gpu_info {
     uint32_t rows_per_stream;      /* 32-byte CDF rows held per in-flight stream */

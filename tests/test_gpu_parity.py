@@ -386,3 +386,33 @@ def test_lane_layouts_bit_exact(lanes, split, corpus, shuffle384):
     blocks[8] = np.random.default_rng(3).integers(0, 256, 33000, dtype=np.uint8)
     blocks[9] = 0
     _compare("simple", blocks, blocks_grid=2, split=split, lanes=lanes, encode_path=1)
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+@pytest.mark.parametrize("slice_streams", [0, 1, 7, 64])
+def test_pipelined_host_wrappers_match_the_serial_ones(cfg_name, slice_streams, corpus):
+    # copy-in / code / copy-out pipeline over slices (pageable and page-locked buffers): same bytes, offsets, sizes
+    import divans_amd as da
+    L, n = 3000, 50
+    blocks = workload.make_blocks(corpus, 21, n, block_len=L)
+    da_, codec = _codec(cfg_name, L)
+    packed, offs, sizes = codec.encode_host(blocks, L)
+    pin_in = da.PinnedBuffer(n * L); pin_in.array[:] = blocks.reshape(-1)
+    pin_out = da.PinnedBuffer(da.encode_bound(L) * n + 64)
+    for data, out in ((blocks, None), (pin_in.array, pin_out.array)):
+        p2, o2, s2 = codec.encode_host_pipelined(data, L, slice_streams=slice_streams, out=out)
+        assert (s2 == sizes).all() and (o2 == offs).all() and p2.size == packed.size and (p2 == packed).all()
+    back = codec.decode_host_pipelined(packed, offs, sizes, L, slice_streams=slice_streams)
+    assert (back == blocks).all()
+    pin_back = da.PinnedBuffer(n * L)
+    back = codec.decode_host_pipelined(pin_out.array[:packed.size], offs, sizes, L, slice_streams=slice_streams, out=pin_back.array)
+    assert (back == blocks).all()
+    # out-of-order offsets fall back to the serial wrapper; damaged streams are still reported
+    perm = np.arange(n)[::-1].copy()
+    assert (codec.decode_host_pipelined(packed, offs[perm], sizes[perm], L, slice_streams=slice_streams) == blocks[perm]).all()
+    bad = packed.copy(); bad[int(offs[n // 2]) + 20] ^= 0x40
+    with pytest.raises(da.DivansGpuError):
+        codec.decode_host_pipelined(bad, offs, sizes, L, slice_streams=slice_streams)
+    for b in (pin_in, pin_out, pin_back):
+        b.close()
+    codec.close()
