@@ -6,10 +6,13 @@
  *
  * Scope: the literal-only internal compressor, i.e. what the reference does with
  * DIVANS_OPTION_USE_BROTLI_COMMAND_SELECTION = 0 (src/ffi/compressor.rs:73-78,168-178).  Option values that
- * select the brotli front end are accepted by divans_set_option (as in the reference) but the first
- * divans_encode() then fails: brotli command generation is out of scope and there is no CPU fallback.
- * The state buffers the whole input and produces the stream in the divans_encode_flush() calls; the
+ * select the brotli front end (1, 2 = the reference's default) are accepted and code the input with the same
+ * internal command selection: a valid .divans stream, larger than a brotli-assisted one (brotli command
+ * generation is out of scope).  There is no CPU fallback for the literal coder: without a HIP device the first
+ * divans_encode() / divans_decode() that needs it returns DIVANS_FAILURE.
+ * The state buffers the input and produces the stream in the divans_encode_flush() calls; the
  * decompressor accepts literal-only streams (one PredictionMode before the first Literal).
+ * include/divans_io.hpp wraps this ABI in the reference's writer / reader adaptors (src/writer.rs, src/reader.rs).
  */
 #ifndef DIVANS_FFI_H_
 #define DIVANS_FFI_H_
