@@ -108,7 +108,7 @@ struct divans_gpu_codec {
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
     uint32_t* d_status = nullptr;
     // bucketed encoder model pass (lit_bucket.hip)
-    bool bucket_ok = false;       // the configuration allows it: order-1, no context map, no mixing, streams <= 64 KiB
+    bool bucket_ok = false;       // the configuration allows it: order-1 rows (see configure_from_geometry), no mixing, streams <= 64 KiB
     bool bucket_mix_ok = false;   // two-model configuration the bucketed pass of lit_bucket_mix.hip covers
     uint32_t bucket_mix_batch = 32768;   // streams per launch sequence of that pass
     uint32_t encode_path = 0;     // 0 automatic (bucketed when bucket_ok), 1 streaming kernels, 2 bucketed
@@ -172,7 +172,7 @@ static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint
         }
     }
     std::memset(&g, 0, sizeof(g));
-    g.bt_first = bt_first; g.n_btypes = n_btypes; g.mix_off = mix_off;
+    g.bt_first = bt_first; g.n_btypes = n_btypes; g.mix_off = mix_off; g.lut1_classes = (uint32_t)nclass;
     g.nctx = maxctx + 1;
     g.ctx_const = constant ? first : -1;
     // reachable mixing values: index = ctx | nibble << 8 | (low ? 4096 : 0)  (literal.rs:176-183)
@@ -260,7 +260,10 @@ static void configure_from_geometry(divans_gpu_codec* c) {
         const uint32_t fit = (160u * 1024u) / lds_per_wg;
         c->blocks = c->num_cus * std::max(1u, std::min(7u, fit));
     }
-    c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && c->geom.ctx_const >= 0 && c->max_stream_len <= 65536u;
+    // order-1 rows: high row [ctx][prev], low row [prev][hi] with the context constant, or a function of prev alone (one lut1
+    // class and one block type: LSB6 / MSB6 -- what the reference's literal-only compressor emits, raw_to_cmd/mod.rs:115-140)
+    const bool ctx_from_prev = c->geom.ctx_const >= 0 || (c->geom.lut1_classes == 1u && c->geom.n_btypes == 1u);
+    c->bucket_ok = !c->mix && c->geom.mm_uniform == 4 && ctx_from_prev && c->max_stream_len <= 65536u;
     // both models' rows depend on (prev, ctx, high nibble) only when every mixing value is 4 (stride 1, literal.rs:184-192)
     c->bucket_mix_ok = c->mix && c->geom.mm_uniform == 4 && c->geom.n_btypes == 1u && c->max_stream_len <= 65536u;
 }

@@ -31,6 +31,7 @@ struct LitGeometry {
     int32_t inc0, lim0, inc1, lim1, inc2, lim2, inc3, lim3;  // literal_adaptation Speeds (scalars: no dynamic indexing of kernargs)
     uint32_t bt_first, n_btypes;   // context tables exist for literal block types [bt_first, bt_first + n_btypes)
     uint32_t mix_off;              // byte offset of mixing_mask inside the configuration blob
+    uint32_t lut1_classes;         // distinct literal_lut1 values of the prediction mode (1 for LSB6 / MSB6: the context is a function of prev alone)
 };
 
 // One Literal command of a general stream (codec/mod.rs:711-792): `len` literal bytes coded with the literal block type
@@ -69,7 +70,7 @@ struct RansBatch {
 };
 
 typedef unsigned int bk_u32x2 __attribute__((ext_vector_type(2)));
-// Bucketed encoder model pass (lit_bucket.hip): order-1 configurations without context map or mixing only.
+// Bucketed encoder model pass (lit_bucket.hip): mixing value 4, no mixing, context constant or a function of the previous byte.
 struct BucketBatch {
     const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
     uint32_t n_streams, stream_len, max_stream_len;

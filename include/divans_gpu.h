@@ -184,8 +184,9 @@ int divans_gpu_codec_set_lane_layout(divans_gpu_codec *c, uint32_t lanes_per_str
 /* Encoder model pass: 0 = automatic, 1 = streaming kernels (one walk per stream against its CDF table in HBM),
  * 2 = bucketed (positions grouped by the byte / context that selects their rows, one lane per bucket, rows in LDS;
  * lit_bucket.hip, lit_bucket_mix.hip).  The bucketed pass exists for configurations whose every mixing value is 4
- * (stride 1) and streams of at most 65536 bytes: without context map and mixing (divans_lit_config_simple), or with a
- * context map and dynamic mixing for one literal block type (divans_lit_config_context_mixing).  There it is what
+ * (stride 1) and streams of at most 65536 bytes: without mixing when the context is constant or follows from the previous
+ * byte alone (divans_lit_config_simple; LSB6 / MSB6 prediction modes with any context map, i.e. what the literal-only
+ * compressor emits), or with a context map and dynamic mixing for one literal block type (divans_lit_config_context_mixing).  There it is what
  * "automatic" picks; asking for it elsewhere is DIVANS_GPU_EINVAL.  Both produce the same bytes. */
 int divans_gpu_codec_set_encode_path(divans_gpu_codec *c, uint32_t path);
 /* Streams the bucketed two-model pass takes per launch sequence (default 32768, halved until its work arrays -- 3.4 MB

@@ -289,6 +289,36 @@ def test_bucketed_two_model_pass_over_prediction_modes(mode, corpus, random_then
         codec.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_bucketed_pass_when_the_context_follows_from_prev(mode, corpus, random_then_unicode):
+    # no mixing, mixing value 4, arbitrary context map: LSB6 / MSB6 contexts are a function of the previous byte, so the
+    # order-1 bucketed pass applies (the literal-only compressor's configuration); UTF8 / SIGN contexts need prev_prev
+    import divans_amd as da
+    rng = np.random.default_rng(900 + mode)
+    speeds = [(16, 8192), (64, 16384), (2, 1024), (128, 16384)]
+    L = 20000
+    blocks = np.stack([corpus[3000:3000 + L], random_then_unicode[100000:100000 + L], np.resize(np.frombuffer(b"abcabcabd", dtype=np.uint8), L),
+                       rng.integers(0, 256, L, dtype=np.uint8)])
+    g, o = _random_config(rng, da, 0, mode, [4], speeds)
+    codec = da.LiteralCodec(g, L)
+    if mode >= 2:
+        with pytest.raises(da.DivansGpuError):
+            codec.set_encode_path(2)
+        codec.close()
+        return
+    codec.set_encode_path(2)
+    packed, offs, sizes = codec.encode_host(blocks, L)
+    for i in range(blocks.shape[0]):
+        ref = po.lit_encode(o, blocks[i])
+        got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
+        assert got.size == ref.size and (got == ref).all(), (mode, i)
+    codec.set_encode_path(1)
+    packed1, offs1, sizes1 = codec.encode_host(blocks, L)
+    assert (sizes == sizes1).all() and (packed == packed1).all()
+    assert (codec.decode_host(packed, offs, sizes, L) == blocks).all()
+    codec.close()
+
+
 @pytest.mark.parametrize("cfg_name,encode_path", [("simple", 1), ("simple", 2), ("mixing", 1), ("mixing", 2)])
 def test_model_pass_matches_oracle_trace(cfg_name, encode_path, corpus, shuffle384):
     # the (start, freq) pair of every nibble, straight out of the model pass on a fresh codec (nothing stale to hide
