@@ -1,5 +1,5 @@
 """debug aid: bucketed (2) vs streaming (1) model pass outputs, fresh codec each time"""
-import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle')
+import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch, divans_amd as da, workload
 corpus = workload.load_corpus()
 dev = torch.device('cuda', 0)

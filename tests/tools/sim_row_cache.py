@@ -1,6 +1,6 @@
 """Offline simulation of LDS row-cache organisations on the benchmark workload (design aid, not product)."""
 import sys
-sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle')
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(_R, 'tests')); sys.path.insert(0, os.path.join(_R, 'oracle'))
 import numpy as np, workload, pyoracle as po, ctypes
 
 c = workload.load_corpus()
