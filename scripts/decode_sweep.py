@@ -23,11 +23,11 @@ def main():
     import torch
     import divans_amd as da
     import workload
-    from bench import make_device_blocks
+    from bench import device_blocks
     dev = torch.device("cuda", 0)
     N, L = args.streams, 65536
     corpus = workload.load_corpus()
-    d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev) if args.data == "zeros" else make_device_blocks(torch, workload, corpus, 0, N, L, dev)
+    d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev) if args.data == "zeros" else device_blocks(torch, torch.from_numpy(corpus).to(dev), 0, N, L)
     cfg = da.config_simple() if args.config == "simple" else da.config_context_mixing()
     enc = da.LiteralCodec(cfg, L)
     outs = enc.alloc_encode_outputs(N, L)
