@@ -195,8 +195,8 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
             if (adv && more) { left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece; }       \
             if (adv && !more) { has_task = false; fresh_finish = true; }                                \
         }                                                                                               \
-        /* slot idx is only taken by step idx % 4 of a group: the group's four pairs then fill one aligned 32-byte sector */ \
-        const bool fetch_ = has_task && left != 0u && (idx & 3u) == POS;                                \
+        /* slot idx is only taken by step idx % 8 of an iteration: its pairs then fill aligned sectors */        \
+        const bool fetch_ = has_task && left != 0u && (idx & 7u) == POS;                                \
         const uint8_t* lp = fetch_ ? cur_sorted + (idx & ~3u) : b.sorted;                               \
         const uint32_t nxt_a = fetch_ ? (idx | ((idx & 3u) << 16) | BK_VALID) : 0u;                     \
         idx += fetch_ ? 1u : 0u; left -= fetch_ ? 1u : 0u;                                              \
@@ -204,27 +204,32 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     }
 
     for (;;) {
-        // eight steps per iteration (eight words in flight per lane), stored as two groups of four pairs: one 32-byte
-        // run when the four are neighbours in the sorted order (the usual case inside a bucket), single pairs otherwise
-#define BK_FOUR(E0, A0, E1, A1, E2, A2, E3, A3)                                                         \
+        // eight steps per iteration (eight words in flight per lane); slot idx is taken by step idx % 8, and the pairs leave
+        // after the eighth step as two groups of four: a 32-byte run each when the four are neighbours in the sorted order
+        // (the usual case inside a bucket; both together then fill one aligned 64 bytes), single pairs otherwise
+#define BK_STORE4(PV0, PA0, PV1, PA1, PV2, PA2, PV3, PA3)                                               \
         {                                                                                               \
-            u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0; uint32_t pa0, pa1, pa2, pa3;         \
-            BK_STEP(E0, A0, pv0, pa0, 0u) BK_STEP(E1, A1, pv1, pa1, 1u) BK_STEP(E2, A2, pv2, pa2, 2u) BK_STEP(E3, A3, pv3, pa3, 3u) \
-            const uint32_t i0 = pa0 & 0xffffu;                                                          \
-            const bool run4 = (pa0 & pa1 & pa2 & pa3 & BK_VALID) && (pa1 & 0xffffu) == i0 + 1u && (pa2 & 0xffffu) == i0 + 2u && (pa3 & 0xffffu) == i0 + 3u; \
+            const uint32_t i0 = PA0 & 0xffffu;                                                          \
+            const bool run4 = (PA0 & PA1 & PA2 & PA3 & BK_VALID) && (PA1 & 0xffffu) == i0 + 1u && (PA2 & 0xffffu) == i0 + 2u && (PA3 & 0xffffu) == i0 + 3u; \
             if (run4) {                                                                                 \
-                const u32x4 lo = {pv0.x, pv0.y, pv1.x, pv1.y}, hi = {pv2.x, pv2.y, pv3.x, pv3.y};       \
+                const u32x4 lo = {PV0.x, PV0.y, PV1.x, PV1.y}, hi = {PV2.x, PV2.y, PV3.x, PV3.y};       \
                 bk_store_quad((u32x4*)(cur_sfs + i0), lo); bk_store_quad((u32x4*)(cur_sfs + i0 + 2u), hi); \
             } else {                                                                                    \
-                if (pa0 & BK_VALID) bk_store_pair(cur_sfs + i0, pv0);                                   \
-                if (pa1 & BK_VALID) bk_store_pair(cur_sfs + (pa1 & 0xffffu), pv1);                      \
-                if (pa2 & BK_VALID) bk_store_pair(cur_sfs + (pa2 & 0xffffu), pv2);                      \
-                if (pa3 & BK_VALID) bk_store_pair(cur_sfs + (pa3 & 0xffffu), pv3);                      \
+                if (PA0 & BK_VALID) bk_store_pair(cur_sfs + i0, PV0);                                   \
+                if (PA1 & BK_VALID) bk_store_pair(cur_sfs + (PA1 & 0xffffu), PV1);                      \
+                if (PA2 & BK_VALID) bk_store_pair(cur_sfs + (PA2 & 0xffffu), PV2);                      \
+                if (PA3 & BK_VALID) bk_store_pair(cur_sfs + (PA3 & 0xffffu), PV3);                      \
             }                                                                                           \
         }
-        BK_FOUR(e0, a0, e1, a1, e2, a2, e3, a3)
-        BK_FOUR(e4, a4, e5, a5, e6, a6, e7, a7)
-#undef BK_FOUR
+        {
+            u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0, pv4 = pv0, pv5 = pv0, pv6 = pv0, pv7 = pv0;
+            uint32_t pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7;
+            BK_STEP(e0, a0, pv0, pa0, 0u) BK_STEP(e1, a1, pv1, pa1, 1u) BK_STEP(e2, a2, pv2, pa2, 2u) BK_STEP(e3, a3, pv3, pa3, 3u)
+            BK_STEP(e4, a4, pv4, pa4, 4u) BK_STEP(e5, a5, pv5, pa5, 5u) BK_STEP(e6, a6, pv6, pa6, 6u) BK_STEP(e7, a7, pv7, pa7, 7u)
+            BK_STORE4(pv0, pa0, pv1, pa1, pv2, pa2, pv3, pa3)
+            BK_STORE4(pv4, pa4, pv5, pa5, pv6, pa6, pv7, pa7)
+        }
+#undef BK_STORE4
         // a lane whose bucket ended at least one full iteration ago (all its bytes coded) takes its prefetched task
         const bool bytes_in_flight = fresh_finish;   // bytes requested in this iteration are coded in the next one
         if (!has_task) {

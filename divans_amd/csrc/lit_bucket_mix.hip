@@ -195,8 +195,8 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
             if (adv && more) { left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece; }       \
             if (adv && !more) { has_task = false; fresh_finish = true; }                                \
         }                                                                                               \
-        /* slot idx is only taken by step idx % 4 of a group: the group's records then start on a 32-byte boundary */ \
-        const bool fetch_ = has_task && left != 0u && (idx & 3u) == POS;                                \
+        /* slot idx is only taken by step idx % 8 of an iteration: its records then fill aligned sectors */   \
+        const bool fetch_ = has_task && left != 0u && (idx & 7u) == POS;                                \
         const uint16_t* lp = fetch_ ? cur_sorted + (idx & ~1u) : b.sorted;                              \
         const uint32_t nxt_a = fetch_ ? (idx | ((idx & 1u) << 16) | BK_VALID) : 0u;                     \
         idx += fetch_ ? 1u : 0u; left -= fetch_ ? 1u : 0u;                                              \
@@ -204,28 +204,32 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
     }
 
     for (;;) {
-#define MX_FOUR(E0, A0, E1, A1, E2, A2, E3, A3)                                                         \
+#define MX_STORE4(H0, L0, PA0, H1, L1, PA1, H2, L2, PA2, H3, L3, PA3)                                   \
         {                                                                                               \
-            u32x2 h0 = {0u, 0u}, h1 = h0, h2 = h0, h3 = h0, l0 = h0, l1 = h0, l2 = h0, l3 = h0;         \
-            uint32_t pa0, pa1, pa2, pa3;                                                                \
-            MX_STEP(E0, A0, h0, l0, pa0, 0u) MX_STEP(E1, A1, h1, l1, pa1, 1u) MX_STEP(E2, A2, h2, l2, pa2, 2u) MX_STEP(E3, A3, h3, l3, pa3, 3u) \
-            const uint32_t i0 = pa0 & 0xffffu;                                                          \
-            const bool run4 = (pa0 & pa1 & pa2 & pa3 & BK_VALID) && (pa1 & 0xffffu) == i0 + 1u && (pa2 & 0xffffu) == i0 + 2u && (pa3 & 0xffffu) == i0 + 3u; \
+            const uint32_t i0 = PA0 & 0xffffu;                                                          \
+            const bool run4 = (PA0 & PA1 & PA2 & PA3 & BK_VALID) && (PA1 & 0xffffu) == i0 + 1u && (PA2 & 0xffffu) == i0 + 2u && (PA3 & 0xffffu) == i0 + 3u; \
             if (run4) {                                                                                 \
-                const u32x4 ha = {h0.x, h0.y, h1.x, h1.y}, hb = {h2.x, h2.y, h3.x, h3.y};               \
-                const u32x4 la = {l0.x, l0.y, l1.x, l1.y}, lb = {l2.x, l2.y, l3.x, l3.y};               \
+                const u32x4 ha = {H0.x, H0.y, H1.x, H1.y}, hb = {H2.x, H2.y, H3.x, H3.y};               \
+                const u32x4 la = {L0.x, L0.y, L1.x, L1.y}, lb = {L2.x, L2.y, L3.x, L3.y};               \
                 bk_store_quad((u32x4*)(cur_h + i0), ha); bk_store_quad((u32x4*)(cur_h + i0 + 2u), hb); \
                 bk_store_quad((u32x4*)(cur_l + i0), la); bk_store_quad((u32x4*)(cur_l + i0 + 2u), lb); \
             } else {                                                                                    \
-                if (pa0 & BK_VALID) { bk_store_pair(cur_h + i0, h0); bk_store_pair(cur_l + i0, l0); }   \
-                if (pa1 & BK_VALID) { bk_store_pair(cur_h + (pa1 & 0xffffu), h1); bk_store_pair(cur_l + (pa1 & 0xffffu), l1); } \
-                if (pa2 & BK_VALID) { bk_store_pair(cur_h + (pa2 & 0xffffu), h2); bk_store_pair(cur_l + (pa2 & 0xffffu), l2); } \
-                if (pa3 & BK_VALID) { bk_store_pair(cur_h + (pa3 & 0xffffu), h3); bk_store_pair(cur_l + (pa3 & 0xffffu), l3); } \
+                if (PA0 & BK_VALID) { bk_store_pair(cur_h + i0, H0); bk_store_pair(cur_l + i0, L0); }   \
+                if (PA1 & BK_VALID) { bk_store_pair(cur_h + (PA1 & 0xffffu), H1); bk_store_pair(cur_l + (PA1 & 0xffffu), L1); } \
+                if (PA2 & BK_VALID) { bk_store_pair(cur_h + (PA2 & 0xffffu), H2); bk_store_pair(cur_l + (PA2 & 0xffffu), L2); } \
+                if (PA3 & BK_VALID) { bk_store_pair(cur_h + (PA3 & 0xffffu), H3); bk_store_pair(cur_l + (PA3 & 0xffffu), L3); } \
             }                                                                                           \
         }
-        MX_FOUR(e0, a0, e1, a1, e2, a2, e3, a3)
-        MX_FOUR(e4, a4, e5, a5, e6, a6, e7, a7)
-#undef MX_FOUR
+        {   // slot idx is taken by step idx % 8; the records leave after the eighth step, 32 aligned bytes per plane and group of four
+            u32x2 h0 = {0u, 0u}, h1 = h0, h2 = h0, h3 = h0, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
+            u32x2 l0 = h0, l1 = h0, l2 = h0, l3 = h0, l4 = h0, l5 = h0, l6 = h0, l7 = h0;
+            uint32_t pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7;
+            MX_STEP(e0, a0, h0, l0, pa0, 0u) MX_STEP(e1, a1, h1, l1, pa1, 1u) MX_STEP(e2, a2, h2, l2, pa2, 2u) MX_STEP(e3, a3, h3, l3, pa3, 3u)
+            MX_STEP(e4, a4, h4, l4, pa4, 4u) MX_STEP(e5, a5, h5, l5, pa5, 5u) MX_STEP(e6, a6, h6, l6, pa6, 6u) MX_STEP(e7, a7, h7, l7, pa7, 7u)
+            MX_STORE4(h0, l0, pa0, h1, l1, pa1, h2, l2, pa2, h3, l3, pa3)
+            MX_STORE4(h4, l4, pa4, h5, l5, pa5, h6, l6, pa6, h7, l7, pa7)
+        }
+#undef MX_STORE4
         const bool bytes_in_flight = fresh_finish;
         if (!has_task) {
             if (fresh_finish) fresh_finish = false;
