@@ -289,6 +289,47 @@ def test_bucketed_two_model_pass_over_prediction_modes(mode, corpus, random_then
         codec.close()
 
 
+def test_bucketed_two_model_pass_random_stress(corpus, random_then_unicode):
+    # random palette speeds, context maps, block types, prediction modes and ragged lengths (0 .. 64 KiB) through the
+    # device-pointer entry point: bucketed pass == streaming kernel on every stream, oracle on a sample
+    import torch
+    import divans_amd as da
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4242)
+    palette = [(1, 16384), (1, 1024), (2, 1024), (4, 2048), (8, 4096), (16, 8192), (32, 4096), (64, 16384), (128, 16384), (256, 16384), (1024, 16384)]
+    src = np.tile(np.concatenate([corpus, random_then_unicode]), 8)
+    for trial in range(6):
+        speeds = [palette[int(k)] for k in rng.integers(0, len(palette), 4)]
+        g, o = _random_config(rng, da, 2, int(rng.integers(0, 4)), [4], speeds)
+        n = 48
+        lens = rng.integers(0, 65537, n).astype(np.int32)
+        lens[:5] = [0, 1, 2, 65536, 8193]
+        starts = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+        base = int(rng.integers(0, src.size - int(lens.sum()) - 64))
+        flat = src[base:base + int(lens.sum())].copy()
+        if trial % 2:
+            flat[::97] ^= 0x5a
+        d_in = torch.from_numpy(np.concatenate([flat, np.zeros(64, np.uint8)])).to(dev)
+        d_off = torch.from_numpy(starts).to(dev); d_sz = torch.from_numpy(lens).to(dev)
+        codec = da.LiteralCodec(g, 65536)
+        got = []
+        for path in (2, 1):
+            codec.set_encode_path(path)
+            outs = codec.alloc_encode_outputs(n)
+            codec.encode_batch(d_in, n, 65536, outs, in_offsets=d_off, in_sizes=d_sz)
+            torch.cuda.synchronize()
+            assert codec.status() == 0
+            got.append((outs["offsets"].cpu().numpy(), outs["sizes"].cpu().numpy(), outs["out"].cpu().numpy()))
+        (o2, s2, b2), (o1, s1, b1) = got
+        assert (s2 == s1).all(), trial
+        for i in range(n):
+            assert (b2[o2[i]:o2[i] + s2[i]] == b1[o1[i]:o1[i] + s1[i]]).all(), (trial, i)
+        for i in (0, 1, 2, 4, 7, n - 1):
+            ref = po.lit_encode(o, flat[starts[i]:starts[i] + lens[i]])
+            assert s2[i] == ref.size and (b2[o2[i]:o2[i] + s2[i]] == ref).all(), (trial, i)
+        codec.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_bucketed_pass_when_the_context_follows_from_prev(mode, corpus, random_then_unicode):
     # no mixing, mixing value 4, arbitrary context map: LSB6 / MSB6 contexts are a function of the previous byte, so the
