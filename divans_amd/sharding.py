@@ -58,10 +58,20 @@ def gather_stream_sizes(local_sizes, n_streams):
     return torch.cat(out)
 
 
+MAX_MESSAGE_BYTES = 1 << 30   # a shard (4 GiB at BASELINE configs[1]) travels as several messages: no 32-bit count anywhere on the way
+
+
 def _run_p2p(ops):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+
+
+def _pieces(t):
+    """`t` (contiguous) as a list of flat views of at most MAX_MESSAGE_BYTES each; sender and receiver cut alike."""
+    flat = t.reshape(-1)
+    step = max(1, MAX_MESSAGE_BYTES // max(1, flat.element_size()))
+    return [flat[i:i + step] for i in range(0, flat.numel(), step)]
 
 
 def scatter_streams(all_streams, n_streams, stream_len, device, dtype=torch.uint8):
@@ -76,12 +86,12 @@ def scatter_streams(all_streams, n_streams, stream_len, device, dtype=torch.uint
         for r in range(1, world):
             rb, re = shard_bounds(n_streams, r, world)
             if re > rb:
-                ops.append(dist.P2POp(dist.isend, all_streams[rb:re].contiguous(), r))
+                ops.extend(dist.P2POp(dist.isend, piece, r) for piece in _pieces(all_streams[rb:re].contiguous()))
         _run_p2p(ops)
         return all_streams[b:e]
     mine = torch.empty((e - b, stream_len), dtype=dtype, device=device)
     if e > b:
-        _run_p2p([dist.P2POp(dist.irecv, mine, 0)])
+        _run_p2p([dist.P2POp(dist.irecv, piece, 0) for piece in _pieces(mine)])
     return mine
 
 
@@ -109,12 +119,12 @@ def gather_coded(local_packed, local_sizes, n_streams):
         ops, pos = [], shard_bytes[0]
         for r in range(1, world):
             if shard_bytes[r]:
-                ops.append(dist.P2POp(dist.irecv, blob[pos:pos + shard_bytes[r]], r))
+                ops.extend(dist.P2POp(dist.irecv, piece, r) for piece in _pieces(blob[pos:pos + shard_bytes[r]]))
             pos += shard_bytes[r]
         _run_p2p(ops)
         return blob, offs, sizes
     if shard_bytes[rank]:
-        _run_p2p([dist.P2POp(dist.isend, local_packed[:shard_bytes[rank]].contiguous(), 0)])
+        _run_p2p([dist.P2POp(dist.isend, piece, 0) for piece in _pieces(local_packed[:shard_bytes[rank]].contiguous())])
     return None, None, sizes
 
 

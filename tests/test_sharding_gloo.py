@@ -36,6 +36,7 @@ def _worker(rank, world, port, n_streams, q):
     import pyoracle as po
     import workload
     from divans_amd import sharding
+    sharding.MAX_MESSAGE_BYTES = 3001        # shards travel as several messages each (the 1 GiB limit, scaled to the test)
     cpu = torch.device("cpu")
     full = None
     if rank == 0:   # rank 0 holds the corpus
