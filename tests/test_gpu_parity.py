@@ -484,6 +484,11 @@ def test_pipelined_host_wrappers_match_the_serial_ones(cfg_name, slice_streams, 
     bad = packed.copy(); bad[int(offs[n // 2]) + 20] ^= 0x40
     with pytest.raises(da.DivansGpuError):
         codec.decode_host_pipelined(bad, offs, sizes, L, slice_streams=slice_streams)
+    # an output buffer that cannot hold the packed streams is refused, and the codec stays usable
+    with pytest.raises(da.DivansGpuError):
+        codec.encode_host_pipelined(blocks, L, slice_streams=slice_streams, out=np.empty(1000, np.uint8))
+    p3, o3, s3 = codec.encode_host_pipelined(blocks, L, slice_streams=slice_streams)
+    assert (s3 == sizes).all() and (p3 == packed).all()
     for b in (pin_in, pin_out, pin_back):
         b.close()
     codec.close()
