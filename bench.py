@@ -97,11 +97,12 @@ def usable_parallelism():
     return info
 
 
-def cpu_baseline(cfg_name, workload, corpus, block_len):
+def cpu_baseline(cfg_name, workload, corpus, block_len, sample_blocks=None, decode_only=False, per_thread=None):
     """The C oracle ("port" of the reference CPU path) timed on this box's host cores on a bounded sample of the same
-    workload: (1) one thread, 256 blocks; (2) one independent stream per worker on every usable core.  Workers allocate
-    their coder state and buffers before a start barrier; each direction is timed as wall clock from the barrier release
-    to the last worker finishing (oracle/literal.c orc_lit_batch_bench)."""
+    workload: (1) one thread; (2) one independent stream per worker on every usable core.  Workers allocate their coder
+    state and buffers before a start barrier; each direction is timed as wall clock from the barrier release to the last
+    worker finishing (oracle/literal.c orc_lit_batch_bench).  sample_blocks(n) supplies n blocks of the workload (default:
+    tests/workload.py blocks 0..n-1); decode_only reports the decode direction alone (BASELINE configs[3])."""
     import ctypes
     import pyoracle as po
     try:
@@ -110,29 +111,35 @@ def cpu_baseline(cfg_name, workload, corpus, block_len):
         lib = po.lib()
     cfg = po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
     par = usable_parallelism()
+    if sample_blocks is None:
+        sample_blocks = lambda n: workload.make_blocks(corpus, 0, n, block_len=block_len)
 
     def run(n, threads):
-        blocks = workload.make_blocks(corpus, 0, n, block_len=block_len)
+        blocks = sample_blocks(n)
         enc = ctypes.c_double(0); dec = ctypes.c_double(0); coded = ctypes.c_uint64(0)
         rc = lib.orc_lit_batch_bench(ctypes.byref(cfg), blocks.ctypes.data, n, block_len, threads,
                                      ctypes.byref(enc), ctypes.byref(dec), ctypes.byref(coded))
         assert rc == 0, "oracle round trip failed"
         total = n * block_len
+        both = enc.value + dec.value
         return {"streams": n, "threads": threads, "enc_s": enc.value, "dec_s": dec.value,
                 "encode_MBps": round(total / 1e6 / enc.value, 2), "decode_MBps": round(total / 1e6 / dec.value, 2),
-                "MBps": round(total / 1e6 / (enc.value + dec.value), 2)}
+                "MBps": round(total / 1e6 / (dec.value if decode_only else both), 2)}
 
     scale = max(1, 65536 // max(block_len, 1))
-    single = run((256 if cfg_name == "simple" else 96) * scale, 1)
+    if per_thread is None:
+        per_thread = 256 if cfg_name == "simple" else 96
+    single = run(per_thread * scale, 1)
     threads = par["usable"]
-    allc = run(threads * (256 if cfg_name == "simple" else 96) * scale, threads)
+    allc = run(threads * per_thread * scale, threads)
     factor = allc["MBps"] / single["MBps"]
     note = ""
     if factor < 0.5 * threads:
         note = (f"; all-core scaling {factor:.1f}x of {threads} threads: every worker walks its own 12.6 MB of prior tables "
                 f"(2 x 3*256*256 rows as the reference lays them out, codec/priors.rs:35-37), so the cores share L3 / memory bandwidth")
+    what = "decode only" if decode_only else "encode+decode"
     return {
-        "value": allc["MBps"], "unit": "MB/s", "cores": threads, "kind": "port",
+        "value": allc["MBps"], "unit": f"MB/s {what}", "cores": threads, "kind": "port",
         "sample": (f"all cores: {allc['streams']} x {block_len} B streams of the same workload on {threads} threads (1 stream per thread at a time), "
                    f"wall enc {allc['enc_s']:.2f}s + dec {allc['dec_s']:.2f}s; single thread: {single['streams']} streams, "
                    f"enc {single['enc_s']:.2f}s + dec {single['dec_s']:.2f}s; buffers allocated before the start barrier" + note),
@@ -144,12 +151,15 @@ def cpu_baseline(cfg_name, workload, corpus, block_len):
 
 
 def load_traffic(cfg_name, n, block_len):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (profiles/traffic_latest.json)."""
+    """HBM bytes per launch REPLAYED from the committed rocprofv3 PMC passes of this same workload (profiles/traffic_latest.json;
+    counters cannot be collected inside a plain bench run).  The returned dict carries the profile tag under "_source"."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         ent = tj if "configs" not in tj else tj["configs"].get(cfg_name, {})
         if ent.get("streams") == n and ent.get("block_bytes") == block_len and ent.get("config", cfg_name) == cfg_name:
-            return ent["kernels"]
+            k = dict(ent["kernels"])
+            k["_source"] = f"replayed from profiles/traffic_latest.json (rocprofv3 --pmc passes, tag {tj.get('tag', ent.get('tag', '?'))}), not measured in this run"
+            return k
     except Exception:
         pass
     return {}
@@ -160,7 +170,9 @@ def roofline_of(kern_ms, alg_bytes, traffic):
     achieved = alg_bytes[dom] / 1e9 / (kern_ms[dom] / 1e3) if kern_ms[dom] > 0 else 0.0
     t = traffic.get(dom, {}).get("hbm_bytes_per_launch") if traffic else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": t, "algorithmic_bytes_per_launch": alg_bytes[dom]}
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": t,
+            "traffic_source": (traffic.get("_source") if t is not None else "no committed PMC pass matches this kernel / workload"),
+            "algorithmic_bytes_per_launch": alg_bytes[dom]}
 
 
 def spawn_ranks(args):
@@ -176,19 +188,27 @@ def spawn_ranks(args):
 
 
 def timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, warmup, barrier):
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    rec = {"enc": [], "dec": [], "model": [], "rans": [], "dkern": []}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    rec = {"enc": [], "dec": [], "model": [], "rans": [], "dkern": [], "pack": []}
+    # the coded streams leave the encoder contiguous (divans_gpu_pack_streams is part of the timed encode: that is what
+    # north_star's "gather of coded streams" ships) and the decoder reads them from there
+    packed = torch.empty(outs["out"].numel(), dtype=torch.uint8, device=d_in.device)
+    poff = torch.empty(N, dtype=torch.int64, device=d_in.device)
+    ptotal = torch.zeros(1, dtype=torch.int64, device=d_in.device)
+    outs["packed"], outs["packed_offsets"], outs["packed_total"] = packed, poff, ptotal
 
     def step(record):
         # the codec launches on torch's current stream, so these events bracket its kernels
         ev[0].record()
         codec.encode_batch(d_in, N, L, outs)
+        ev[3].record()
+        codec.pack_into(outs, N, packed, poff, ptotal)
         ev[1].record()
-        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
+        codec.decode_batch(packed, poff, outs["sizes"], N, L, d_back)
         ev[2].record()
         if record:
             torch.cuda.synchronize()
-            rec["enc"].append(ev[0].elapsed_time(ev[1])); rec["dec"].append(ev[1].elapsed_time(ev[2]))
+            rec["enc"].append(ev[0].elapsed_time(ev[1])); rec["dec"].append(ev[1].elapsed_time(ev[2])); rec["pack"].append(ev[3].elapsed_time(ev[1]))
             inf = codec.info()   # hipEvent timings taken inside the C ABI around each kernel launch, on the launch stream
             rec["model"].append(inf.last_model_ms); rec["rans"].append(inf.last_rans_ms); rec["dkern"].append(inf.last_decode_ms)
 
@@ -204,19 +224,27 @@ def timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, warmup, barrier):
 
 def verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, n_check):
     """Correctness on the codec's very first pass (its scratch holds nothing from an earlier pass that could stand in for
-    skipped work), outside the timed region: exact round trip of every stream + coded bytes == oracle on a spread of streams."""
+    skipped work), outside the timed region: exact round trip of every stream + coded bytes == oracle on a spread of
+    n_check streams (the oracle encodes them on every usable host core, oracle/literal.c orc_lit_batch_check)."""
+    import numpy as np
     codec.encode_batch(d_in, N, L, outs)
     codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
     torch.cuda.synchronize()
     ok = bool(torch.equal(d_back, d_in)) and codec.status() == 0
-    offs = outs["offsets"].cpu().numpy(); sz = outs["sizes"].cpu().numpy()
-    picks = sorted(set([0, N // 2, N - 1] + list(range(0, N, max(1, N // n_check)))))
-    host_in = d_in[picks].cpu().numpy()
-    for k, i in enumerate(picks):
-        ref = po.lit_encode(ocfg, host_in[k])
-        got = outs["out"][int(offs[i]):int(offs[i]) + int(sz[i])].cpu().numpy()
-        ok = ok and got.size == ref.size and bool((got == ref).all())
-    return ok, len(picks)
+    picks = sorted(set([0, N // 2, N - 1] + list(range(0, N, max(1, N // max(n_check, 1))))))
+    idx = torch.tensor(picks, dtype=torch.int64, device=d_in.device)
+    host_in = d_in[idx].cpu().numpy()
+    offs = outs["offsets"][idx].cpu().numpy().astype(np.int64); sz = outs["sizes"][idx].cpu().numpy().astype(np.int64)
+    # gather the picked streams' coded bytes into one host blob
+    starts = np.concatenate([[0], np.cumsum(sz[:-1])]).astype(np.int64)
+    pos = torch.arange(int(sz.sum()), device=d_in.device, dtype=torch.int64)
+    seg = torch.repeat_interleave(torch.arange(len(picks), device=d_in.device), torch.tensor(sz, device=d_in.device))
+    src = torch.tensor(offs, device=d_in.device)[seg] + (pos - torch.tensor(starts, device=d_in.device)[seg])
+    blob = outs["out"][src].cpu().numpy()
+    bad, first = po.lit_batch_check(ocfg, host_in, blob, starts.astype(np.uint64), sz.astype(np.uint32), threads=usable_parallelism()["usable"])
+    if bad:
+        sys.stderr.write(f"bench: {bad} of {len(picks)} checked streams differ from the oracle, first: stream {picks[first]}\n")
+    return ok and bad == 0, len(picks)
 
 
 def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note=""):
@@ -248,11 +276,13 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
         ok = ok and bool(torch.equal(outs["sizes"], first_sizes)) and bool(torch.equal(d_back, d_in)) and codec.status() == 0
     coded_total = int(outs["sizes"].to(torch.int64).sum().item())
     avg = lambda xs: sum(xs) / max(len(xs), 1)
-    kern = {"lit_decode_kernel": avg(rec["dkern"]), "encode_model_pass": avg(rec["model"]), "encode_rans_pass": avg(rec["rans"])}
+    kern = {"lit_decode_kernel": avg(rec["dkern"]), "encode_model_pass": avg(rec["model"]), "encode_rans_pass": avg(rec["rans"]),
+            "pack_streams": avg(rec["pack"])}
     raw = N * L
     # algorithmic bytes per launch: decode reads C + writes raw; the model pass reads raw and hands
     # 4 B per nibble to the rANS pass; the rANS pass reads that spill and writes C
-    alg = {"lit_decode_kernel": raw + coded_total, "encode_model_pass": raw + 8 * raw, "encode_rans_pass": 8 * raw + coded_total}
+    alg = {"lit_decode_kernel": raw + coded_total, "encode_model_pass": raw + 8 * raw, "encode_rans_pass": 8 * raw + coded_total,
+           "pack_streams": 2 * coded_total}
     res = {
         "elapsed": elapsed, "steps": steps, "ok": ok, "checked_vs_oracle": checked, "coded_total": coded_total,
         "encode_MBps": round(raw / 1e6 / (avg(rec["enc"]) / 1e3), 2), "decode_MBps": round(raw / 1e6 / (avg(rec["dec"]) / 1e3), 2),
@@ -328,7 +358,7 @@ def main():
     ap.add_argument("--block-len", type=int, default=65536)
     ap.add_argument("--config", choices=["all", "simple", "mixing", "decode_only"], default="all",
                     help="all = configs[1] as the headline + configs[2] and configs[3] as sub-records (N = 1); a single name runs only that one")
-    ap.add_argument("--check-streams", type=int, default=256, help="streams whose coded bytes are compared with the oracle before timing")
+    ap.add_argument("--check-streams", type=int, default=4096, help="streams whose coded bytes are compared with the oracle before timing")
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per stream, 8 or 16 (tuning)")
@@ -480,8 +510,19 @@ def main():
                 "encode_MBps": r2["encode_MBps"], "decode_MBps": r2["decode_MBps"], "compressed_ratio": round(r2["coded_total"] / float(N * L), 4),
                 "kernel_ms": r2["kernel_ms"], "roofline": r2["roofline"],
             }
+            if not args.no_cpu_baseline:
+                sub["mixing"]["cpu_baseline"] = cpu_baseline("mixing", workload, corpus, L)
         if args.config in ("all", "decode_only"):
             sub["decode_only"] = run_decode_only(torch, da, po, args, dev)
+            if not args.no_cpu_baseline:
+                import lzma
+                with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
+                    rtu = np.frombuffer(f.read(), dtype=np.uint8).copy()
+                full = rtu[:(rtu.size // 65536) * 65536].reshape(-1, 65536)     # the four whole 64 KiB blocks of the file
+                cb = cpu_baseline("mixing", workload, corpus, 65536, sample_blocks=lambda n: np.ascontiguousarray(full[np.arange(n) % full.shape[0]]),
+                                  decode_only=True, per_thread=96)
+                cb["sample"] = "decode direction of: " + cb["sample"].replace("streams of the same workload", "streams (the four whole 64 KiB blocks of testdata/random_then_unicode, repeated)")
+                sub["decode_only"]["cpu_baseline"] = cb
         if line is None:
             line = {"metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU", "value": None, "unit": "MB/s", "n_gpus": 1,
                     "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic",

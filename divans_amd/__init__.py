@@ -117,6 +117,8 @@ def load_library():
     L.divans_gpu_codec_info.argtypes = [vp, ctypes.POINTER(GpuInfo)]
     L.divans_gpu_codec_set_geometry.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
+    L.divans_gpu_codec_set_decoder.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]
+    L.divans_gpu_codec_set_decoder.restype = ctypes.c_int
     L.divans_gpu_codec_set_lane_layout.argtypes = [vp, u32]
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
     L.divans_gpu_codec_set_bucket_batch.argtypes = [vp, u32]
@@ -163,7 +165,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
@@ -322,6 +324,14 @@ class LiteralCodec:
     def set_lane_layout(self, lanes_per_stream):
         _check(self._lib.divans_gpu_codec_set_lane_layout(self._h, int(lanes_per_stream)), "set_lane_layout")
 
+    def set_decoder(self, generation=2, rows=None, shifts=None, blocks=0):
+        """Decode kernel generation (2 = lit_decode2.hip, 1 = lit_kernels.hip) and, for generation 2, the rows / hash shifts of its
+        four direct-mapped caches (high stride, high context-map, low stride, low context-map rows) and its persistent grid."""
+        u32x4 = ctypes.c_uint32 * 4
+        r = u32x4(*[int(x) for x in rows]) if rows is not None else None
+        sh = u32x4(*[int(x) for x in (shifts if shifts is not None else (5, 5, 5, 5))]) if rows is not None else None
+        _check(self._lib.divans_gpu_codec_set_decoder(self._h, int(generation), r, sh, int(blocks)), "set_decoder")
+
     def set_split_cache(self, high_rows, low_rows):
         _check(self._lib.divans_gpu_codec_set_split_cache(self._h, int(high_rows), int(low_rows)), "set_split_cache")
 
@@ -409,6 +419,12 @@ class LiteralCodec:
             self._h, d_coded.data_ptr(), d_offsets.data_ptr(), d_sizes.data_ptr(), int(n_streams),
             d_out.data_ptr(), out_offsets.data_ptr() if out_offsets is not None else None,
             out_sizes.data_ptr() if out_sizes is not None else None, int(stream_len)), "divans_gpu_lit_decode_batch")
+
+    def pack_into(self, outputs, n_streams, packed, packed_offsets, total):
+        """divans_gpu_pack_streams into caller-owned tensors (packed: uint8, >= sum of 4-byte-rounded sizes; offsets int64[n]; total int64[1])."""
+        _check(self._lib.divans_gpu_pack_streams(self._h, outputs["out"].data_ptr(), outputs["offsets"].data_ptr(),
+                                                 outputs["sizes"].data_ptr(), int(n_streams), packed.data_ptr(),
+                                                 packed_offsets.data_ptr(), total.data_ptr()), "divans_gpu_pack_streams")
 
     def pack(self, outputs, n_streams):
         t = self._torch

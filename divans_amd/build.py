@@ -1,13 +1,20 @@
-"""Builds divans_amd/libdivans_hip.so (HIP kernels + C ABI) in-tree with hipcc for gfx950."""
+"""Builds divans_amd/libdivans_hip.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+Every source is compiled to its own object (in parallel, only when it or a header changed) under divans_amd/build/, then
+linked; the objects stay out of history and off the GPU box's critical path (only the .so is loaded)."""
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdivans_hip.so")
-SOURCES = ["lit_kernels.hip", "lit_kernels_p8.hip", "lit_bucket.hip", "lit_bucket_mix.hip", "capi.cpp", "host_stream.cpp", "ffi.cpp", "ir.cpp", "batch.cpp"]
+SOURCES = ["lit_kernels.hip", "lit_decode2.hip", "lit_kernels_p8.hip", "lit_bucket.hip", "lit_bucket_mix.hip", "capi.cpp", "host_stream.cpp",
+           "ffi.cpp", "ir.cpp", "batch.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():
@@ -17,25 +24,60 @@ def hipcc():
     raise RuntimeError("hipcc not found: the divans HIP extension cannot be built")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(HERE, "..", "include", h) for h in ("divans_gpu.h", "divans_ffi.h", "divans_ir.h", "divans_batch.h")]
+    return [h for h in hs if os.path.exists(h)]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", h) for h in ("divans_gpu.h", "divans_ffi.h", "divans_ir.h", "divans_batch.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def is_stale():
+    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB] + os.environ.get("DIVANS_EXTRA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    extra = os.environ.get("DIVANS_EXTRA_HIPCC_FLAGS", "").split()
+    headers = _headers()
+    flags_tag = os.path.join(OBJ, "flags.txt")
+    flags_now = " ".join(FLAGS + extra)
+    if not os.path.exists(flags_tag) or open(flags_tag).read() != flags_now:
+        force = True
+
+    def compile_one(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, src + ".o")
+        if not force and not _stale(obj, [path] + headers):
+            return obj, None
+        res = subprocess.run([cc] + FLAGS + extra + ["-x", "hip", "-c", path, "-o", obj], capture_output=True, text=True)
+        if res.returncode != 0:
+            return obj, res.stdout + res.stderr
+        return obj, res.stderr if verbose else None
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    objs = []
+    for obj, msg in results:
+        if msg:
+            sys.stderr.write(msg)
+        if not os.path.exists(obj) or (msg and "error" in msg):
+            raise RuntimeError("hipcc failed building libdivans_hip.so")
+        objs.append(obj)
+    res = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building libdivans_hip.so")
-    if verbose:
-        sys.stderr.write(res.stderr)
+        raise RuntimeError("hipcc failed linking libdivans_hip.so")
+    with open(flags_tag, "w") as f:
+        f.write(flags_now)
     return LIB
 
 

@@ -103,6 +103,10 @@ struct divans_gpu_codec {
     uint32_t cache_high = 0, cache_low = 0;   // per-stream LDS row caches (rows; 0 = that table is accessed in HBM/L2 directly)
     bool cache_unified = false;
     bool packed8 = false;         // non-mixing configurations: 8 lanes per stream, two CDF entries per lane (lit_kernels_p8.hip)
+    // decoder generation: 2 = lit_decode2.hip (direct-mapped row caches, LDS word ring), 1 = lit_decode_kernel of lit_kernels.hip
+    uint32_t decode_gen = 2;
+    uint32_t dm_log2 = 0, dm_shift = 0;   // LitBatch::dm_log2 / dm_shift
+    uint32_t blocks2 = 0;                 // persistent grid of lit_decode2_kernel
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
@@ -215,7 +219,8 @@ static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
 }
 
 static uint32_t groups_per_block(const divans_gpu_codec* c) { return c->packed8 ? LIT_THREADS / 8 : LIT_THREADS / 16; }
-static uint32_t resident_groups(const divans_gpu_codec* c) { return c->blocks * groups_per_block(c); }
+static bool use_decode2(const divans_gpu_codec* c) { return c->decode_gen == 2u && !c->packed8 && c->blocks2 != 0u; }
+static uint32_t resident_groups(const divans_gpu_codec* c) { return std::max(c->blocks, use_decode2(c) ? c->blocks2 : 0u) * groups_per_block(c); }
 
 static int ensure_tables(divans_gpu_codec* c) {
     // big geometries (many context columns / planes) shrink the persistent grid instead of asking for hundreds of GB:
@@ -225,6 +230,7 @@ static int ensure_tables(divans_gpu_codec* c) {
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && c->tables_bytes == 0) {
         const size_t budget = std::max<size_t>(free_b / 4, per_block);
         if ((size_t)c->blocks * per_block > budget) c->blocks = (uint32_t)std::max<size_t>(1, budget / per_block);
+        if ((size_t)c->blocks2 * per_block > budget) c->blocks2 = (uint32_t)std::max<size_t>(1, budget / per_block);
     }
     const size_t need = (size_t)resident_groups(c) * c->geom.total_rows * 32u;
     if (need <= c->tables_bytes) return 0;
@@ -259,6 +265,21 @@ static void configure_from_geometry(divans_gpu_codec* c) {
                                     (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
         const uint32_t fit = (160u * 1024u) / lds_per_wg;
         c->blocks = c->num_cus * std::max(1u, std::min(7u, fit));
+    }
+    // lit_decode2_kernel: direct-mapped caches, 16-bit row ids in the tags.  Defaults (profiles/r03_*): the high stride rows get 32
+    // slots -- indexed by the previous byte itself when the context is constant, by row ^ (row >> 5) otherwise -- and with prior
+    // mixing the FirstNibble context-map rows 16 of their own; the low-nibble rows are many and stay in HBM / L2.
+    c->blocks2 = 0; c->dm_log2 = 0; c->dm_shift = 0;
+    if (c->geom.total_rows < 0xffffu) {
+        if (c->mix) { c->dm_log2 = 5u | (5u << 8); c->dm_shift = 5u | (5u << 8); }
+        else { c->dm_log2 = 6u; c->dm_shift = c->geom.ctx_const >= 0 ? 31u : 5u; }
+    }
+    {
+        const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
+        const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) +
+                                    (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
+        const uint32_t fit = (160u * 1024u) / lds_per_wg;
+        c->blocks2 = c->num_cus * std::max(1u, std::min(7u, fit));
     }
     // order-1 rows: high row [ctx][prev], low row [prev][hi] with the context constant, or a function of prev alone (one lut1
     // class and one block type: LSB6 / MSB6 -- what the reference's literal-only compressor emits, raw_to_cmd/mod.rs:115-140)
@@ -440,6 +461,42 @@ extern "C" int divans_gpu_codec_set_lane_layout(divans_gpu_codec* c, uint32_t la
     return 0;
 }
 
+// Decoder generation and the geometry of lit_decode2_kernel: rows[i] of the four direct-mapped caches (high stride, high
+// context-map, low stride, low context-map rows; 0 = not cached, else a power of two in [4, 256]), their hash shifts, and
+// the persistent grid (0 = keep).
+extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (generation != 1u && generation != 2u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1 or 2");
+    HIP_TRY(hipSetDevice(c->device));
+    if (generation == 2u && rows && shifts) {
+        uint32_t lg2 = 0, sh = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (rows[i]) {
+                if (rows[i] < 4u || rows[i] > 256u || (rows[i] & (rows[i] - 1u))) return fail(DIVANS_GPU_EINVAL, "cache rows must be 0 or a power of two in [4, 256]");
+                if (c->geom.total_rows >= 0xffffu) return fail(DIVANS_GPU_EINVAL, "row caches need fewer than 65535 rows per stream");
+                uint32_t l = 0; while ((1u << l) < rows[i]) ++l;
+                lg2 |= (l + 1u) << (8 * i);
+            }
+            if (shifts[i] > 31u) return fail(DIVANS_GPU_EINVAL, "hash shift must be below 32");
+            sh |= shifts[i] << (8 * i);
+        }
+        c->dm_log2 = lit_decode2_effective_caches(lg2, c->mix, false); c->dm_shift = sh;   // only the cache sets that exist as kernel instances
+    }
+    const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
+    const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) +
+                                (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
+    const uint32_t fit = (160u * 1024u) / lds_per_wg;
+    if (fit == 0u) return fail(DIVANS_GPU_EINVAL, "these caches do not fit the 160 KB of LDS");
+    uint32_t nb = blocks ? blocks : c->blocks2;
+    nb = std::min(nb, c->num_cus * std::min(8u, fit));
+    if (generation == 2u && nb > c->blocks2 && c->d_tables) {   // more resident streams than the tables were sized for
+        HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0;
+    }
+    if (generation == 2u) c->blocks2 = std::max(1u, nb);
+    c->decode_gen = generation;
+    return 0;
+}
+
 static bool valid_cache_rows(uint32_t r) { return r == 0 || (r >= 16 && r <= 256 && (r & (r - 1)) == 0); }
 
 extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t cache_rows) {
@@ -448,8 +505,17 @@ extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t block
         if (!valid_cache_rows(cache_rows)) return fail(DIVANS_GPU_EINVAL, "cache_rows must be 0 or a power of two in [16, 256]");
         if (cache_rows && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
         c->cache_high = cache_rows; c->cache_low = 0; c->cache_unified = cache_rows != 0;
+        c->decode_gen = 1;   // these are the caches of the first-generation decoder (and of the streaming model kernel)
     }
-    if (blocks) c->blocks = blocks;
+    if (blocks) {
+        c->blocks = blocks;
+        if (c->blocks2) {    // the second-generation decoder follows, as far as its LDS use allows
+            const uint32_t keep_log2 = c->dm_log2;
+            const uint32_t gen = c->decode_gen;
+            int rc = divans_gpu_codec_set_decoder(c, 2, nullptr, nullptr, blocks); if (rc) return rc;
+            c->decode_gen = gen; c->dm_log2 = keep_log2;
+        }
+    }
     return 0;
 }
 
@@ -459,6 +525,7 @@ extern "C" int divans_gpu_codec_set_split_cache(divans_gpu_codec* c, uint32_t hi
     if (high_rows == 0 && low_rows != 0) return fail(DIVANS_GPU_EINVAL, "a low-nibble cache needs a high-nibble cache");
     if ((high_rows || low_rows) && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
     c->cache_high = high_rows; c->cache_low = low_rows; c->cache_unified = false;
+    c->decode_gen = 1;
     return 0;
 }
 
@@ -640,8 +707,13 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
     if (d_segs && (c->packed8 || (b.cache_mode != 2u && b.cache_mode != 0u))) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache or none");
+    if (use_decode2(c)) {
+        b.dm_log2 = lit_decode2_effective_caches(c->dm_log2, c->mix, d_segs != nullptr); b.dm_shift = c->dm_shift;
+        b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
+    }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     if (c->packed8) HIP_TRY(launch_decode_p8(b, c->blocks, c->stream));
+    else if (use_decode2(c)) HIP_TRY(launch_decode2(b, c->mix, c->blocks2, c->stream));
     else HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     c->timing_pending_dec = true;

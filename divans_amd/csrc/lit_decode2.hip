@@ -1,0 +1,497 @@
+// lit_decode2.hip -- the literal decoder's second generation: the same 16-lane DPP-row mapping as lit_kernels.hip
+// (lane i of a row holds cdf[i], four streams per wave64), rebuilt around the instruction-issue budget of gfx950
+// (~2.4 cycles for the add / logic / shift-right / fp32 class, ~4.2 for everything else):
+//
+//   * symbol search (probability/interface.rs:136-198): the compare runs on (cdf << 15) against max * slot, i.e. on the
+//     numerator the division needs anyway; the row's CDF is non-decreasing, so the lanes above the coded slot form a suffix of
+//     the row whose first lane is the symbol (v_ffbl), and the same predicate later selects the lanes blend increments;
+//   * (start, freq) of the symbol (probability/interface.rs:97-108): one division pass over the 16 entries, then TWO
+//     ds_bpermute reads (the scaled entry and its row_shr:1 copy) instead of packing, permuting and unpacking -- the LDS pipe
+//     does not cost VALU issue cycles;
+//   * blend (probability/frequentist_cdf.rs:74-85): the renormalisation half sits behind a wave-level branch (with the
+//     reference's speeds a row renormalises once in hundreds of updates);
+//   * row caches: direct mapped, tag and data are read in parallel (one LDS round trip, a third of the instructions of the
+//     2-way lookup), one cache per table so that the rows of one nibble never compete for a slot;
+//   * coded words: a 32-word ring per stream in LDS, topped up 16 words at a time (ans.rs:428-442 reads them in this order).
+//
+// Arithmetic and results are those of lit_decode_kernel (the parity tests run both against the oracle).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lit_device.h"
+
+namespace divans_hip {
+
+namespace {
+
+// LDS is addressed with 32-bit byte addresses (address space 3): no generic-pointer arithmetic in the byte loop
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_read16(uint32_t a) { return *(const lds_u16*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_write16(uint32_t a, uint32_t v) { *(lds_u16*)(uintptr_t)a = (uint16_t)v; }
+__device__ __forceinline__ uint32_t lds_read32(uint32_t a) { return *(const lds_u32*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_write32(uint32_t a, uint32_t v) { *(lds_u32*)(uintptr_t)a = v; }
+
+constexpr uint32_t kRingWords = 32u;
+constexpr uint32_t kRingBytes = kRingWords * 4u;
+
+struct DmCache {
+    uint32_t data_off;   // LDS address of slot 0 of this stream's cache + 2 * lane-in-row
+    uint32_t tag_off;    // LDS address of its tags (u16 row ids, 0xffff = empty)
+    uint32_t mask;       // slots - 1, 0xffffffff = this table is accessed in HBM / L2 directly
+    uint32_t shift;      // set = (row ^ (row >> shift)) & mask
+};
+
+struct RowSlot { uint32_t row; uint32_t addr; };
+
+struct Table2 {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t lane_off;   // row-of-lanes slab offset + 2 * lane-in-row
+    __device__ __forceinline__ int gload(uint32_t row) const {
+        return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, 0);
+    }
+    __device__ __forceinline__ void gstore(uint32_t row, int v) const {
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, rsrc, lane_off + (row << 5), 0, 0);
+    }
+    // Every access of the coder is a read-modify-write of a whole row: a cached row is always dirty, a miss writes the
+    // slot's previous row back (its data is what the speculative read returned) and fetches the new one.
+    template <bool PRESENT>
+    __device__ __forceinline__ int load(const DmCache& d, uint32_t row, RowSlot& s) const {
+        s.row = row;
+        if (!PRESENT) return gload(row);
+        const uint32_t set = (row ^ (row >> d.shift)) & d.mask;
+        s.addr = d.data_off + (set << 5);
+        const uint32_t taddr = d.tag_off + (set << 1);
+        int v = (int)lds_read16(s.addr);
+        const uint32_t tag = lds_read16(taddr);
+        if (tag != row) {
+            if (tag != 0xffffu) gstore(tag, v);
+            v = gload(row);
+            lds_write16(taddr, row);
+        }
+        return v;
+    }
+    template <bool PRESENT>
+    __device__ __forceinline__ void store(const DmCache& d, const RowSlot& s, int v) const {
+        if (!PRESENT) gstore(s.row, v);
+        else lds_write16(s.addr, (uint32_t)v);
+    }
+    template <bool PRESENT>
+    __device__ __forceinline__ void reset(const DmCache& d, int li) const {
+        if (!PRESENT) return;
+        for (uint32_t s = (uint32_t)li; s <= d.mask; s += 16u) lds_write16(d.tag_off + (s << 1), 0xffffu);
+    }
+};
+
+struct Caches { DmCache hs, hc, ls, lc; };   // high stride rows, high context-map rows (FirstNibble), low stride rows, low context-map rows
+// which of them exist is a compile-time mask CM (an absent cache then costs no registers): bit 0 hs, 1 hc, 2 ls, 3 lc
+constexpr int CM_HS = 1, CM_HC = 2, CM_LS = 4, CM_LC = 8;
+
+__device__ __forceinline__ uint32_t dm_rows(uint32_t packed, int i) { return (packed >> (8 * i)) & 0xffu; }   // log2(rows) + 1, 0 = absent
+
+// per-stream LDS region: [ring][hs data][hc data][ls data][lc data][hs tags][hc tags][ls tags][lc tags]
+__device__ __forceinline__ Caches make_caches(const LitBatch& b, uint32_t stream_base, int li) {
+    Caches c;
+    DmCache* all[4] = {&c.hs, &c.hc, &c.ls, &c.lc};
+    uint32_t off = stream_base + kRingBytes;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lg = dm_rows(b.dm_log2, i);
+        const uint32_t rows = lg ? 1u << (lg - 1u) : 0u;
+        all[i]->data_off = off + 2u * (uint32_t)li;
+        all[i]->mask = rows ? rows - 1u : 0xffffffffu;
+        all[i]->shift = (b.dm_shift >> (8 * i)) & 0xffu;
+        off += rows * 32u;
+    }
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lg = dm_rows(b.dm_log2, i);
+        const uint32_t rows = lg ? 1u << (lg - 1u) : 0u;
+        all[i]->tag_off = off;
+        off += rows * 2u;
+    }
+    return c;
+}
+
+// The coded stream, 32 words at a time in LDS (one ring per stream): word p sits at ring[p & 31]; when the reader crosses a
+// multiple of 16 the half it has just left takes the 16 words after the other half (held in `wn` since the previous crossing).
+struct WordRing {
+    const uint32_t* in; uint32_t nwords, pos, wn, off;     // off = LDS address of the ring
+    __device__ __forceinline__ uint32_t fetch(uint32_t first, int li) const { return (first + li < nwords) ? in[first + li] : 0u; }
+    __device__ __forceinline__ void start(int li) {
+        pos = 0;
+        lds_write32(off + ((uint32_t)li << 2), fetch(0u, li));
+        lds_write32(off + ((16u + (uint32_t)li) << 2), fetch(16u, li));
+        wn = fetch(32u, li);
+    }
+    __device__ __forceinline__ uint32_t next(int li) {
+        const uint32_t v = lds_read32(off + ((pos & (kRingWords - 1u)) << 2));
+        pos += 1u;
+        if ((pos & 15u) == 0u) {
+            lds_write32(off + ((((pos + 16u) & (kRingWords - 1u)) + (uint32_t)li) << 2), wn);
+            wn = fetch(pos + 32u, li);
+        }
+        return v;
+    }
+};
+
+// The decoded bytes the context and row selection look back at (last_8_literals, codec/literal.rs:66-85).  Configurations
+// whose every mixing value is 0 or 4 (stride <= 1) read the previous byte only, the context tables the one before it as well:
+// the 8-byte window is then never assembled.
+template <bool NEED8>
+struct History {
+    uint64_t last8; uint32_t p1, p2;
+    __device__ __forceinline__ void set(uint64_t v) { last8 = v; p1 = (uint32_t)(v >> 56); p2 = (uint32_t)(v >> 48) & 0xffu; }
+    __device__ __forceinline__ void push(uint32_t byte) {
+        p2 = p1; p1 = byte;
+        if (NEED8) last8 = (last8 >> 8) | ((uint64_t)byte << 56);
+    }
+    __device__ __forceinline__ uint32_t stride_byte(uint32_t offset_bits) const { return NEED8 ? (uint32_t)(last8 >> (56u - offset_bits)) & 0xffu : p1; }
+};
+
+// codec/literal.rs:176-208, as select_rows of lit_device.h but on a History
+template <bool HIGH, int MM, bool NEED8>
+__device__ __forceinline__ RowSel select_rows2(const LitGeometry& g, const uint8_t* lds_mix, uint32_t ctx, const History<NEED8>& h, uint32_t hi_nib) {
+    uint32_t mm_opts;
+    if (MM >= 0) mm_opts = (uint32_t)MM;
+    else mm_opts = lds_mix[ctx | (HIGH ? ((h.p1 >> 4) << 8) : ((hi_nib << 8) | 4096u))];
+    const uint32_t fast_cm = (mm_opts != 3) ? 0xffu : 0u;
+    const uint32_t mm = (mm_opts != 0 && mm_opts != 3) ? 0xffu : 0u;
+    const uint32_t opt1 = (mm_opts == 1) ? 0xfu : 0u;
+    uint32_t stride_offset = 0;
+    if (mm_opts >= 4) { uint32_t x = mm_opts ^ 4u; stride_offset = (x < 7u ? x : 7u) << 3; }
+    const uint32_t sb = h.stride_byte(stride_offset);
+    uint32_t b, c, width;
+    if (HIGH) { b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx; }
+    else { b = ((mm & sb) | (~mm & ctx)) & 0xffu; c = (hi_nib & fast_cm) | ((ctx & opt1) << 4); width = g.low_width; }
+    const uint32_t t = (mm >> 7) ^ (opt1 >> 2);
+    const uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);
+    RowSel r;
+    r.stride_row = (HIGH ? 0u : g.low_base) + ((plane * width + c) << 8) + b;
+    r.cm_row = g.cm_base + (HIGH ? ctx : g.nctx + hi_nib + 16u * ctx);
+    r.is_default = mm_opts == 2;
+    return r;
+}
+
+struct Searched {
+    int sym;     // the decoded nibble
+    int mx;      // cdf[15] of the row that was searched
+    int c15;     // this lane's entry << 15
+    bool above;  // this lane's entry is above the coded slot  <=>  lane >= sym  (always true in lane 15)
+};
+
+// cdf_offset_to_sym_start_and_freq, the search: sym = number of entries i < 15 with (max * slot >> 15) >= cdf[i].
+// (max * slot >> 15) >= c  <=>  max * slot >= c << 15, and c[15] << 15 = max << 15 > max * slot.
+__device__ __forceinline__ Searched search2(int cv, uint32_t slot, int rbase) {
+    Searched r;
+    r.mx = row_bcast<15>(cv);
+    const uint32_t prod = __umul24(slot, (uint32_t)r.mx);
+    r.c15 = cv << 15;
+    r.above = (uint32_t)r.c15 > prod;
+    const unsigned long long m = __ballot(r.above);
+    r.sym = __builtin_ctz((uint32_t)(m >> rbase));
+    __builtin_assume(r.sym >= 0 && r.sym < 16);
+    return r;
+}
+
+// helper_advance_sym (ans.rs:238): x = freq * (state >> 15) + (state & mask) - start, with start = dprev + 1 and
+// freq = d - dprev - 1 taken from the two scaled CDF entries around the symbol.
+__device__ __forceinline__ void advance_state(uint64_t& S, uint32_t slot, uint32_t d, uint32_t dprev) {
+    const uint32_t freq = d - dprev - 1u;
+    const int32_t a = (int32_t)slot - (int32_t)dprev - 1;            // slot - start: non-negative for every stream an encoder produced
+    const uint32_t xlo = (uint32_t)(S >> 15), xhi = (uint32_t)(S >> 47);
+    const uint64_t t = (uint64_t)xlo * freq + (uint64_t)(int64_t)a;
+    const uint32_t thi = (uint32_t)(t >> 32) + __umul24(xhi, freq);     // v_mad_u32_u24: xhi < 2^16, freq < 2^16
+    S = ((uint64_t)thi << 32) | (uint32_t)t;
+}
+
+// frequentist_cdf.rs:74-85 with the search predicate as the increment mask and the row's previous total at hand
+__device__ __forceinline__ int blend2(int c, int li1, bool above, int inc, int lim, int old_max) {
+    int c2 = c + inc;
+    asm("" : "+v"(c2));                    // one add and one select (not a select of the increment followed by the add)
+    c = above ? c2 : c;
+    const bool renorm = old_max >= lim - inc;       // lim - inc is uniform: a scalar subtraction
+    if (__builtin_expect(__ballot(renorm) != 0ull, 0)) {
+        asm volatile("" ::: "memory");     // keep this a branch: with the reference's speeds it is taken once in hundreds of updates
+        const int t = c + li1;
+        c = renorm ? t - (t >> 2) : c;
+    }
+    return c;
+}
+
+// sym_to_start_and_freq for the searched symbol under the row `cv`, state update, blend and store: the non-mixing nibble
+template <bool PRESENT>
+__device__ __forceinline__ void finish2(const Table2& tb, const DmCache& dc, int li1, int rbase4, const RowSlot& slot_ref, int value,
+                                        bool is_default, int cv, const Searched& s, uint32_t slot, uint64_t& S, int inc, int lim) {
+    const float rl = biased_rcp15(s.mx);
+    const uint32_t q = (uint32_t)((float)cv * rl);
+    const int32_t r = s.c15 - __mul24((int)q, s.mx);
+    const uint32_t d = r >= s.mx ? q + 1u : q;
+    const int dp = row_prev_or_zero((int)d);
+    const int addr = rbase4 + (s.sym << 2);
+    const uint32_t dsym = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)d);
+    const uint32_t dpsym = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, dp);
+    advance_state(S, slot, dsym, dpsym);
+    int st = value;
+    if (!is_default) st = blend2(st, li1, s.above, inc, lim, s.mx);     // cv == value here, so mx is its total and `above` its predicate
+    tb.template store<PRESENT>(dc, slot_ref, st);
+}
+
+// The mixing nibble's three (start, freq) pairs -- the symbol under the mixed row p, under the context-map row and under the
+// stride row, each entry scaled by its own row total -- through ONE division pass: lanes 0/1 take p, lanes 4/5 the context-map
+// row, lanes 8/9 the stride row; even lanes entry sym, odd lanes entry sym-1 (lane 15 of the own row when sym == 0: its scaled
+// value is 2^15, which the 15-bit mask turns into the 0 the reference uses there).
+struct MixLanes { int addr_bias; bool is_p, is_cm, odd; };
+__device__ __forceinline__ uint32_t mixed_sf2(int p, int cm, int st, int pmax, int cmax, int smax, const MixLanes& ml, int rbase4, int sym,
+                                              uint32_t& dprev_out, uint32_t& wfreqs) {
+    const int a = rbase4 | (((sym << 2) + ml.addr_bias) & 60);
+    const int gp = __builtin_amdgcn_ds_bpermute(a, p);
+    const int gc = __builtin_amdgcn_ds_bpermute(a, cm);
+    const int gs = __builtin_amdgcn_ds_bpermute(a, st);
+    const int num = ml.is_p ? gp : (ml.is_cm ? gc : gs);
+    const int den = ml.is_p ? pmax : (ml.is_cm ? cmax : smax);
+    const uint32_t q = scaled_div(num, den, biased_rcp15(den));
+    const uint32_t qn = (uint32_t)row_next_or_zero((int)q) & 0x7fffu;      // odd neighbour: scaled entry sym-1
+    const int f = (int)q - (int)qn - 1;                                     // even lanes: freq of their row's entry
+    dprev_out = (uint32_t)row_bcast<1>((int)q) & 0x7fffu;
+    wfreqs = ((uint32_t)row_bcast<4>(f) & 0xffffu) | ((uint32_t)row_bcast<8>(f) << 16);
+    return (uint32_t)row_bcast<0>((int)q);
+}
+
+template <bool HIGH, int MM, bool NEED8, int CM>
+__device__ __forceinline__ uint32_t decode_nibble_mix2(const LitGeometry& g, const LdsView& lv, const Table2& tb, const Caches& cc, int li1,
+                                                       int rbase, int rbase4, const MixLanes& ml, uint32_t ctx, const History<NEED8>& hist, uint32_t hi_nib,
+                                                       uint64_t& S, int mix_rate, uint32_t& wfreqs, uint32_t& wpmix) {
+    const RowSel rs = select_rows2<HIGH, MM, NEED8>(g, lv.mix, ctx, hist, hi_nib);
+    const DmCache& dst = HIGH ? cc.hs : cc.ls;
+    const DmCache& dcm = HIGH ? cc.hc : cc.lc;
+    RowSlot sref, cref;
+    constexpr bool ST_C = (CM & (HIGH ? CM_HS : CM_LS)) != 0, CM_C = (CM & (HIGH ? CM_HC : CM_LC)) != 0;
+    int st = tb.template load<ST_C>(dst, rs.stride_row, sref);
+    int cm = tb.template load<CM_C>(dcm, rs.cm_row, cref);
+    const int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
+    const int cv = average_rows(cm, st, cmax, smax, mix_rate);
+    const uint32_t slot = (uint32_t)S & 0x7fffu;
+    const Searched s = search2(cv, slot, rbase);
+    uint32_t dprev;
+    const uint32_t d = mixed_sf2(cv, cm, st, s.mx, cmax, smax, ml, rbase4, s.sym, dprev, wfreqs);
+    wpmix = d - dprev - 1u;
+    advance_state(S, slot, d, dprev);
+    cm = blend2(cm, li1, s.above, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
+    tb.template store<CM_C>(dcm, cref, cm);
+    const bool is_default = (MM < 0 || MM == 2) && rs.is_default;
+    if (!is_default) st = blend2(st, li1, s.above, g.inc0, g.lim0, smax);
+    tb.template store<ST_C>(dst, sref, st);
+    return (uint32_t)s.sym;
+}
+
+struct Fetched2 { RowSlot ref; int value; bool is_default; };
+
+template <bool HIGH, int MM, bool NEED8, int CM>
+__device__ __forceinline__ Fetched2 fetch2(const LitGeometry& g, const LdsView& lv, const Table2& tb, const Caches& cc, uint32_t ctx,
+                                           const History<NEED8>& hist, uint32_t hi_nib) {
+    const RowSel rs = select_rows2<HIGH, MM, NEED8>(g, lv.mix, ctx, hist, hi_nib);
+    Fetched2 f;
+    f.value = tb.template load<(CM & (HIGH ? CM_HS : CM_LS)) != 0>(HIGH ? cc.hs : cc.ls, rs.stride_row, f.ref);
+    f.is_default = (MM < 0 || MM == 2) && rs.is_default;
+    return f;
+}
+
+template <int CM>
+__device__ __forceinline__ void init_table2(const Table2& t, const Caches& cc, uint32_t rows, int li) {
+    // row = 16 x i16 = two 16-byte halves; even lanes write the first half, odd lanes the second (ffi/alloc_util.rs:77-79:
+    // allocations are default-initialised = every row the default CDF)
+    const u32x4 lo = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
+    const u32x4 hi = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
+    const u32x4 v = (li & 1) ? hi : lo;
+    const uint32_t base = t.lane_off - 2u * (uint32_t)li + 16u * (uint32_t)li;
+    for (uint32_t i = 0; i < rows * 32u; i += 256u) {
+        if (i + 16u * (uint32_t)li < rows * 32u) __builtin_amdgcn_raw_buffer_store_b128(v, t.rsrc, base + i, 0, 0);
+    }
+    t.template reset<(CM & CM_HS) != 0>(cc.hs, li); t.template reset<(CM & CM_HC) != 0>(cc.hc, li);
+    t.template reset<(CM & CM_LS) != 0>(cc.ls, li); t.template reset<(CM & CM_LC) != 0>(cc.lc, li);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // the row loads that follow must see the fill
+}
+
+}  // namespace
+
+template <int MM, bool CTXC, bool MIX, bool SEG, int CM>
+__global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel(const LitBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
+    const LitGeometry& g = b.geom;
+    const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48, rbase4 = rbase << 2, li1 = li + 1;
+    const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
+    const uint32_t G = gridDim.x * (LIT_THREADS / 16);
+    Table2 tb;
+    {
+        const uint32_t slab = g.total_rows * 32u;           // bytes of one stream's table
+        tb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab),
+                                                    0, (LIT_THREADS / 16) * slab, 0x00020000);
+        tb.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t stream_base = lds_base + (threadIdx.x >> 4) * (b.cache_bytes_per_wg / (LIT_THREADS / 16));
+    const Caches cc = make_caches(b, stream_base, li);
+    MixLanes ml;
+    ml.odd = (li & 1) != 0; ml.is_p = li < 4; ml.is_cm = (li & 12) == 4; ml.addr_bias = ml.odd ? -4 : 0;
+    for (uint32_t s = gg; s < b.n_streams; s += G) {
+        const uint32_t len = b.out_sizes ? b.out_sizes[s] : b.stream_len;
+        uint8_t* out = b.out + (b.out_offsets ? b.out_offsets[s] : (uint64_t)s * b.stream_len);
+        WordRing ww;
+        ww.in = (const uint32_t*)(b.in + b.in_offsets[s]);
+        ww.nwords = b.in_sizes[s] >> 2;
+        ww.off = stream_base;
+        ww.start(li);
+        init_table2<CM>(tb, cc, g.total_rows, li);
+        WeightsPair wp; wp.init();
+        int nh = 1 << 14, nl = 1 << 14;     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
+        constexpr bool NEED8 = SEG || !(MM == 0 || MM == 4);
+        History<NEED8> hist;
+        uint64_t seg_last8 = 0;
+        uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
+        SegCursor sc;
+        if (SEG) sc.start(b, s, seg_last8, ctab);
+        hist.set(seg_last8);
+        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];   // lut1 class of the byte before the previous one
+        uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
+        bool corrupt = false;
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, hist.p1, k1);
+        Fetched2 rowH = {};
+        if (!MIX) rowH = fetch2<true, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, 0u);
+        for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
+            // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
+            {
+                const uint32_t a0 = ww.next(li), a1 = ww.next(li), b0 = ww.next(li), b1 = ww.next(li);
+                SA = ((uint64_t)a1 << 32) | a0;
+                SB = ((uint64_t)b1 << 32) | b0;
+            }
+            const uint32_t cend = cbeg + 32768u < len ? cbeg + 32768u : len;
+            for (uint32_t base = cbeg; base < cend; base += 16u) {
+                const uint32_t cnt = cend - base < 16u ? cend - base : 16u;
+                uint32_t outb = 0;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    if (MIX) {
+                        const uint32_t ctx = ctx_cur;
+                        // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
+                        if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li);
+                        uint32_t fh = 0, fl = 0, ph = 0, pl = 0;
+                        const uint32_t hi = decode_nibble_mix2<true, MM, NEED8, CM>(g, lv, tb, cc, li1, rbase, rbase4, ml, ctx, hist, 0u, SA, nh, fh, ph);
+                        if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li);
+                        const uint32_t lo = decode_nibble_mix2<false, MM, NEED8, CM>(g, lv, tb, cc, li1, rbase, rbase4, ml, ctx, hist, hi, SB, nl, fl, pl);
+                        wp.update(li, fh, ph, fl, pl);
+                        nh = wp.norm_high(); nl = wp.norm_low();
+                        const uint32_t byte = (hi << 4) | lo;
+                        hist.push(byte);
+                        if (SEG) {   // the next Literal command starts from the ring buffer's last 8 bytes and its own block type
+                            if (--sc.left == 0u) { seg_last8 = hist.last8; sc.advance(g, seg_last8, ctab); hist.set(seg_last8); }
+                        }
+                        if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];
+                        ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, hist.p1, k1);
+                        outb = (uint32_t)li == k ? byte : outb;
+                    } else {
+                        // rowH (this byte's high-nibble row) was requested while the previous byte was being finished
+                        if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li);
+                        const int cvh = rowH.is_default ? 4 * li1 : rowH.value;
+                        const uint32_t slot_a = (uint32_t)SA & 0x7fffu;
+                        const Searched sh = search2(cvh, slot_a, rbase);
+                        const uint32_t hi = (uint32_t)sh.sym;
+                        const Fetched2 rowL = fetch2<false, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, hi);
+                        finish2<(CM & CM_HS) != 0>(tb, cc.hs, li1, rbase4, rowH.ref, rowH.value, rowH.is_default, cvh, sh, slot_a, SA, g.inc0, g.lim0);
+                        if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li);
+                        const int cvl = rowL.is_default ? 4 * li1 : rowL.value;
+                        const uint32_t slot_b = (uint32_t)SB & 0x7fffu;
+                        const Searched sl = search2(cvl, slot_b, rbase);
+                        const uint32_t lo = (uint32_t)sl.sym;
+                        const uint32_t byte = (hi << 4) | lo;
+                        hist.push(byte);
+                        if (SEG) { if (--sc.left == 0u) { seg_last8 = hist.last8; sc.advance(g, seg_last8, ctab); hist.set(seg_last8); } }
+                        if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];
+                        ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, hist.p1, k1);
+                        rowH = fetch2<true, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, 0u);   // next byte's row (harmless past the end)
+                        finish2<(CM & CM_LS) != 0>(tb, cc.ls, li1, rbase4, rowL.ref, rowL.value, rowL.is_default, cvl, sl, slot_b, SB, g.inc0, g.lim0);
+                        outb = (uint32_t)li == k ? byte : outb;
+                    }
+                }
+                if ((uint32_t)li < cnt) __builtin_nontemporal_store((uint8_t)outb, out + base + li);
+            }
+            // rANS is an exact inverse: a chunk that was coded from the start states 2^31 (ans.rs:135-136,331-378) decodes back
+            // to exactly those; anything else means a truncated, corrupt or mismatched stream
+            corrupt |= (SA != (1ull << 31)) | (SB != (1ull << 31));
+        }
+        corrupt |= ww.pos != ww.nwords;     // every coded word consumed, none read past the end
+        if (corrupt && li == 0 && b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
+    }
+}
+
+typedef void (*LitKernel)(const LitBatch);
+
+template <bool MIX, bool SEG, int CM>
+static LitKernel pick_decode2_cm(int mm, bool ctxc) {
+    const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 2 + (ctxc ? 1 : 0);
+    switch (key) {
+    case 0: return lit_decode2_kernel<-1, false, MIX, SEG, CM>; case 1: return lit_decode2_kernel<-1, true, MIX, SEG, CM>;
+    case 2: return lit_decode2_kernel<0, false, MIX, SEG, CM>;  case 3: return lit_decode2_kernel<0, true, MIX, SEG, CM>;
+    case 4: return lit_decode2_kernel<4, false, MIX, SEG, CM>;  default: return lit_decode2_kernel<4, true, MIX, SEG, CM>;
+    }
+}
+
+// The cache sets that exist as kernels: none; the high rows (stride, and context-map with mixing); the high rows plus the
+// low stride rows (no mixing) / the low context-map rows (mixing).  Streams with segment lists: none or the high rows.
+static uint32_t supported_cache_mask(bool mix, bool seg, uint32_t want) {
+    const uint32_t high = mix ? (uint32_t)(CM_HS | CM_HC) : (uint32_t)CM_HS;
+    const uint32_t full = high | (mix ? (uint32_t)CM_LC : (uint32_t)CM_LS);
+    if (!seg && (want & full) == full) return full;
+    if ((want & high) == high) return high;
+    return 0u;
+}
+
+static LitKernel pick_decode2(bool mix, bool seg, uint32_t cm, int mm, bool ctxc) {
+    if (mix) {
+        if (seg) return cm ? pick_decode2_cm<true, true, CM_HS | CM_HC>(mm, ctxc) : pick_decode2_cm<true, true, 0>(mm, ctxc);
+        if (cm == (uint32_t)(CM_HS | CM_HC | CM_LC)) return pick_decode2_cm<true, false, CM_HS | CM_HC | CM_LC>(mm, ctxc);
+        return cm ? pick_decode2_cm<true, false, CM_HS | CM_HC>(mm, ctxc) : pick_decode2_cm<true, false, 0>(mm, ctxc);
+    }
+    if (seg) return cm ? pick_decode2_cm<false, true, CM_HS>(mm, ctxc) : pick_decode2_cm<false, true, 0>(mm, ctxc);
+    if (cm == (uint32_t)(CM_HS | CM_LS)) return pick_decode2_cm<false, false, CM_HS | CM_LS>(mm, ctxc);
+    return cm ? pick_decode2_cm<false, false, CM_HS>(mm, ctxc) : pick_decode2_cm<false, false, 0>(mm, ctxc);
+}
+
+static uint32_t wanted_cache_mask(uint32_t dm_log2) {
+    uint32_t m = 0;
+    for (int i = 0; i < 4; ++i) if ((dm_log2 >> (8 * i)) & 0xffu) m |= 1u << i;
+    return m;
+}
+
+// dm_log2 with the caches no kernel instance implements dropped (the host sizes the LDS and the grid from this)
+uint32_t lit_decode2_effective_caches(uint32_t dm_log2, bool mix, bool seg) {
+    const uint32_t cm = supported_cache_mask(mix, seg, wanted_cache_mask(dm_log2));
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) if (cm & (1u << i)) out |= dm_log2 & (0xffu << (8 * i));
+    return out;
+}
+
+uint32_t lit_lds_bytes2(const LitBatch& b) {
+    uint32_t bytes = b.cache_bytes_per_wg;
+    if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTXF + LIT_CTXF_BYTES * b.geom.n_btypes;
+    if (!(b.geom.mm_uniform == 0 || b.geom.mm_uniform == 4)) bytes += 8192u;
+    return bytes;
+}
+
+uint32_t lit_decode2_stream_lds(uint32_t dm_log2) {
+    uint32_t rows = 0;
+    for (int i = 0; i < 4; ++i) { const uint32_t lg = (dm_log2 >> (8 * i)) & 0xffu; rows += lg ? 1u << (lg - 1u) : 0u; }
+    return kRingBytes + rows * 34u;
+}
+
+hipError_t launch_decode2(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
+    const int mm = (b.geom.mm_uniform == 0 || b.geom.mm_uniform == 4) ? b.geom.mm_uniform : -1;
+    const uint32_t cm = wanted_cache_mask(b.dm_log2);
+    if (cm != supported_cache_mask(mix, b.segs != nullptr, cm)) return hipErrorInvalidValue;   // the host passes lit_decode2_effective_caches()
+    LitKernel k = pick_decode2(mix, b.segs != nullptr, cm, mm, b.geom.ctx_const >= 0);
+    const uint32_t lds = lit_lds_bytes2(b);
+    if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);
+    return hipGetLastError();
+}
+
+}  // namespace divans_hip

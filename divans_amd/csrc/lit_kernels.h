@@ -56,6 +56,10 @@ struct LitBatch {
     const uint32_t* seg_begin;  // [n_streams + 1] first segment of every stream in `segs`, or null: each stream is one segment
     const LitSegment* segs;     //   with zero context and the block type the tables were built for
     uint32_t* status;           // device word: bit 0 = encoder saw an invalid (start,freq), bit 1 = decoder integrity check failed
+    // lit_decode2.hip: four direct-mapped row caches per stream (high stride rows, high context-map rows, low stride rows, low
+    // context-map rows), one byte each: log2(rows) + 1, 0 = that table is not cached; and the hash shift of each
+    // (set = (row ^ (row >> shift)) & (rows - 1)).  cache_bytes_per_wg then covers the word rings too.
+    uint32_t dm_log2, dm_shift;
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
 constexpr uint32_t LIT_STATUS_BAD_STREAM = 2u;    // decode: a chunk did not end with both states at 2^31, or the coded words were not consumed exactly
@@ -116,6 +120,9 @@ uint32_t lit_lds_bytes(const LitBatch& b);
 hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st);
 hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
+hipError_t launch_decode2(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
+uint32_t lit_decode2_effective_caches(uint32_t dm_log2, bool mix, bool seg);   // the caches of dm_log2 a kernel instance exists for
+uint32_t lit_decode2_stream_lds(uint32_t dm_log2);   // LDS bytes one stream takes in lit_decode2_kernel (word ring + row caches)
 hipError_t launch_model_encode_p8(const LitBatch& b, uint32_t blocks, hipStream_t st);
 hipError_t launch_decode_p8(const LitBatch& b, uint32_t blocks, hipStream_t st);
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,

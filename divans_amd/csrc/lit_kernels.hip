@@ -151,23 +151,6 @@ __device__ __forceinline__ Table<CACHE> make_table(const LitBatch& b, uint8_t* l
 // ---------------------------------------------------------------------------------------------
 // Encode, pass 1: adaptive model.  bytes -> (start | freq << 16) per nibble.
 // ---------------------------------------------------------------------------------------------
-// The Weights update (weights.rs:23-38) is per-stream scalar work.  Both nibbles of a byte own a Weights object
-// (model_weights[1] high, [0] low, literal.rs:230) that is only read again one byte later, so the mixing paths hand the three
-// probabilities of each nibble back (`wfreqs` = cm freq | stride freq << 16, the mixed freq is in the returned pair) and the byte
-// loop runs ONE update for both: lanes 0..7 of the row carry the high nibble's Weights, lanes 8..15 the low nibble's.
-struct WeightsPair {
-    Weights w;   // lane-varying: high nibble's object in lanes 0..7, low nibble's in lanes 8..15
-    __device__ __forceinline__ void init() { w.w0 = 1; w.w1 = 1; w.norm = 1 << 14; }
-    __device__ __forceinline__ int norm_high() const { return row_bcast<0>(w.norm); }
-    __device__ __forceinline__ int norm_low() const { return row_bcast<8>(w.norm); }
-    __device__ __forceinline__ void update(int li, uint32_t freqs_h, uint32_t pmix_h, uint32_t freqs_l, uint32_t pmix_l) {
-        const bool hi = li < 8;
-        const uint32_t fr = hi ? freqs_h : freqs_l;
-        const uint32_t pm = hi ? pmix_h : pmix_l;
-        weights_update(w, (int)(short)(fr & 0xffffu), (int)(short)(fr >> 16), (int)(short)pm);
-    }
-};
-
 // Mixing paths: (start | freq << 16) of `sym` under the mixed row p, plus the frequencies of `sym` under the context-map row
 // and the stride row alone (wfreqs = cm freq | stride freq << 16, the Weights update's model_probs, literal.rs:236-239).
 // That is six quotients -- entries sym and sym-1 of three rows, each by its own row total (probability/interface.rs:97-108)

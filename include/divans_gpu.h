@@ -193,6 +193,14 @@ int divans_gpu_codec_set_encode_path(divans_gpu_codec *c, uint32_t path);
  * per 64 KiB stream -- fit the device).  A tuning / test knob: the coded bytes do not depend on it. */
 int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
 
+/* Tuning: which decode kernel runs -- generation 2 (default: direct-mapped LDS row caches, coded words through an LDS ring;
+ * lit_decode2.hip) or 1 (2-way caches, lit_kernels.hip) -- and for generation 2 the rows of its four per-stream caches
+ * {high stride rows, high context-map rows, low stride rows, low context-map rows} (0 = not cached, else a power of two in
+ * [4, 256]), their hash shifts (set = (row ^ (row >> shift)) & (rows - 1)) and the persistent grid (0 = keep; clamped to
+ * what the LDS holds).  rows / shifts may be NULL to keep the current ones.  Both generations produce the same bytes. */
+int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4],
+                                 uint32_t blocks);
+
 /* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */
 int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, uint32_t low_rows);
 

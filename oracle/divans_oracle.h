@@ -155,6 +155,11 @@ int orc_lit_segments_decode(const orc_lit_config *cfg, const uint8_t *in, size_t
 int orc_lit_batch_bench(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len,
                         int nthreads, double *enc_wall, double *dec_wall, uint64_t *coded_bytes);
 
+/* checker: encode n_streams streams on nthreads workers and compare each with coded[off[i] .. off[i] + size[i]);
+ * returns how many differ (-1: allocation failure), *first_bad = index of the first that does (n_streams if none) */
+long orc_lit_batch_check(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len, int nthreads,
+                         const uint8_t *coded, const uint64_t *off, const uint32_t *size, size_t *first_bad);
+
 /* ---- complete literal-only .divans streams (stream.c) ---- */
 typedef struct {
     int window_size;                 /* header byte 5, clamped to [10,24] (divans_compressor.rs:89) */

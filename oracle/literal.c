@@ -501,6 +501,59 @@ int orc_lit_batch_bench(const orc_lit_config *cfg, const uint8_t *in, size_t n_s
 }
 
 
+/* ---- bench / test checker: encode many independent streams on nthreads workers and compare each with the coded bytes
+ * another implementation produced (coded[off[i] .. off[i] + size[i])).  Returns the number of streams that differ, -1 on
+ * allocation failure.  first_bad receives the index of the first differing stream (or n_streams). */
+typedef struct {
+    const orc_lit_config *cfg; const uint8_t *in; size_t n_streams, stream_len; int tid, nthreads;
+    const uint8_t *coded; const uint64_t *off; const uint32_t *size;
+    size_t bad, first_bad;
+} check_arg;
+
+static void *check_worker(void *p) {
+    check_arg *a = (check_arg *)p;
+    orc_lit_state *s = orc_lit_state_new(a->cfg);
+    orc_ans_encoder enc;
+    orc_ans_encoder_init(&enc);
+    a->first_bad = a->n_streams;
+    for (size_t i = (size_t)a->tid; i < a->n_streams; i += (size_t)a->nthreads) {
+        lit_state_reset(s, a->cfg);
+        orc_ans_encoder_reset(&enc);
+        orc_lit_encode_bytes(s, &enc, a->in + i * a->stream_len, a->stream_len);
+        orc_ans_flush_chunk(&enc);
+        if (enc.failed || enc.out.len != a->size[i] || memcmp(enc.out.data, a->coded + a->off[i], enc.out.len) != 0) {
+            a->bad += 1;
+            if (i < a->first_bad) a->first_bad = i;
+        }
+    }
+    orc_ans_encoder_free(&enc);
+    orc_lit_state_free(s);
+    return NULL;
+}
+
+long orc_lit_batch_check(const orc_lit_config *cfg, const uint8_t *in, size_t n_streams, size_t stream_len, int nthreads,
+                         const uint8_t *coded, const uint64_t *off, const uint32_t *size, size_t *first_bad) {
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    check_arg *args = (check_arg *)calloc((size_t)nthreads, sizeof(check_arg));
+    if (!th || !args) return -1;
+    for (int t = 0; t < nthreads; ++t) {
+        args[t].cfg = cfg; args[t].in = in; args[t].n_streams = n_streams; args[t].stream_len = stream_len;
+        args[t].tid = t; args[t].nthreads = nthreads; args[t].coded = coded; args[t].off = off; args[t].size = size;
+        pthread_create(&th[t], NULL, check_worker, &args[t]);
+    }
+    long bad = 0; size_t fb = n_streams;
+    for (int t = 0; t < nthreads; ++t) {
+        pthread_join(th[t], NULL);
+        bad += (long)args[t].bad;
+        if (args[t].first_bad < fb) fb = args[t].first_bad;
+    }
+    if (first_bad) *first_bad = fb;
+    free(th); free(args);
+    return bad;
+}
+
+
 /* ---- general streams: the literals of a stream with Copy / Dict commands in between (codec/mod.rs:711-792).
  * One segment per Literal command: the block type in force (obs_literal_block_switch, codec/interface.rs:289-292) and
  * last_8_literals as reloaded from the ring buffer after the previous command (codec/mod.rs:771-783).  Priors, Weights

@@ -104,6 +104,9 @@ def lib(native=False):
     L.orc_lit_config_from_prediction_mode.argtypes = [ctypes.POINTER(StreamOptions), ctypes.c_void_p, ctypes.c_uint8, ctypes.POINTER(LitConfig)]
     L.orc_lit_batch_bench.restype = ctypes.c_int
     L.orc_lit_batch_bench.argtypes = L.orc_lit_batch_roundtrip.argtypes
+    L.orc_lit_batch_check.restype = ctypes.c_long
+    L.orc_lit_batch_check.argtypes = [ctypes.POINTER(LitConfig), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
     L.orc_cdf_default.argtypes = [ctypes.POINTER(Cdf16)]
     L.orc_cdf_blend.argtypes = [ctypes.POINTER(Cdf16), ctypes.c_uint8, Speed]
     L.orc_cdf_average.argtypes = [ctypes.POINTER(Cdf16), ctypes.POINTER(Cdf16), ctypes.c_int32, ctypes.POINTER(Cdf16)]
@@ -171,6 +174,20 @@ def lit_encode(cfg, data, trace=False):
         raise RuntimeError("oracle encode failed")
     coded = out[:r].copy()
     return (coded, tr) if trace else coded
+
+
+def lit_batch_check(cfg, blocks, coded, offsets, sizes, threads=1):
+    """Encode every row of `blocks` (n x L uint8) on `threads` workers and compare with coded[offsets[i] : offsets[i] + sizes[i]].
+    Returns (number of differing streams, index of the first one or n)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    coded = np.ascontiguousarray(coded, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    n, L = blocks.shape
+    first = ctypes.c_size_t(n)
+    bad = lib().orc_lit_batch_check(ctypes.byref(cfg), blocks.ctypes.data, n, L, int(threads), coded.ctypes.data, offsets.ctypes.data,
+                                    sizes.ctypes.data, ctypes.byref(first))
+    return int(bad), int(first.value)
 
 
 def lit_decode(cfg, coded, n):

@@ -74,6 +74,8 @@ constexpr int UNROLL = 16;
 #define T_BPERM(i) "ds_bpermute_b32 %" #i ", %8, %" #i "\n"
 #define T_SWIZ(i) "ds_swizzle_b32 %" #i ", %" #i " offset:0x8000\n"
 #define T_PERMLANE(i) "v_permlane32_swap %" #i ", %" #i "\n"
+#define T_FFBL(i) "v_ffbl_b32 %" #i ", %" #i "\n"
+#define T_FFBH(i) "v_ffbh_u32 %" #i ", %" #i "\n"
 
 DEF_KERNEL(k_add, T_ADD)
 DEF_KERNEL(k_add3, T_ADD3)
@@ -110,6 +112,8 @@ DEF_KERNEL(k_readfirst, T_READFIRST)
 DEF_KERNEL(k_salu, T_SNOP)
 DEF_KERNEL(k_bperm, T_BPERM)
 DEF_KERNEL(k_swizzle, T_SWIZ)
+DEF_KERNEL(k_ffbl, T_FFBL)
+DEF_KERNEL(k_ffbh, T_FFBH)
 
 
 #define T_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
@@ -168,6 +172,10 @@ __global__ __launch_bounds__(256) void k_pairs(uint32_t* out, uint64_t* ticks, u
 #define T_CVTF64(i) "v_cvt_f64_u32 %" #i ", %8\n"
 #define T_RCPF64(i) "v_rcp_f64 %" #i ", %" #i "\n"
 #define T_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %" #i ", %" #i "\n"
+#define T_CMPU64(i) "v_cmp_gt_u64 vcc, %" #i ", %" #i "\n"
+#define T_MOV64(i) "v_mov_b64 %" #i ", %" #i "\n"
+#define T_LSHLADD64(i) "v_lshl_add_u64 %" #i ", %" #i ", 0, %" #i "\n"
+#define T_LSHR64V(i) "v_lshrrev_b64 %" #i ", %8, %" #i "\n"
     if (which == 0) for (int i = 0; i < ITERS; ++i) { P8(T_LSHL64) P8(T_LSHL64) }
     else if (which == 1) for (int i = 0; i < ITERS; ++i) { P8(T_LSHR64) P8(T_LSHR64) }
     else if (which == 2) for (int i = 0; i < ITERS; ++i) { P8(T_MAD64) P8(T_MAD64) }
@@ -175,7 +183,11 @@ __global__ __launch_bounds__(256) void k_pairs(uint32_t* out, uint64_t* ticks, u
     else if (which == 4) for (int i = 0; i < ITERS; ++i) { P8(T_FMAF64) P8(T_FMAF64) }
     else if (which == 5) for (int i = 0; i < ITERS; ++i) { P8(T_CVTF64) P8(T_CVTF64) }
     else if (which == 6) for (int i = 0; i < ITERS; ++i) { P8(T_RCPF64) P8(T_RCPF64) }
-    else for (int i = 0; i < ITERS; ++i) { P8(T_PKFMA) P8(T_PKFMA) }
+    else if (which == 7) for (int i = 0; i < ITERS; ++i) { P8(T_PKFMA) P8(T_PKFMA) }
+    else if (which == 8) for (int i = 0; i < ITERS; ++i) { P8(T_CMPU64) P8(T_CMPU64) }
+    else if (which == 9) for (int i = 0; i < ITERS; ++i) { P8(T_MOV64) P8(T_MOV64) }
+    else if (which == 10) for (int i = 0; i < ITERS; ++i) { P8(T_LSHLADD64) P8(T_LSHLADD64) }
+    else for (int i = 0; i < ITERS; ++i) { P8(T_LSHR64V) P8(T_LSHR64V) }
     uint64_t t1 = __builtin_readcyclecounter();
     if ((r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7) == 0xdeadbeefull) out[0] = (uint32_t)r0;
     if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
@@ -272,8 +284,10 @@ int main() {
         {"v_cndmask_b32", k_cndmask}, {"v_cmp vcc", k_cmp}, {"v_cmp sgpr", k_cmps}, {"v_bcnt", k_bcnt}, {"v_pk_add_u16", k_pkadd},
         {"v_pk_sub_i16", k_pksub}, {"v_pk_lshrrev_b16", k_pklshr}, {"v_pk_mul_lo_u16", k_pkmullo}, {"v_pk_max_u16", k_pkmax}, {"v_perm_b32", k_perm},
         {"v_bfe_u32", k_bfe}, {"v_and_or_b32", k_andor}, {"v_alignbit_b32", k_alignbit}, {"v_lshrrev_b32", k_lshr}, {"v_sad_u16", k_sad},
-        {"v_readlane_b32", k_readlane}, {"v_readfirstlane", k_readfirst}, {"s_add_u32", k_salu}, {"ds_bpermute_b32", k_bperm}, {"ds_swizzle_b32", k_swizzle},
+        {"ds_bpermute_b32", k_bperm}, {"ds_swizzle_b32", k_swizzle},
+        {"v_ffbl_b32", k_ffbl}, {"v_ffbh_u32", k_ffbh},
     };
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     for (auto& v : vs) {
         for (int wps : {1, 4, 8}) {
             v.k<<<ncu * wps, 256>>>(out, ticks, 1u);
@@ -284,8 +298,8 @@ int main() {
             report(v.name, wps, ms, UNROLL);
         }
     }
-    const char* pn[] = {"v_lshlrev_b64", "v_lshrrev_b64", "v_mad_u64_u32", "v_mul_f64", "v_fma_f64", "v_cvt_f64_u32", "v_rcp_f64", "v_pk_fma_f32"};
-    for (int w = 0; w < 8; ++w)
+    const char* pn[] = {"v_lshlrev_b64", "v_lshrrev_b64", "v_mad_u64_u32", "v_mul_f64", "v_fma_f64", "v_cvt_f64_u32", "v_rcp_f64", "v_pk_fma_f32", "v_cmp_gt_u64", "v_mov_b64", "v_lshl_add_u64", "v_lshrrev_b64 vgpr shift"};
+    for (int w = 0; w < 12; ++w)
         for (int wps : {1, 2, 4, 8}) {
             k_pairs<<<ncu * wps, 256>>>(out, ticks, 1u, w);
             CK(hipEventRecord(e0));

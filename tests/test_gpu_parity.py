@@ -492,3 +492,63 @@ def test_pipelined_host_wrappers_match_the_serial_ones(cfg_name, slice_streams, 
     for b in (pin_in, pin_out, pin_back):
         b.close()
     codec.close()
+
+
+# ---- second-generation decoder (lit_decode2.hip): direct-mapped caches of every size, with and without low-row caches ----
+_DM_GEOMETRIES = [
+    ((32, 0, 0, 0), (31, 5, 5, 5)),      # the non-mixing default: high stride rows, indexed by the previous byte
+    ((16, 16, 0, 0), (5, 5, 5, 5)),      # the mixing default
+    ((0, 0, 0, 0), (5, 5, 5, 5)),        # every row in HBM / L2
+    ((4, 4, 4, 4), (0, 1, 2, 3)),        # tiny caches: evictions on almost every access, four different hashes
+    ((64, 8, 32, 64), (8, 31, 4, 5)),
+    ((256, 0, 256, 0), (5, 5, 7, 5)),
+    ((0, 32, 0, 16), (5, 5, 5, 5)),
+]
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+@pytest.mark.parametrize("geom", range(len(_DM_GEOMETRIES)))
+def test_decoder2_cache_geometries(cfg_name, geom, corpus, shuffle384, random_then_unicode):
+    rows, shifts = _DM_GEOMETRIES[geom]
+    L = 20000
+    blocks = np.stack([corpus[5000:5000 + L], corpus[90000:90000 + L], np.resize(shuffle384, L), random_then_unicode[99000:99000 + L],
+                       random_then_unicode[250000:250000 + L], np.resize(np.frombuffer(b"abracadabra ", dtype=np.uint8), L)])
+    import torch
+    lens = [L, 17, L - 3, 4097, L, 9000]
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    flat = np.concatenate([blocks[i, :lens[i]] for i in range(6)])
+    dev = torch.device("cuda", 0)
+    da, codec = _codec(cfg_name, L)
+    codec.set_decoder(2, rows, shifts, blocks=2)          # two workgroups: the 6 streams share waves with idle rows of lanes
+    d_in = torch.from_numpy(np.concatenate([flat, np.zeros(64, np.uint8)])).to(dev)
+    outs = codec.alloc_encode_outputs(6)
+    d_off = torch.tensor(starts, dtype=torch.int64, device=dev); d_sz = torch.tensor(lens, dtype=torch.int32, device=dev)
+    codec.encode_batch(d_in, 6, L, outs, in_offsets=d_off, in_sizes=d_sz)
+    d_back = torch.zeros(sum(lens) + 64, dtype=torch.uint8, device=dev)
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], 6, L, d_back, out_offsets=d_off, out_sizes=d_sz)
+    torch.cuda.synchronize()
+    assert (d_back.cpu().numpy()[:sum(lens)] == flat).all(), (cfg_name, rows)
+    assert codec.status() == 0
+    offs = outs["offsets"].cpu().numpy(); szs = outs["sizes"].cpu().numpy(); blob = outs["out"].cpu().numpy()
+    ocfg = _oracle_cfg(cfg_name)
+    for i, (s0, ln) in enumerate(zip(starts, lens)):
+        ref = po.lit_encode(ocfg, flat[s0:s0 + ln])
+        assert szs[i] == ref.size and (blob[offs[i]:offs[i] + szs[i]] == ref).all(), i
+    codec.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_both_decoder_generations_agree(cfg_name, corpus):
+    blocks = workload.make_blocks(corpus, 40, 300, block_len=3000)
+    da, codec = _codec(cfg_name, 3000)
+    packed, offs, sizes = codec.encode_host(blocks, 3000)
+    for gen in (1, 2):
+        codec.set_decoder(gen)
+        assert (codec.decode_host(packed, offs, sizes, 3000) == blocks).all(), gen
+    # a damaged stream fails the integrity check of either generation
+    bad = packed.copy(); bad[int(offs[7]) + 40] ^= 0x10
+    for gen in (1, 2):
+        codec.set_decoder(gen)
+        codec.decode_host(bad, offs, sizes, 3000)
+        assert codec.status() & 2, gen
+    codec.close()
