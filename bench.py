@@ -355,6 +355,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=65536, help="independent 64 KiB streams per GPU")
+    ap.add_argument("--total-streams", type=int, default=0, help="strong scaling (BASELINE configs[4]): this many streams in total, split over the GPUs "
+                    "(131072 = 8 GiB); 0 = weak scaling with --streams per GPU")
     ap.add_argument("--block-len", type=int, default=65536)
     ap.add_argument("--config", choices=["all", "simple", "mixing", "decode_only"], default="all",
                     help="all = configs[1] as the headline + configs[2] and configs[3] as sub-records (N = 1); a single name runs only that one")
@@ -403,12 +405,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    N, L = args.streams, args.block_len
-    total_streams = N * world      # weak scaling: every rank owns N streams of the job's N * world
-    first, last = sharding.shard_bounds(total_streams, rank, world)
-    assert last - first == N
+    L = args.block_len
+    strong = args.total_streams > 0
+    if strong:
+        total_streams = args.total_streams          # BASELINE configs[4]: one fixed job split over the GPUs
+        first, last = sharding.shard_bounds(total_streams, rank, world)
+        N = last - first
+        if N == 0:
+            sys.exit(f"bench: --total-streams {total_streams} leaves rank {rank} of {world} without work")
+    else:
+        N = args.streams
+        total_streams = N * world      # weak scaling: every rank owns N streams of the job's N * world
+        first, last = sharding.shard_bounds(total_streams, rank, world)
+        assert last - first == N
     corpus = workload.load_corpus()
     mg = None
+    full = None
     if args.diag_data == "zeros":
         d_in = torch.zeros((N, L), dtype=torch.uint8, device=dev)
     elif args.diag_data == "random":
@@ -422,8 +434,6 @@ def main():
             d_in = sharding.scatter_streams(full, total_streams, L, dev)
             barrier(); scatter_s = time.perf_counter() - t0
             mg = {"scatter_ms": round(sharding.max_over_ranks(scatter_s, dev) * 1e3, 3)}
-            if rank != 0:
-                full = None
         elif args.host_data:
             d_in = torch.empty((N, L), dtype=torch.uint8, device=dev)
             for c0 in range(0, N, 2048):
@@ -437,24 +447,27 @@ def main():
         if args.diag_data == "repeat1k":
             d_in = d_in[:, :1024].repeat(1, L // 1024).contiguous()
 
-    head_name = "simple" if args.config in ("all", "simple") else ("mixing" if args.config == "mixing" else None)
-    line = None
-    codec = None
-    if head_name:
-        res, codec, outs = run_pair_config(torch, da, po, head_name, d_in, N, L, args, dev, barrier)
+    scaling = "strong" if strong else "weak"
+    shard_text = (f"{total_streams} independent {L} B streams in total, split into contiguous ranges over the GPUs ({N} on this rank)" if strong
+                  else f"{N} independent {L} B streams per GPU")
+
+    def pair_record(name):
+        """One encode+decode configuration on every rank: verify, time (max over ranks), at world > 1 gather the coded streams
+        to rank 0 and check them there.  Returns (record for rank 0, bit-exact on all ranks)."""
+        res, codec, outs = run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier)
         elapsed = sharding.max_over_ranks(res["elapsed"], dev)
         coded_all, ok_count = sharding.sum_over_ranks([res["coded_total"], int(res["ok"])], dev)
         ok_all = ok_count == world
         K = res["steps"]
+        m = None
         if world > 1:
             # variable-length gather of the coded streams to rank 0 (outside the timed region), checked there
             barrier(); t0 = time.perf_counter()
-            packed, poff, ptotal = codec.pack(outs, N)
-            blob, goffs, gsizes = sharding.gather_coded(packed, outs["sizes"].to(torch.int64), total_streams)
+            blob, goffs, gsizes = sharding.gather_coded(outs["packed"], outs["sizes"].to(torch.int64), total_streams)
             barrier(); gather_s = sharding.max_over_ranks(time.perf_counter() - t0, dev)
             g_ok = 1
             if rank == 0:
-                ocfg = po.config_simple() if head_name == "simple" else po.config_context_mixing()
+                ocfg = po.config_simple() if name == "simple" else po.config_context_mixing()
                 g_ok = int(int(gsizes.sum().item()) == coded_all)
                 for r in range(world):
                     rb, re = sharding.shard_bounds(total_streams, r, world)
@@ -465,72 +478,84 @@ def main():
             g_ok, = sharding.sum_over_ranks([g_ok if rank == 0 else 1], dev)
             ok_all = ok_all and g_ok == world
             step_s = elapsed / K
-            mg.update({"gather_ms": round(gather_s * 1e3, 3), "gathered_bytes": int(coded_all), "gather_checked_on_rank0": bool(g_ok == world),
-                       "rccl_world_size": world,
-                       "scatter_gather_inclusive_MBps": round(total_streams * L / 1e6 / (step_s + mg["scatter_ms"] / 1e3 + gather_s), 2)})
+            m = dict(mg)
+            m.update({"gather_ms": round(gather_s * 1e3, 3), "gathered_bytes": int(coded_all), "gather_checked_on_rank0": bool(g_ok == world),
+                      "rccl_world_size": world,
+                      "scatter_gather_inclusive_MBps": round(total_streams * L / 1e6 / (step_s + mg["scatter_ms"] / 1e3 + gather_s), 2)})
             t = torch.zeros(world, dtype=torch.float64, device=dev); t[rank] = res["elapsed"] / K * 1e3
             dist.all_reduce(t)
-            mg["per_rank_ms_per_step"] = [round(float(x), 3) for x in t.tolist()]
+            m["per_rank_ms_per_step"] = [round(float(x), 3) for x in t.tolist()]
+        codec.close()
+        del outs
+        torch.cuda.empty_cache()
+        total_bytes = total_streams * L
+        rec = {"value": round(total_bytes / 1e6 / (elapsed / K), 2), "steps": K, "ms_per_step": round(elapsed * 1e3 / K, 3),
+               "bit_exact": bool(ok_all), "checked_vs_oracle": res["checked_vs_oracle"], "compressed_ratio": round(coded_all / float(total_bytes), 4),
+               "encode_MBps": res["encode_MBps"], "decode_MBps": res["decode_MBps"], "kernel_ms": res["kernel_ms"], "roofline": res["roofline"]}
+        if m:
+            rec["multi_gpu"] = m
+        return rec, ok_all
+
+    head_name = "simple" if args.config in ("all", "simple") else ("mixing" if args.config == "mixing" else None)
+    line = None
+    if head_name:
+        rec, ok_all = pair_record(head_name)
         if rank == 0:
-            total_bytes = total_streams * L
             cfg_text = ("TestSimple: stride 1, context map off (BASELINE configs[1])" if head_name == "simple"
                         else "TestContextMixing: context map + dynamic_context_mixing=2 (BASELINE configs[2])")
             line = {
                 "metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU",
-                "value": round(total_bytes / 1e6 / (elapsed / K), 2), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-                "ms_per_step": round(elapsed * 1e3 / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "value": rec["value"], "unit": "MB/s", "n_gpus": world, "steps": rec["steps"], "warmup": args.warmup,
+                "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                 "dtype": "u16/u64 integer", "data": "synthetic",
-                "config": {"workload": f"{N} independent {L} B streams per GPU cut from alice29||asyoulik (stride 4099, 1% xorshift64* perturbation); {cfg_text}",
-                           "streams_per_gpu": N, "block_bytes": L, "sharding": "contiguous stream ranges per rank; no collective inside the timed region"},
-                "bit_exact": bool(ok_all), "bit_exact_against": f"in-repo C oracle (restatement of the reference CPU path; compressed bytes unpinned vs the Rust build): "
-                                                                f"coded bytes of {res['checked_vs_oracle']} streams per rank + exact round trip of all",
-                "compressed_ratio": round(coded_all / float(total_bytes), 4),
-                "encode_MBps": res["encode_MBps"], "decode_MBps": res["decode_MBps"],
-                "kernel_ms": res["kernel_ms"], "roofline": res["roofline"],
+                "config": {"workload": f"{shard_text} cut from alice29||asyoulik (stride 4099, 1% xorshift64* perturbation); {cfg_text}",
+                           "streams_per_gpu": N, "total_streams": total_streams, "block_bytes": L,
+                           "sharding": "contiguous stream ranges per rank; no collective inside the timed region"},
+                "bit_exact": rec["bit_exact"], "bit_exact_against": f"in-repo C oracle (restatement of the reference CPU path; compressed bytes unpinned vs the Rust build): "
+                                                                f"coded bytes of {rec['checked_vs_oracle']} streams per rank + exact round trip of all",
+                "compressed_ratio": rec["compressed_ratio"],
+                "encode_MBps": rec["encode_MBps"], "decode_MBps": rec["decode_MBps"],
+                "kernel_ms": rec["kernel_ms"], "roofline": rec["roofline"],
             }
-            if mg:
-                line["multi_gpu"] = mg
-        codec.close(); codec = None
-        del outs
-        torch.cuda.empty_cache()
-        if not ok_all and rank == 0:
-            print(json.dumps(line))
+            if "multi_gpu" in rec:
+                line["multi_gpu"] = rec["multi_gpu"]
+        if not ok_all:
+            if rank == 0:
+                print(json.dumps(line))
             sys.exit("bench: GPU output is NOT bit-exact / round-trip failed")
 
-    if world == 1 and args.config in ("all", "mixing", "decode_only"):
+    if args.config in ("all", "mixing", "decode_only"):
         sub = {}
         if args.config == "all":
-            r2, c2, o2 = run_pair_config(torch, da, po, "mixing", d_in, N, L, args, dev, barrier)
-            c2.close(); del o2; torch.cuda.empty_cache()
-            sub["mixing"] = {
-                "workload": "same streams, TestContextMixing: context map cm[i]=i&63, utf8, block type 1, dynamic_context_mixing=2 (BASELINE configs[2])",
-                "bit_exact": bool(r2["ok"]), "checked_vs_oracle": r2["checked_vs_oracle"], "steps": r2["steps"],
-                "ms_per_step": round(r2["elapsed"] * 1e3 / r2["steps"], 3),
-                "value": round(N * L / 1e6 / (r2["elapsed"] / r2["steps"]), 2), "unit": "MB/s encode+decode",
-                "encode_MBps": r2["encode_MBps"], "decode_MBps": r2["decode_MBps"], "compressed_ratio": round(r2["coded_total"] / float(N * L), 4),
-                "kernel_ms": r2["kernel_ms"], "roofline": r2["roofline"],
-            }
-            if not args.no_cpu_baseline:
+            # configs[2] on the same streams; at world > 1 this is configs[4]'s second option set, with its own scatter/gather record
+            r2, ok2 = pair_record("mixing")
+            r2 = dict(r2)
+            r2.update({"workload": "same streams, TestContextMixing: context map cm[i]=i&63, utf8, block type 1, dynamic_context_mixing=2 (BASELINE configs[2])",
+                       "unit": "MB/s encode+decode"})
+            sub["mixing"] = r2
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 sub["mixing"]["cpu_baseline"] = cpu_baseline("mixing", workload, corpus, L)
-        if args.config in ("all", "decode_only"):
+        if world == 1 and args.config in ("all", "decode_only"):
             sub["decode_only"] = run_decode_only(torch, da, po, args, dev)
             if not args.no_cpu_baseline:
                 import lzma
                 with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
                     rtu = np.frombuffer(f.read(), dtype=np.uint8).copy()
-                full = rtu[:(rtu.size // 65536) * 65536].reshape(-1, 65536)     # the four whole 64 KiB blocks of the file
-                cb = cpu_baseline("mixing", workload, corpus, 65536, sample_blocks=lambda n: np.ascontiguousarray(full[np.arange(n) % full.shape[0]]),
+                whole = rtu[:(rtu.size // 65536) * 65536].reshape(-1, 65536)     # the four whole 64 KiB blocks of the file
+                cb = cpu_baseline("mixing", workload, corpus, 65536, sample_blocks=lambda n: np.ascontiguousarray(whole[np.arange(n) % whole.shape[0]]),
                                   decode_only=True, per_thread=96)
                 cb["sample"] = "decode direction of: " + cb["sample"].replace("streams of the same workload", "streams (the four whole 64 KiB blocks of testdata/random_then_unicode, repeated)")
                 sub["decode_only"]["cpu_baseline"] = cb
-        if line is None:
-            line = {"metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU", "value": None, "unit": "MB/s", "n_gpus": 1,
-                    "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic",
-                    "config": {"workload": f"sub-config run: {args.config}"}}
-        line["configs"] = sub
+        if rank == 0:
+            if line is None:
+                line = {"metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU", "value": None, "unit": "MB/s", "n_gpus": world,
+                        "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic", "scaling": scaling,
+                        "config": {"workload": f"sub-config run: {args.config}"}}
+            line["configs"] = sub
         bad = [k for k, v in sub.items() if not v["bit_exact"]]
         if bad:
-            print(json.dumps(line))
+            if rank == 0:
+                print(json.dumps(line))
             sys.exit(f"bench: sub-config {bad} is NOT bit-exact")
 
     if rank == 0:

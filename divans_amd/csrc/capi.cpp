@@ -266,14 +266,15 @@ static void configure_from_geometry(divans_gpu_codec* c) {
         const uint32_t fit = (160u * 1024u) / lds_per_wg;
         c->blocks = c->num_cus * std::max(1u, std::min(7u, fit));
     }
-    // lit_decode2_kernel: direct-mapped caches, 16-bit row ids in the tags.  Defaults (profiles/r03_*): the high stride rows get 32
-    // slots -- indexed by the previous byte itself when the context is constant, by row ^ (row >> 5) otherwise -- and with prior
+    // lit_decode2_kernel: 2-way caches, 15-bit row ids in the tags.  Defaults (profiles/r03_*): the high stride rows get 32
+    // rows -- sets indexed by the previous byte itself when the context is constant, by row ^ (row >> 5) otherwise -- and with prior
     // mixing the FirstNibble context-map rows 16 of their own; the low-nibble rows are many and stay in HBM / L2.
     c->blocks2 = 0; c->dm_log2 = 0; c->dm_shift = 0;
-    if (c->geom.total_rows < 0xffffu) {
+    if (c->geom.total_rows < 0x7fffu) {
         if (c->mix) { c->dm_log2 = 5u | (5u << 8); c->dm_shift = 5u | (5u << 8); }
         else { c->dm_log2 = 6u; c->dm_shift = c->geom.ctx_const >= 0 ? 31u : 5u; }
     }
+    c->dm_shift |= 0x80000000u;   // 2-way organisation (generation 3): fewer misses than direct mapped at the same time per byte
     {
         const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
         const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) +
@@ -466,21 +467,25 @@ extern "C" int divans_gpu_codec_set_lane_layout(divans_gpu_codec* c, uint32_t la
 // the persistent grid (0 = keep).
 extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    if (generation != 1u && generation != 2u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1 or 2");
+    if (generation < 1u || generation > 3u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches) or 3 (second generation, 2-way caches)");
     HIP_TRY(hipSetDevice(c->device));
+    const bool two_way = generation == 3u;
+    if (generation == 3u) generation = 2u;
+    c->dm_shift = (c->dm_shift & 0x7fffffffu) | (two_way ? 0x80000000u : 0u);
     if (generation == 2u && rows && shifts) {
         uint32_t lg2 = 0, sh = 0;
         for (int i = 0; i < 4; ++i) {
             if (rows[i]) {
                 if (rows[i] < 4u || rows[i] > 256u || (rows[i] & (rows[i] - 1u))) return fail(DIVANS_GPU_EINVAL, "cache rows must be 0 or a power of two in [4, 256]");
-                if (c->geom.total_rows >= 0xffffu) return fail(DIVANS_GPU_EINVAL, "row caches need fewer than 65535 rows per stream");
+                if (c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row caches need fewer than 32767 rows per stream");
                 uint32_t l = 0; while ((1u << l) < rows[i]) ++l;
                 lg2 |= (l + 1u) << (8 * i);
             }
             if (shifts[i] > 31u) return fail(DIVANS_GPU_EINVAL, "hash shift must be below 32");
             sh |= shifts[i] << (8 * i);
         }
-        c->dm_log2 = lit_decode2_effective_caches(lg2, c->mix, false); c->dm_shift = sh;   // only the cache sets that exist as kernel instances
+        c->dm_log2 = lit_decode2_effective_caches(lg2, c->mix, false);   // only the cache sets that exist as kernel instances
+        c->dm_shift = sh | (two_way ? 0x80000000u : 0u);
     }
     const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
     const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) +
@@ -510,10 +515,9 @@ extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t block
     if (blocks) {
         c->blocks = blocks;
         if (c->blocks2) {    // the second-generation decoder follows, as far as its LDS use allows
-            const uint32_t keep_log2 = c->dm_log2;
             const uint32_t gen = c->decode_gen;
-            int rc = divans_gpu_codec_set_decoder(c, 2, nullptr, nullptr, blocks); if (rc) return rc;
-            c->decode_gen = gen; c->dm_log2 = keep_log2;
+            int rc = divans_gpu_codec_set_decoder(c, (c->dm_shift >> 31) ? 3 : 2, nullptr, nullptr, blocks); if (rc) return rc;
+            c->decode_gen = gen;
         }
     }
     return 0;

@@ -10,8 +10,8 @@
 //     does not cost VALU issue cycles;
 //   * blend (probability/frequentist_cdf.rs:74-85): the renormalisation half sits behind a wave-level branch (with the
 //     reference's speeds a row renormalises once in hundreds of updates);
-//   * row caches: direct mapped, tag and data are read in parallel (one LDS round trip, a third of the instructions of the
-//     2-way lookup), one cache per table so that the rows of one nibble never compete for a slot;
+//   * row caches: 2-way, both ways' data and the tag word are read in parallel (one LDS round trip), one cache per table so that
+//     the rows of one nibble never compete for a set;
 //   * coded words: a 32-word ring per stream in LDS, topped up 16 words at a time (ans.rs:428-442 reads them in this order).
 //
 // Arithmetic and results are those of lit_decode_kernel (the parity tests run both against the oracle).
@@ -25,6 +25,7 @@ namespace divans_hip {
 namespace {
 
 // LDS is addressed with 32-bit byte addresses (address space 3): no generic-pointer arithmetic in the byte loop
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_read16(uint32_t a) { return *(const lds_u16*)(uintptr_t)a; }
@@ -35,17 +36,24 @@ __device__ __forceinline__ void lds_write32(uint32_t a, uint32_t v) { *(lds_u32*
 constexpr uint32_t kRingWords = 32u;
 constexpr uint32_t kRingBytes = kRingWords * 4u;
 
+// One per-stream row cache in LDS, write back, in one of two organisations (compile-time, CM_2WAY):
+//  * direct mapped: slot = 16 lanes x u16, tag = u16 row id (0x7fff = empty); the slot's data and its tag are read in parallel;
+//  * 2-way set associative: a set is 16 lanes x u32 of data -- lane i holds entry i of way 0 in the low half and of way 1 in the
+//    high half, so ONE ds_read_b32 per lane fetches both candidates while the set's tag word (way 0 row id | way 1 row id << 15 |
+//    most recently used way << 31) is read in parallel.
+// Either way a hit costs one LDS round trip.
 struct DmCache {
-    uint32_t data_off;   // LDS address of slot 0 of this stream's cache + 2 * lane-in-row
-    uint32_t tag_off;    // LDS address of its tags (u16 row ids, 0xffff = empty)
-    uint32_t mask;       // slots - 1, 0xffffffff = this table is accessed in HBM / L2 directly
-    uint32_t shift;      // set = (row ^ (row >> shift)) & mask
+    uint32_t data_off;   // LDS address of slot / set 0 of this stream's cache + (2 or 4) * lane-in-row
+    uint32_t tag_off;    // LDS address of its tags
+    uint32_t mask;       // slots - 1 / sets - 1
+    uint32_t shift;      // index = (row ^ (row >> shift)) & mask
 };
 
-struct RowSlot { uint32_t row; uint32_t addr; };
+struct RowSlot { uint32_t row; uint32_t addr; bool missed; };   // missed: the row was requested with gload_async()
 
 struct Table2 {
     __amdgpu_buffer_rsrc_t rsrc;
+    i32x4 rsrc_words;    // the same descriptor as four dwords, for the loads issued from inline asm
     uint32_t lane_off;   // row-of-lanes slab offset + 2 * lane-in-row
     __device__ __forceinline__ int gload(uint32_t row) const {
         return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, 0);
@@ -53,22 +61,57 @@ struct Table2 {
     __device__ __forceinline__ void gstore(uint32_t row, int v) const {
         __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, rsrc, lane_off + (row << 5), 0, 0);
     }
+    // A high-nibble row fetched on a cache miss is requested one nibble ahead and first used at the top of the next byte.  The
+    // vector-memory counter covers loads AND stores (and a store may be acknowledged before an older load has returned, so only
+    // vmcnt(0) proves a load complete): a compiler-placed wait at the top of the byte would wait for the row stores the previous
+    // byte ended with on EVERY byte -- a store acknowledgement on the dependency chain -- although most bytes miss nothing.
+    // These loads therefore go out through inline asm (the compiler does not see them), the lookup reports the miss, and the
+    // byte loop waits (wait_async) only when some stream of the wave did miss.
+    __device__ __forceinline__ int gload_async(uint32_t row) const {
+        int v;
+        asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" : "=v"(v) : "v"(lane_off + (row << 5)), "s"(rsrc_words) : "memory");
+        return v;
+    }
     // Every access of the coder is a read-modify-write of a whole row: a cached row is always dirty, a miss writes the
-    // slot's previous row back (its data is what the speculative read returned) and fetches the new one.
-    template <bool PRESENT>
+    // victim's row back (its data is in what the speculative read returned) and fetches the new one.
+    template <bool PRESENT, bool TWOWAY, bool ASYNC>
     __device__ __forceinline__ int load(const DmCache& d, uint32_t row, RowSlot& s) const {
         s.row = row;
+        s.missed = false;
         if (!PRESENT) return gload(row);
         const uint32_t set = (row ^ (row >> d.shift)) & d.mask;
-        s.addr = d.data_off + (set << 5);
-        const uint32_t taddr = d.tag_off + (set << 1);
-        int v = (int)lds_read16(s.addr);
-        const uint32_t tag = lds_read16(taddr);
-        if (tag != row) {
-            if (tag != 0xffffu) gstore(tag, v);
-            v = gload(row);
-            lds_write16(taddr, row);
+        if (!TWOWAY) {
+            s.addr = d.data_off + (set << 5);
+            const uint32_t taddr = d.tag_off + (set << 1);
+            int v = (int)lds_read16(s.addr);
+            const uint32_t tag = lds_read16(taddr);
+            if (tag != row) {
+                if (tag != 0x7fffu) gstore(tag, v);
+                v = ASYNC ? gload_async(row) : gload(row);
+                lds_write16(taddr, row);
+                s.missed = ASYNC;
+            }
+            return v;
         }
+        const uint32_t daddr = d.data_off + (set << 6);
+        const uint32_t taddr = d.tag_off + (set << 2);
+        const uint32_t pair = lds_read32(daddr);
+        const uint32_t tp = lds_read32(taddr);
+        const uint32_t t0 = tp & 0x7fffu, t1 = (tp >> 15) & 0x7fffu;
+        const bool h0 = t0 == row, h1 = t1 == row;
+        const uint32_t way = h1 ? 1u : (h0 ? 0u : ((tp >> 31) ^ 1u));
+        int v = (int)(way ? pair >> 16 : pair & 0xffffu);
+        s.addr = daddr + (way << 1);
+        uint32_t ntp = tp;
+        if (!(h0 || h1)) {
+            const uint32_t victim = way ? t1 : t0;
+            if (victim != 0x7fffu) gstore(victim, v);
+            v = ASYNC ? gload_async(row) : gload(row);
+            s.missed = ASYNC;
+            ntp = way ? ((tp & ~(0x7fffu << 15)) | (row << 15)) : ((tp & ~0x7fffu) | row);
+        }
+        ntp = (ntp & 0x7fffffffu) | (way << 31);
+        if (ntp != tp) lds_write32(taddr, ntp);
         return v;
     }
     template <bool PRESENT>
@@ -76,20 +119,26 @@ struct Table2 {
         if (!PRESENT) gstore(s.row, v);
         else lds_write16(s.addr, (uint32_t)v);
     }
-    template <bool PRESENT>
+    template <bool PRESENT, bool TWOWAY>
     __device__ __forceinline__ void reset(const DmCache& d, int li) const {
         if (!PRESENT) return;
-        for (uint32_t s = (uint32_t)li; s <= d.mask; s += 16u) lds_write16(d.tag_off + (s << 1), 0xffffu);
+        if (TWOWAY) { for (uint32_t s = (uint32_t)li; s <= d.mask; s += 16u) lds_write32(d.tag_off + (s << 2), 0x3fffffffu); }
+        else { for (uint32_t s = (uint32_t)li; s <= d.mask; s += 16u) lds_write16(d.tag_off + (s << 1), 0x7fffu); }
     }
 };
 
+// wait for the gload_async() requests; the value operands tie the first uses of the loaded registers to this point
+__device__ __forceinline__ void wait_async(int& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
+__device__ __forceinline__ void wait_async(int& a, int& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+
 struct Caches { DmCache hs, hc, ls, lc; };   // high stride rows, high context-map rows (FirstNibble), low stride rows, low context-map rows
 // which of them exist is a compile-time mask CM (an absent cache then costs no registers): bit 0 hs, 1 hc, 2 ls, 3 lc
-constexpr int CM_HS = 1, CM_HC = 2, CM_LS = 4, CM_LC = 8;
+constexpr int CM_HS = 1, CM_HC = 2, CM_LS = 4, CM_LC = 8, CM_2WAY = 16;   // CM_2WAY: the organisation of all of them
 
 __device__ __forceinline__ uint32_t dm_rows(uint32_t packed, int i) { return (packed >> (8 * i)) & 0xffu; }   // log2(rows) + 1, 0 = absent
 
 // per-stream LDS region: [ring][hs data][hc data][ls data][lc data][hs tags][hc tags][ls tags][lc tags]
+template <bool TWOWAY>
 __device__ __forceinline__ Caches make_caches(const LitBatch& b, uint32_t stream_base, int li) {
     Caches c;
     DmCache* all[4] = {&c.hs, &c.hc, &c.ls, &c.lc};
@@ -97,9 +146,9 @@ __device__ __forceinline__ Caches make_caches(const LitBatch& b, uint32_t stream
     for (int i = 0; i < 4; ++i) {
         const uint32_t lg = dm_rows(b.dm_log2, i);
         const uint32_t rows = lg ? 1u << (lg - 1u) : 0u;
-        all[i]->data_off = off + 2u * (uint32_t)li;
-        all[i]->mask = rows ? rows - 1u : 0xffffffffu;
-        all[i]->shift = (b.dm_shift >> (8 * i)) & 0xffu;
+        all[i]->data_off = off + (TWOWAY ? 4u : 2u) * (uint32_t)li;
+        all[i]->mask = rows ? (TWOWAY ? rows >> 1 : rows) - 1u : 0u;
+        all[i]->shift = (b.dm_shift >> (8 * i)) & 0x1fu;   // bit 31 of dm_shift selects the 2-way organisation
         off += rows * 32u;
     }
     for (int i = 0; i < 4; ++i) {
@@ -256,31 +305,45 @@ __device__ __forceinline__ uint32_t mixed_sf2(int p, int cm, int st, int pmax, i
     return (uint32_t)row_bcast<0>((int)q);
 }
 
+// The mixing nibble in three steps, so that the byte loop can request the NEXT nibble's rows as soon as a symbol is known and
+// run the rest of the current one (three (start, freq) pairs, state update, two blends) under those fetches.
+struct MixRows { RowSlot sref, cref; int st, cm; bool is_default; };
+struct MixSearched { Searched s; int cv, cmax, smax; uint32_t slot; };
+
 template <bool HIGH, int MM, bool NEED8, int CM>
-__device__ __forceinline__ uint32_t decode_nibble_mix2(const LitGeometry& g, const LdsView& lv, const Table2& tb, const Caches& cc, int li1,
-                                                       int rbase, int rbase4, const MixLanes& ml, uint32_t ctx, const History<NEED8>& hist, uint32_t hi_nib,
-                                                       uint64_t& S, int mix_rate, uint32_t& wfreqs, uint32_t& wpmix) {
+__device__ __forceinline__ MixRows fetch_mix2(const LitGeometry& g, const LdsView& lv, const Table2& tb, const Caches& cc, uint32_t ctx,
+                                              const History<NEED8>& hist, uint32_t hi_nib) {
     const RowSel rs = select_rows2<HIGH, MM, NEED8>(g, lv.mix, ctx, hist, hi_nib);
-    const DmCache& dst = HIGH ? cc.hs : cc.ls;
-    const DmCache& dcm = HIGH ? cc.hc : cc.lc;
-    RowSlot sref, cref;
     constexpr bool ST_C = (CM & (HIGH ? CM_HS : CM_LS)) != 0, CM_C = (CM & (HIGH ? CM_HC : CM_LC)) != 0;
-    int st = tb.template load<ST_C>(dst, rs.stride_row, sref);
-    int cm = tb.template load<CM_C>(dcm, rs.cm_row, cref);
-    const int cmax = row_bcast<15>(cm), smax = row_bcast<15>(st);
-    const int cv = average_rows(cm, st, cmax, smax, mix_rate);
-    const uint32_t slot = (uint32_t)S & 0x7fffu;
-    const Searched s = search2(cv, slot, rbase);
+    MixRows r;
+    r.st = tb.template load<ST_C, (CM & CM_2WAY) != 0, HIGH>(HIGH ? cc.hs : cc.ls, rs.stride_row, r.sref);
+    r.cm = tb.template load<CM_C, (CM & CM_2WAY) != 0, HIGH>(HIGH ? cc.hc : cc.lc, rs.cm_row, r.cref);
+    r.is_default = (MM < 0 || MM == 2) && rs.is_default;
+    return r;
+}
+
+__device__ __forceinline__ MixSearched search_mix2(const MixRows& r, uint64_t S, int mix_rate, int rbase) {
+    MixSearched m;
+    m.cmax = row_bcast<15>(r.cm); m.smax = row_bcast<15>(r.st);
+    m.cv = average_rows(r.cm, r.st, m.cmax, m.smax, mix_rate);
+    m.slot = (uint32_t)S & 0x7fffu;
+    m.s = search2(m.cv, m.slot, rbase);
+    return m;
+}
+
+template <bool HIGH, int CM>
+__device__ __forceinline__ void finish_mix2(const LitGeometry& g, const Table2& tb, const Caches& cc, int li1, int rbase4, const MixLanes& ml,
+                                            MixRows& r, const MixSearched& m, uint64_t& S, uint32_t& wfreqs, uint32_t& wpmix) {
+    constexpr bool ST_C = (CM & (HIGH ? CM_HS : CM_LS)) != 0, CM_C = (CM & (HIGH ? CM_HC : CM_LC)) != 0;
     uint32_t dprev;
-    const uint32_t d = mixed_sf2(cv, cm, st, s.mx, cmax, smax, ml, rbase4, s.sym, dprev, wfreqs);
+    const uint32_t d = mixed_sf2(m.cv, r.cm, r.st, m.s.mx, m.cmax, m.smax, ml, rbase4, m.s.sym, dprev, wfreqs);
     wpmix = d - dprev - 1u;
-    advance_state(S, slot, d, dprev);
-    cm = blend2(cm, li1, s.above, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
-    tb.template store<CM_C>(dcm, cref, cm);
-    const bool is_default = (MM < 0 || MM == 2) && rs.is_default;
-    if (!is_default) st = blend2(st, li1, s.above, g.inc0, g.lim0, smax);
-    tb.template store<ST_C>(dst, sref, st);
-    return (uint32_t)s.sym;
+    advance_state(S, m.slot, d, dprev);
+    const int cm = blend2(r.cm, li1, m.s.above, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, m.cmax);
+    tb.template store<CM_C>(HIGH ? cc.hc : cc.lc, r.cref, cm);
+    int st = r.st;
+    if (!r.is_default) st = blend2(st, li1, m.s.above, g.inc0, g.lim0, m.smax);
+    tb.template store<ST_C>(HIGH ? cc.hs : cc.ls, r.sref, st);
 }
 
 struct Fetched2 { RowSlot ref; int value; bool is_default; };
@@ -290,7 +353,7 @@ __device__ __forceinline__ Fetched2 fetch2(const LitGeometry& g, const LdsView& 
                                            const History<NEED8>& hist, uint32_t hi_nib) {
     const RowSel rs = select_rows2<HIGH, MM, NEED8>(g, lv.mix, ctx, hist, hi_nib);
     Fetched2 f;
-    f.value = tb.template load<(CM & (HIGH ? CM_HS : CM_LS)) != 0>(HIGH ? cc.hs : cc.ls, rs.stride_row, f.ref);
+    f.value = tb.template load<(CM & (HIGH ? CM_HS : CM_LS)) != 0, (CM & CM_2WAY) != 0, HIGH>(HIGH ? cc.hs : cc.ls, rs.stride_row, f.ref);
     f.is_default = (MM < 0 || MM == 2) && rs.is_default;
     return f;
 }
@@ -306,8 +369,9 @@ __device__ __forceinline__ void init_table2(const Table2& t, const Caches& cc, u
     for (uint32_t i = 0; i < rows * 32u; i += 256u) {
         if (i + 16u * (uint32_t)li < rows * 32u) __builtin_amdgcn_raw_buffer_store_b128(v, t.rsrc, base + i, 0, 0);
     }
-    t.template reset<(CM & CM_HS) != 0>(cc.hs, li); t.template reset<(CM & CM_HC) != 0>(cc.hc, li);
-    t.template reset<(CM & CM_LS) != 0>(cc.ls, li); t.template reset<(CM & CM_LC) != 0>(cc.lc, li);
+    constexpr bool W2 = (CM & CM_2WAY) != 0;
+    t.template reset<(CM & CM_HS) != 0, W2>(cc.hs, li); t.template reset<(CM & CM_HC) != 0, W2>(cc.hc, li);
+    t.template reset<(CM & CM_LS) != 0, W2>(cc.ls, li); t.template reset<(CM & CM_LC) != 0, W2>(cc.lc, li);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);  // the row loads that follow must see the fill
 }
@@ -315,8 +379,7 @@ __device__ __forceinline__ void init_table2(const Table2& t, const Caches& cc, u
 }  // namespace
 
 template <int MM, bool CTXC, bool MIX, bool SEG, int CM>
-__global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel(const LitBatch b) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+__device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
     const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
     const LitGeometry& g = b.geom;
     const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48, rbase4 = rbase << 2, li1 = li + 1;
@@ -328,10 +391,13 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel(const LitBatch
         tb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab),
                                                     0, (LIT_THREADS / 16) * slab, 0x00020000);
         tb.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
+        const uint64_t base = (uint64_t)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab);
+        tb.rsrc_words = i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)base), __builtin_amdgcn_readfirstlane((int)((uint32_t)(base >> 32) & 0xffffu)),
+                              __builtin_amdgcn_readfirstlane((int)((LIT_THREADS / 16) * slab)), 0x00020000};
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
     const uint32_t stream_base = lds_base + (threadIdx.x >> 4) * (b.cache_bytes_per_wg / (LIT_THREADS / 16));
-    const Caches cc = make_caches(b, stream_base, li);
+    const Caches cc = make_caches<(CM & CM_2WAY) != 0>(b, stream_base, li);
     MixLanes ml;
     ml.odd = (li & 1) != 0; ml.is_p = li < 4; ml.is_cm = (li & 12) == 4; ml.addr_bias = ml.odd ? -4 : 0;
     for (uint32_t s = gg; s < b.n_streams; s += G) {
@@ -357,7 +423,9 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel(const LitBatch
         bool corrupt = false;
         uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, hist.p1, k1);
         Fetched2 rowH = {};
+        MixRows mrowH = {};
         if (!MIX) rowH = fetch2<true, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, 0u);
+        else mrowH = fetch_mix2<true, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, 0u);
         for (uint32_t cbeg = 0; cbeg < len; cbeg += 32768u) {
             // start of a 65 536-symbol chunk: 16 bytes = state_a, state_b (ans.rs:174-186)
             {
@@ -371,15 +439,18 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel(const LitBatch
                 uint32_t outb = 0;
                 for (uint32_t k = 0; k < cnt; ++k) {
                     if (MIX) {
-                        const uint32_t ctx = ctx_cur;
                         // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
                         if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li);
+                        // the rows requested one nibble ahead, if a stream of this wave missed its cache
+                        if ((CM & (CM_HS | CM_HC)) && __ballot(mrowH.sref.missed || mrowH.cref.missed) != 0ull) wait_async(mrowH.st, mrowH.cm);
+                        const MixSearched mh = search_mix2(mrowH, SA, nh, rbase);
+                        const uint32_t hi = (uint32_t)mh.s.sym;
+                        MixRows mrowL = fetch_mix2<false, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, hi);
                         uint32_t fh = 0, fl = 0, ph = 0, pl = 0;
-                        const uint32_t hi = decode_nibble_mix2<true, MM, NEED8, CM>(g, lv, tb, cc, li1, rbase, rbase4, ml, ctx, hist, 0u, SA, nh, fh, ph);
+                        finish_mix2<true, CM>(g, tb, cc, li1, rbase4, ml, mrowH, mh, SA, fh, ph);
                         if (SB < (1ull << 31)) SB = (SB << 32) | ww.next(li);
-                        const uint32_t lo = decode_nibble_mix2<false, MM, NEED8, CM>(g, lv, tb, cc, li1, rbase, rbase4, ml, ctx, hist, hi, SB, nl, fl, pl);
-                        wp.update(li, fh, ph, fl, pl);
-                        nh = wp.norm_high(); nl = wp.norm_low();
+                        const MixSearched mlo = search_mix2(mrowL, SB, nl, rbase);
+                        const uint32_t lo = (uint32_t)mlo.s.sym;
                         const uint32_t byte = (hi << 4) | lo;
                         hist.push(byte);
                         if (SEG) {   // the next Literal command starts from the ring buffer's last 8 bytes and its own block type
@@ -387,10 +458,15 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel(const LitBatch
                         }
                         if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];
                         ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, hist.p1, k1);
+                        mrowH = fetch_mix2<true, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, 0u);   // next byte's rows (harmless past the end)
+                        finish_mix2<false, CM>(g, tb, cc, li1, rbase4, ml, mrowL, mlo, SB, fl, pl);
+                        wp.update(li, fh, ph, fl, pl);
+                        nh = wp.norm_high(); nl = wp.norm_low();
                         outb = (uint32_t)li == k ? byte : outb;
                     } else {
                         // rowH (this byte's high-nibble row) was requested while the previous byte was being finished
                         if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li);
+                        if ((CM & CM_HS) && __ballot(rowH.ref.missed) != 0ull) wait_async(rowH.value);
                         const int cvh = rowH.is_default ? 4 * li1 : rowH.value;
                         const uint32_t slot_a = (uint32_t)SA & 0x7fffu;
                         const Searched sh = search2(cvh, slot_a, rbase);
@@ -423,15 +499,29 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel(const LitBatch
     }
 }
 
+// Seven waves per SIMD hide the per-byte HBM round trip better than six with a few more registers each: the instances whose
+// mixing value is a compile-time constant are held to 72 VGPRs (the mixing ones then park one 64-bit value per stream in
+// scratch, outside the byte loop); the table-driven ones keep what they need.
+template <int MM, bool CTXC, bool MIX, bool SEG, int CM>
+__global__ __launch_bounds__(LIT_THREADS) __attribute__((amdgpu_waves_per_eu(7))) void lit_decode2_kernel_w7(const LitBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    decode2_body<MM, CTXC, MIX, SEG, CM>(b, lds);
+}
+template <int MM, bool CTXC, bool MIX, bool SEG, int CM>
+__global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel_any(const LitBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    decode2_body<MM, CTXC, MIX, SEG, CM>(b, lds);
+}
+
 typedef void (*LitKernel)(const LitBatch);
 
 template <bool MIX, bool SEG, int CM>
 static LitKernel pick_decode2_cm(int mm, bool ctxc) {
     const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 2 + (ctxc ? 1 : 0);
     switch (key) {
-    case 0: return lit_decode2_kernel<-1, false, MIX, SEG, CM>; case 1: return lit_decode2_kernel<-1, true, MIX, SEG, CM>;
-    case 2: return lit_decode2_kernel<0, false, MIX, SEG, CM>;  case 3: return lit_decode2_kernel<0, true, MIX, SEG, CM>;
-    case 4: return lit_decode2_kernel<4, false, MIX, SEG, CM>;  default: return lit_decode2_kernel<4, true, MIX, SEG, CM>;
+    case 0: return lit_decode2_kernel_any<-1, false, MIX, SEG, CM>; case 1: return lit_decode2_kernel_any<-1, true, MIX, SEG, CM>;
+    case 2: return lit_decode2_kernel_w7<0, false, MIX, SEG, CM>;  case 3: return lit_decode2_kernel_w7<0, true, MIX, SEG, CM>;
+    case 4: return lit_decode2_kernel_w7<4, false, MIX, SEG, CM>;  default: return lit_decode2_kernel_w7<4, true, MIX, SEG, CM>;
     }
 }
 
@@ -445,15 +535,19 @@ static uint32_t supported_cache_mask(bool mix, bool seg, uint32_t want) {
     return 0u;
 }
 
-static LitKernel pick_decode2(bool mix, bool seg, uint32_t cm, int mm, bool ctxc) {
+template <int W2>
+static LitKernel pick_decode2_w(bool mix, bool seg, uint32_t cm, int mm, bool ctxc) {
     if (mix) {
-        if (seg) return cm ? pick_decode2_cm<true, true, CM_HS | CM_HC>(mm, ctxc) : pick_decode2_cm<true, true, 0>(mm, ctxc);
-        if (cm == (uint32_t)(CM_HS | CM_HC | CM_LC)) return pick_decode2_cm<true, false, CM_HS | CM_HC | CM_LC>(mm, ctxc);
-        return cm ? pick_decode2_cm<true, false, CM_HS | CM_HC>(mm, ctxc) : pick_decode2_cm<true, false, 0>(mm, ctxc);
+        if (seg) return cm ? pick_decode2_cm<true, true, CM_HS | CM_HC | W2>(mm, ctxc) : pick_decode2_cm<true, true, 0>(mm, ctxc);
+        if (cm == (uint32_t)(CM_HS | CM_HC | CM_LC)) return pick_decode2_cm<true, false, CM_HS | CM_HC | CM_LC | W2>(mm, ctxc);
+        return cm ? pick_decode2_cm<true, false, CM_HS | CM_HC | W2>(mm, ctxc) : pick_decode2_cm<true, false, 0>(mm, ctxc);
     }
-    if (seg) return cm ? pick_decode2_cm<false, true, CM_HS>(mm, ctxc) : pick_decode2_cm<false, true, 0>(mm, ctxc);
-    if (cm == (uint32_t)(CM_HS | CM_LS)) return pick_decode2_cm<false, false, CM_HS | CM_LS>(mm, ctxc);
-    return cm ? pick_decode2_cm<false, false, CM_HS>(mm, ctxc) : pick_decode2_cm<false, false, 0>(mm, ctxc);
+    if (seg) return cm ? pick_decode2_cm<false, true, CM_HS | W2>(mm, ctxc) : pick_decode2_cm<false, true, 0>(mm, ctxc);
+    if (cm == (uint32_t)(CM_HS | CM_LS)) return pick_decode2_cm<false, false, CM_HS | CM_LS | W2>(mm, ctxc);
+    return cm ? pick_decode2_cm<false, false, CM_HS | W2>(mm, ctxc) : pick_decode2_cm<false, false, 0>(mm, ctxc);
+}
+static LitKernel pick_decode2(bool mix, bool seg, uint32_t cm, bool two_way, int mm, bool ctxc) {
+    return two_way ? pick_decode2_w<CM_2WAY>(mix, seg, cm, mm, ctxc) : pick_decode2_w<0>(mix, seg, cm, mm, ctxc);
 }
 
 static uint32_t wanted_cache_mask(uint32_t dm_log2) {
@@ -487,7 +581,7 @@ hipError_t launch_decode2(const LitBatch& b, bool mix, uint32_t blocks, hipStrea
     const int mm = (b.geom.mm_uniform == 0 || b.geom.mm_uniform == 4) ? b.geom.mm_uniform : -1;
     const uint32_t cm = wanted_cache_mask(b.dm_log2);
     if (cm != supported_cache_mask(mix, b.segs != nullptr, cm)) return hipErrorInvalidValue;   // the host passes lit_decode2_effective_caches()
-    LitKernel k = pick_decode2(mix, b.segs != nullptr, cm, mm, b.geom.ctx_const >= 0);
+    LitKernel k = pick_decode2(mix, b.segs != nullptr, cm, (b.dm_shift >> 31) != 0u, mm, b.geom.ctx_const >= 0);
     const uint32_t lds = lit_lds_bytes2(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);

@@ -19,6 +19,12 @@ def _rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _staged(t):
+    """gloo moves host memory only: device tensors are staged through the host (the 2-ranks-on-one-GPU test and any CPU-only
+    fabric); with RCCL the device tensors go out as they are."""
+    return t.is_cuda and _world() > 1 and dist.get_backend() == "gloo"
+
+
 def shard_bounds(n_streams, rank, world):
     """[begin, end) of the streams rank owns: contiguous, sizes differ by at most one, covers everything once."""
     base, extra = divmod(int(n_streams), int(world))
@@ -29,6 +35,8 @@ def shard_bounds(n_streams, rank, world):
 def max_over_ranks(seconds, device):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     if _world() > 1:
+        if _staged(t):
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -36,6 +44,8 @@ def max_over_ranks(seconds, device):
 def sum_over_ranks(values, device):
     t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
     if _world() > 1:
+        if _staged(t):
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(x) for x in t.tolist()]
 
@@ -46,8 +56,10 @@ def gather_stream_sizes(local_sizes, n_streams):
     if world == 1:
         return local_sizes.clone()
     longest = max(shard_bounds(n_streams, r, world)[1] - shard_bounds(n_streams, r, world)[0] for r in range(world))
-    pad = torch.zeros(longest, dtype=local_sizes.dtype, device=local_sizes.device)
-    pad[:local_sizes.numel()] = local_sizes
+    dev = local_sizes.device
+    wire = torch.device("cpu") if _staged(local_sizes) else dev
+    pad = torch.zeros(longest, dtype=local_sizes.dtype, device=wire)
+    pad[:local_sizes.numel()] = local_sizes.to(wire)
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     out = []
@@ -55,7 +67,7 @@ def gather_stream_sizes(local_sizes, n_streams):
         b, e = shard_bounds(n_streams, r, world)
         out.append(parts[r][:e - b])
     assert out[rank].numel() == local_sizes.numel()
-    return torch.cat(out)
+    return torch.cat(out).to(dev)
 
 
 MAX_MESSAGE_BYTES = 1 << 30   # a shard (4 GiB at BASELINE configs[1]) travels as several messages: no 32-bit count anywhere on the way
@@ -86,13 +98,17 @@ def scatter_streams(all_streams, n_streams, stream_len, device, dtype=torch.uint
         for r in range(1, world):
             rb, re = shard_bounds(n_streams, r, world)
             if re > rb:
-                ops.extend(dist.P2POp(dist.isend, piece, r) for piece in _pieces(all_streams[rb:re].contiguous()))
+                shard = all_streams[rb:re].contiguous()
+                if _staged(shard):
+                    shard = shard.cpu()
+                ops.extend(dist.P2POp(dist.isend, piece, r) for piece in _pieces(shard))
         _run_p2p(ops)
         return all_streams[b:e]
-    mine = torch.empty((e - b, stream_len), dtype=dtype, device=device)
+    staged = torch.device(device).type == "cuda" and dist.get_backend() == "gloo"
+    mine = torch.empty((e - b, stream_len), dtype=dtype, device="cpu" if staged else device)
     if e > b:
         _run_p2p([dist.P2POp(dist.irecv, piece, 0) for piece in _pieces(mine)])
-    return mine
+    return mine.to(device) if staged else mine
 
 
 def gather_coded(local_packed, local_sizes, n_streams):
@@ -113,18 +129,20 @@ def gather_coded(local_packed, local_sizes, n_streams):
     for r in range(world):
         rb, re = shard_bounds(n_streams, r, world)
         shard_bytes.append(int(al[rb:re].sum().item()))
+    staged = _staged(local_packed)
     if rank == 0:
-        blob = torch.empty(sum(shard_bytes), dtype=torch.uint8, device=local_packed.device)
-        blob[:shard_bytes[0]] = local_packed[:shard_bytes[0]]
+        blob = torch.empty(sum(shard_bytes), dtype=torch.uint8, device="cpu" if staged else local_packed.device)
+        blob[:shard_bytes[0]] = local_packed[:shard_bytes[0]].to(blob.device)
         ops, pos = [], shard_bytes[0]
         for r in range(1, world):
             if shard_bytes[r]:
                 ops.extend(dist.P2POp(dist.irecv, piece, r) for piece in _pieces(blob[pos:pos + shard_bytes[r]]))
             pos += shard_bytes[r]
         _run_p2p(ops)
-        return blob, offs, sizes
+        return (blob.to(local_packed.device) if staged else blob), offs, sizes
     if shard_bytes[rank]:
-        _run_p2p([dist.P2POp(dist.isend, piece, 0) for piece in _pieces(local_packed[:shard_bytes[rank]].contiguous())])
+        mine = local_packed[:shard_bytes[rank]].contiguous()
+        _run_p2p([dist.P2POp(dist.isend, piece, 0) for piece in _pieces(mine.cpu() if staged else mine)])
     return None, None, sizes
 
 

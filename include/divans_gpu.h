@@ -193,8 +193,8 @@ int divans_gpu_codec_set_encode_path(divans_gpu_codec *c, uint32_t path);
  * per 64 KiB stream -- fit the device).  A tuning / test knob: the coded bytes do not depend on it. */
 int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
 
-/* Tuning: which decode kernel runs -- generation 2 (default: direct-mapped LDS row caches, coded words through an LDS ring;
- * lit_decode2.hip) or 1 (2-way caches, lit_kernels.hip) -- and for generation 2 the rows of its four per-stream caches
+/* Tuning: which decode kernel runs -- generation 2 / 3 (lit_decode2.hip: LDS row caches read in one round trip, direct mapped (2)
+ * or 2-way (3), coded words through an LDS ring) or 1 (lit_kernels.hip) -- and for generations 2 / 3 the rows of the four per-stream caches
  * {high stride rows, high context-map rows, low stride rows, low context-map rows} (0 = not cached, else a power of two in
  * [4, 256]), their hash shifts (set = (row ^ (row >> shift)) & (rows - 1)) and the persistent grid (0 = keep; clamped to
  * what the LDS holds).  rows / shifts may be NULL to keep the current ones.  Both generations produce the same bytes. */

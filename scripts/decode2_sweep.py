@@ -56,7 +56,8 @@ def main():
             print(f"{label}: FAILED {e}", flush=True)
 
     run("gen1 default", lambda c: c.set_decoder(1))
-    run("gen2 default", lambda c: c.set_decoder(2))
+    run("gen2 default (direct mapped)", lambda c: c.set_decoder(2))
+    run("gen3 default (2-way)", lambda c: c.set_decoder(3))
     if args.geoms:
         geoms = [tuple(int(x) for x in g.split(":")) for g in args.geoms.split(",")]
     elif args.config == "simple":
@@ -69,7 +70,8 @@ def main():
                  (16, 16, 16, 16, 5, 5, 5, 5, 4), (0, 0, 0, 0, 5, 5, 5, 5, 7)]
     for g in geoms:
         rows, shifts, wpc = g[0:4], g[4:8], g[8]
-        run(f"gen2 rows {rows} shifts {shifts} wg/cu {wpc}", lambda c: c.set_decoder(2, rows, shifts, blocks=cus * wpc))
+        gen = g[9] if len(g) > 9 else 2
+        run(f"gen{gen} rows {rows} shifts {shifts} wg/cu {wpc}", lambda c: c.set_decoder(gen, rows, shifts, blocks=cus * wpc))
 
 
 if __name__ == "__main__":
