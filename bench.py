@@ -257,8 +257,6 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
         codec.set_geometry(blocks=max(1, int(cus * args.blocks_per_cu)))
     if args.cache_rows >= 0:
         codec.set_geometry(cache_rows=args.cache_rows)
-    if args.lanes:
-        codec.set_lane_layout(args.lanes)
     if args.encode_path:
         codec.set_encode_path(args.encode_path)
     if args.split_cache:
@@ -363,7 +361,6 @@ def main():
     ap.add_argument("--check-streams", type=int, default=4096, help="streams whose coded bytes are compared with the oracle before timing")
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per stream, 8 or 16 (tuning)")
     ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
     ap.add_argument("--host-data", action="store_true", help="build the input with tests/workload.py on the host instead of on the GPU (same bytes; "

@@ -119,7 +119,6 @@ def load_library():
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_decoder.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]
     L.divans_gpu_codec_set_decoder.restype = ctypes.c_int
-    L.divans_gpu_codec_set_lane_layout.argtypes = [vp, u32]
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
     L.divans_gpu_codec_set_bucket_batch.argtypes = [vp, u32]
     L.divans_gpu_lit_encode_host_pipelined.argtypes = [vp, vp, u32, u32, vp, ctypes.c_size_t, vp, vp, ctypes.POINTER(ctypes.c_size_t), u32]
@@ -165,8 +164,8 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_lane_layout", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
-        "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_block_types",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
+        "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
         "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
@@ -320,9 +319,6 @@ class LiteralCodec:
     def set_bucket_batch(self, streams):
         """streams per launch sequence of the bucketed two-model pass (tuning / test knob)"""
         _check(self._lib.divans_gpu_codec_set_bucket_batch(self._h, int(streams)), "set_bucket_batch")
-
-    def set_lane_layout(self, lanes_per_stream):
-        _check(self._lib.divans_gpu_codec_set_lane_layout(self._h, int(lanes_per_stream)), "set_lane_layout")
 
     def set_decoder(self, generation=2, rows=None, shifts=None, blocks=0):
         """Decode kernel generation (2 = lit_decode2.hip, 1 = lit_kernels.hip) and, for generation 2, the rows / hash shifts of its

@@ -1,6 +1,12 @@
 // batch.cpp -- many complete .divans streams per call (include/divans_batch.h): the LIT coder of every stream on the GPU,
 // the CMD coders and the framing on host threads, the two overlapped (the reference overlaps
 // the same halves of ONE stream with a worker thread, src/parallel_decompressor.rs:55-141, src/threading.rs:88-100).
+//
+// Both directions run as a pipeline of SLICES over a few lanes (lane = HIP stream + codecs + page-locked staging buffers):
+// while the GPU codes the slices that are in flight, the host threads stage the next one and assemble / copy out the one
+// that has just finished.  Streams are binned into LENGTH CLASSES first (<= 64 KiB, then powers of two): device memory is
+// sized per slice from the class bound, so one long stream among many short ones costs its own slice and nothing else, and
+// the <= 64 KiB class keeps the bucketed encoder passes.
 #include "../../include/divans_batch.h"
 
 #include <hip/hip_runtime.h>
@@ -46,22 +52,124 @@ void parallel_for(size_t n, int threads, F&& body) {
     for (auto& t : pool) t.join();
 }
 
+// grow-only buffers: a lane reuses them from slice to slice
 struct DeviceBuf {
-    void* p = nullptr;
+    void* p = nullptr; size_t cap = 0;
     ~DeviceBuf() { if (p) (void)hipFree(p); }
     template <typename T> T* as() const { return (T*)p; }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
 };
 struct PinnedBuf {
-    void* p = nullptr;
+    void* p = nullptr; size_t cap = 0;
     ~PinnedBuf() { if (p) (void)hipHostFree(p); }
     template <typename T> T* as() const { return (T*)p; }
-    hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault); }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
 };
-struct StreamGuard { hipStream_t s = nullptr; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } };
-struct CodecGuard { divans_gpu_codec* c = nullptr; ~CodecGuard() { if (c) divans_gpu_codec_destroy(c); } };
 
 #define HIP_OR_FAIL(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_last_error(DIVANS_GPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ---- length classes and slices ---------------------------------------------------------------------------------------
+// class bound of a stream length: 65536 for everything up to 64 KiB (one codec with the bucketed encoder passes), then the
+// next power of two
+uint32_t class_bound(size_t len) {
+    uint32_t b = 65536u;
+    while ((size_t)b < len) b <<= 1;
+    return b;
+}
+struct Slice { uint32_t bound = 0; std::vector<size_t> members; size_t bytes = 0; };
+
+// device bytes one stream of a class costs the codec and this file (slots, packed copy, start/freq spill, bucket arrays of the
+// two-model pass: DESIGN.md section 2), rounded up
+size_t device_bytes_per_stream(uint32_t bound) { return (size_t)bound * 64u + (1u << 16); }
+
+constexpr int kLanes = 3;
+
+// Streams of one class go into slices of about a quarter of the class (at least 512, at most 8192 streams, never more than the
+// device budget allows): enough slices to pipeline, few enough that each still fills a good part of the GPU.
+void make_slices(const std::vector<size_t>& order, const std::vector<uint32_t>& bound_of, const size_t* sizes, size_t budget_bytes,
+                 std::vector<Slice>& slices) {
+    size_t i = 0;
+    while (i < order.size()) {
+        const uint32_t bound = bound_of[order[i]];
+        size_t j = i;
+        while (j < order.size() && bound_of[order[j]] == bound) ++j;
+        const size_t n_class = j - i;
+        size_t per = std::min<size_t>(8192, std::max<size_t>(512, (n_class + 3) / 4));
+        per = std::max<size_t>(1, std::min(per, budget_bytes / device_bytes_per_stream(bound)));
+        for (size_t b = i; b < j; b += per) {
+            Slice s; s.bound = bound;
+            for (size_t k = b; k < std::min(j, b + per); ++k) { s.members.push_back(order[k]); s.bytes += sizes[order[k]]; }
+            slices.push_back(std::move(s));
+        }
+        i = j;
+    }
+}
+
+size_t device_budget() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)8 << 30;
+    return std::max<size_t>((size_t)1 << 30, free_b / (2 * kLanes));    // per lane, half of what is free in all
+}
+
+struct CodecKey {
+    divans_lit_config cfg; uint32_t bound;
+    bool operator<(const CodecKey& o) const { const int c = std::memcmp(&cfg, &o.cfg, sizeof(cfg)); return c != 0 ? c < 0 : bound < o.bound; }
+};
+
+struct Lane {
+    hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    std::map<CodecKey, divans_gpu_codec*> codecs;
+    PinnedBuf h_in, h_off, h_sz, h_ooff, h_osz, h_out, h_chunks, h_total, h_flags;
+    DeviceBuf d_in, d_off, d_sz, d_slots, d_ooff, d_osz, d_packed, d_poff, d_total, d_chunks, d_out, d_flags;
+    long slice = -1;                 // slice in flight on this lane
+    ~Lane() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto& kv : codecs) divans_gpu_codec_destroy(kv.second);
+        if (done) (void)hipEventDestroy(done);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int init() {
+        HIP_OR_FAIL(hipStreamCreate(&stream));
+        HIP_OR_FAIL(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        return 0;
+    }
+    int codec_for(const divans_lit_config& cfg, uint32_t bound, int device, size_t n_streams, divans_gpu_codec** out) {
+        CodecKey key; key.cfg = cfg; key.bound = bound;
+        auto it = codecs.find(key);
+        if (it == codecs.end()) {
+            divans_gpu_codec* c = nullptr;
+            const int rc = divans_gpu_codec_create(&c, &cfg, device, stream, bound);
+            if (rc) return rc;
+            it = codecs.emplace(key, c).first;
+        }
+        // a small slice does not need the full persistent grid's worth of CDF tables
+        divans_gpu_info info;
+        if (divans_gpu_codec_info(it->second, &info) == 0 && info.blocks > (n_streams + 15) / 16)
+            (void)divans_gpu_codec_set_geometry(it->second, (uint32_t)std::max<size_t>(1, (n_streams + 15) / 16), 0xffffffffu);
+        *out = it->second;
+        return 0;
+    }
+};
+
+// wall-clock bookkeeping of the overlap: host work counts as overlapped while at least one slice is in flight on the GPU
+struct Overlap {
+    int in_flight = 0; double overlapped = 0, serial = 0, gpu_first = -1, gpu_last = 0;
+    void host(double t0, double t1) { (in_flight > 0 ? overlapped : serial) += t1 - t0; }
+};
 
 }  // namespace
 
@@ -88,99 +196,148 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     if (n_streams >= (1u << 24)) return set_last_error(DIVANS_GPU_EINVAL, "too many streams in one batch");
     const double t_begin = now_ms();
     const divans_host::StreamOptions so = to_stream_options(*opt);
-    size_t longest = 0, total_in = 0;
+    std::vector<uint32_t> bound_of(n_streams);
     for (size_t i = 0; i < n_streams; ++i) {
         if (sizes[i] > 0x7fffffffu) return set_last_error(DIVANS_GPU_EINVAL, "stream too long");
-        longest = std::max(longest, sizes[i]); total_in += sizes[i];
+        bound_of[i] = class_bound(sizes[i]);
     }
     // the LIT configuration follows from the options alone (the PredictionMode of the internal compressor)
     divans_host::StreamPlan probe;
     int rc = divans_host::plan_stream(so, 0, nullptr, probe);
     if (rc) return set_last_error(rc, "options cannot be coded");
     HIP_OR_FAIL(hipSetDevice(opt->device));
-    StreamGuard stream; HIP_OR_FAIL(hipStreamCreate(&stream.s));
-    CodecGuard codec;
-    const uint32_t max_len = (uint32_t)std::max<size_t>(longest, 16);
-    rc = divans_gpu_codec_create(&codec.c, &probe.cfg, opt->device, stream.s, max_len);
-    if (rc) return rc;
-    {   // a small batch does not need the full persistent grid's worth of CDF tables
-        divans_gpu_info info;
-        if (divans_gpu_codec_info(codec.c, &info) == 0) (void)divans_gpu_codec_set_geometry(codec.c, std::max<uint32_t>(1, std::min<uint32_t>(info.blocks, (uint32_t)((n_streams + 15) / 16))), 0xffffffffu);
-    }
-    const uint32_t max_chunks = (uint32_t)std::max<uint64_t>(1, (2ull * max_len + 65535ull) / 65536ull);
-    const uint64_t slot = divans_gpu_lit_encode_bound(max_len);
-    // ---- GPU half: enqueue everything, no host synchronisation until the CMD coders are done -------------------------
-    const double t_gpu0 = now_ms();
-    PinnedBuf h_in, h_off, h_sz, h_packed, h_poff, h_psz, h_chunks, h_total;
-    DeviceBuf d_in, d_off, d_sz, d_slots, d_ooff, d_osz, d_packed, d_poff, d_total, d_chunks;
-    HIP_OR_FAIL(h_in.alloc(total_in + 64)); HIP_OR_FAIL(h_off.alloc(8 * n_streams)); HIP_OR_FAIL(h_sz.alloc(4 * n_streams));
-    HIP_OR_FAIL(h_poff.alloc(8 * n_streams)); HIP_OR_FAIL(h_psz.alloc(4 * n_streams)); HIP_OR_FAIL(h_total.alloc(8));
-    HIP_OR_FAIL(h_chunks.alloc(4ull * n_streams * max_chunks));
-    {
-        uint64_t* off = h_off.as<uint64_t>(); uint32_t* sz = h_sz.as<uint32_t>(); uint8_t* dst = h_in.as<uint8_t>();
-        uint64_t pos = 0;
-        for (size_t i = 0; i < n_streams; ++i) { off[i] = pos; sz[i] = (uint32_t)sizes[i]; pos += sizes[i]; }
-        parallel_for(n_streams, opt->host_threads, [&](size_t i) { if (sizes[i]) std::memcpy(dst + off[i], inputs[i], sizes[i]); });
-    }
-    HIP_OR_FAIL(d_in.alloc(total_in + 64)); HIP_OR_FAIL(d_off.alloc(8 * n_streams)); HIP_OR_FAIL(d_sz.alloc(4 * n_streams));
-    HIP_OR_FAIL(d_slots.alloc(slot * n_streams + 64)); HIP_OR_FAIL(d_ooff.alloc(8 * n_streams)); HIP_OR_FAIL(d_osz.alloc(4 * n_streams));
-    HIP_OR_FAIL(d_packed.alloc(slot * n_streams + 64)); HIP_OR_FAIL(d_poff.alloc(8 * n_streams)); HIP_OR_FAIL(d_total.alloc(8));
-    HIP_OR_FAIL(d_chunks.alloc(4ull * n_streams * max_chunks));
-    HIP_OR_FAIL(hipMemcpyAsync(d_in.p, h_in.p, total_in, hipMemcpyHostToDevice, stream.s));
-    HIP_OR_FAIL(hipMemcpyAsync(d_off.p, h_off.p, 8 * n_streams, hipMemcpyHostToDevice, stream.s));
-    HIP_OR_FAIL(hipMemcpyAsync(d_sz.p, h_sz.p, 4 * n_streams, hipMemcpyHostToDevice, stream.s));
-    HIP_OR_FAIL(hipMemsetAsync(d_chunks.p, 0, 4ull * n_streams * max_chunks, stream.s));
-    rc = divans_gpu_lit_encode_batch_chunks(codec.c, d_in.as<uint8_t>(), d_off.as<uint64_t>(), d_sz.as<uint32_t>(), max_len, (uint32_t)n_streams,
-                                            d_slots.as<uint8_t>(), slot, d_ooff.as<uint64_t>(), d_osz.as<uint32_t>(), d_chunks.as<uint32_t>(), max_chunks);
-    if (rc) return rc;
-    rc = divans_gpu_pack_streams(codec.c, d_slots.as<uint8_t>(), d_ooff.as<uint64_t>(), d_osz.as<uint32_t>(), (uint32_t)n_streams,
-                                 d_packed.as<uint8_t>(), d_poff.as<uint64_t>(), d_total.as<uint64_t>());
-    if (rc) return rc;
-    HIP_OR_FAIL(hipMemcpyAsync(h_poff.p, d_poff.p, 8 * n_streams, hipMemcpyDeviceToHost, stream.s));
-    HIP_OR_FAIL(hipMemcpyAsync(h_psz.p, d_osz.p, 4 * n_streams, hipMemcpyDeviceToHost, stream.s));
-    HIP_OR_FAIL(hipMemcpyAsync(h_chunks.p, d_chunks.p, 4ull * n_streams * max_chunks, hipMemcpyDeviceToHost, stream.s));
-    HIP_OR_FAIL(hipMemcpyAsync(h_total.p, d_total.p, 8, hipMemcpyDeviceToHost, stream.s));
-    // ---- host half, overlapped: the CMD coder of every stream (it sees lengths and options only, never the data) --------
-    const double t_host0 = now_ms();
+    std::vector<size_t> order(n_streams);
+    for (size_t i = 0; i < n_streams; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bound_of[a] < bound_of[b]; });
+    std::vector<Slice> slices;
+    make_slices(order, bound_of, sizes, device_budget(), slices);
+    Lane lanes[kLanes];
+    for (auto& l : lanes) { rc = l.init(); if (rc) return rc; }
+    Overlap ov;
+
+    // the CMD coder of every stream sees lengths and options only: one plan per distinct length, made while the first slices run
     std::map<size_t, std::unique_ptr<divans_host::StreamPlan>> plans;
     for (size_t i = 0; i < n_streams; ++i) plans.emplace(sizes[i], nullptr);
-    std::vector<size_t> distinct; for (auto& kv : plans) distinct.push_back(kv.first);
+    std::vector<std::unique_ptr<divans_host::StreamPlan>*> plan_slots; std::vector<size_t> plan_len;
+    for (auto& kv : plans) { plan_slots.push_back(&kv.second); plan_len.push_back(kv.first); }
     std::atomic<int> plan_rc{0};
-    parallel_for(distinct.size(), opt->host_threads, [&](size_t k) {
-        auto p = std::make_unique<divans_host::StreamPlan>();
-        const int r = divans_host::plan_stream(so, distinct[k], nullptr, *p);
-        if (r) plan_rc = r;
-        plans[distinct[k]] = std::move(p);     // the map's nodes exist already: no rebalancing, distinct keys per thread
-    });
-    const double t_host1 = now_ms();
-    if (plan_rc) return set_last_error(plan_rc, "a stream's command stream cannot be coded");
-    // ---- join --------------------------------------------------------------------------------------------------------
-    HIP_OR_FAIL(hipStreamSynchronize(stream.s));
-    uint32_t status = 0;
-    if (divans_gpu_codec_status(codec.c, &status) || status) return set_last_error(DIVANS_GPU_EINVAL, "the literal coder reported an invalid model state");
-    const uint64_t packed_total = *h_total.as<uint64_t>();
-    HIP_OR_FAIL(h_packed.alloc(packed_total + 64));
-    HIP_OR_FAIL(hipMemcpy(h_packed.p, d_packed.p, packed_total, hipMemcpyDeviceToHost));
-    const double t_gpu1 = now_ms();
-    // ---- framing: Mux replay, EOF marker, CRC trailer per stream ---------------------------------------------------------
+    bool plans_done = false;
+    auto make_plans = [&]() {
+        const double t0 = now_ms();
+        parallel_for(plan_slots.size(), opt->host_threads, [&](size_t k) {
+            auto p = std::make_unique<divans_host::StreamPlan>();
+            const int r = divans_host::plan_stream(so, plan_len[k], nullptr, *p);
+            if (r) plan_rc = r;
+            *plan_slots[k] = std::move(p);
+        });
+        plans_done = true;
+        ov.host(t0, now_ms());
+    };
+
+    auto issue = [&](size_t k) -> int {
+        Lane& L = lanes[k % kLanes];
+        const Slice& s = slices[k];
+        const size_t m = s.members.size();
+        const uint32_t max_chunks = (uint32_t)std::max<uint64_t>(1, (2ull * s.bound + 65535ull) / 65536ull);
+        const uint64_t slot = divans_gpu_lit_encode_bound(s.bound);
+        const double t0 = now_ms();
+        HIP_OR_FAIL(L.h_in.reserve(s.bytes + 64)); HIP_OR_FAIL(L.h_off.reserve(8 * m)); HIP_OR_FAIL(L.h_sz.reserve(4 * m));
+        HIP_OR_FAIL(L.h_ooff.reserve(8 * m)); HIP_OR_FAIL(L.h_osz.reserve(4 * m)); HIP_OR_FAIL(L.h_total.reserve(8));
+        HIP_OR_FAIL(L.h_chunks.reserve(4ull * m * max_chunks)); HIP_OR_FAIL(L.h_out.reserve(slot * m + 64));
+        HIP_OR_FAIL(L.d_in.reserve(s.bytes + 64)); HIP_OR_FAIL(L.d_off.reserve(8 * m)); HIP_OR_FAIL(L.d_sz.reserve(4 * m));
+        HIP_OR_FAIL(L.d_slots.reserve(slot * m + 64)); HIP_OR_FAIL(L.d_ooff.reserve(8 * m)); HIP_OR_FAIL(L.d_osz.reserve(4 * m));
+        HIP_OR_FAIL(L.d_packed.reserve(slot * m + 64)); HIP_OR_FAIL(L.d_poff.reserve(8 * m)); HIP_OR_FAIL(L.d_total.reserve(8));
+        HIP_OR_FAIL(L.d_chunks.reserve(4ull * m * max_chunks));
+        {
+            uint64_t* off = L.h_off.as<uint64_t>(); uint32_t* sz = L.h_sz.as<uint32_t>(); uint8_t* dst = L.h_in.as<uint8_t>();
+            uint64_t pos = 0;
+            for (size_t j = 0; j < m; ++j) { off[j] = pos; sz[j] = (uint32_t)sizes[s.members[j]]; pos += sizes[s.members[j]]; }
+            parallel_for(m, opt->host_threads, [&](size_t j) { if (sz[j]) std::memcpy(dst + off[j], inputs[s.members[j]], sz[j]); });
+        }
+        divans_gpu_codec* codec = nullptr;
+        int r = L.codec_for(probe.cfg, s.bound, opt->device, m, &codec); if (r) return r;
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_in.p, L.h_in.p, s.bytes, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_off.p, L.h_off.p, 8 * m, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_sz.p, L.h_sz.p, 4 * m, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemsetAsync(L.d_chunks.p, 0, 4ull * m * max_chunks, L.stream));
+        r = divans_gpu_lit_encode_batch_chunks(codec, L.d_in.as<uint8_t>(), L.d_off.as<uint64_t>(), L.d_sz.as<uint32_t>(), s.bound, (uint32_t)m,
+                                               L.d_slots.as<uint8_t>(), slot, L.d_ooff.as<uint64_t>(), L.d_osz.as<uint32_t>(), L.d_chunks.as<uint32_t>(), max_chunks);
+        if (r) return r;
+        r = divans_gpu_pack_streams(codec, L.d_slots.as<uint8_t>(), L.d_ooff.as<uint64_t>(), L.d_osz.as<uint32_t>(), (uint32_t)m,
+                                    L.d_packed.as<uint8_t>(), L.d_poff.as<uint64_t>(), L.d_total.as<uint64_t>());
+        if (r) return r;
+        // the packed streams are at most slot * m bytes, in practice about half the input: copy what a stream can be at most only
+        // when the slice is tiny, otherwise the first bytes that can hold the whole slice at the input's size (checked on completion)
+        HIP_OR_FAIL(hipMemcpyAsync(L.h_ooff.p, L.d_poff.p, 8 * m, hipMemcpyDeviceToHost, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.h_osz.p, L.d_osz.p, 4 * m, hipMemcpyDeviceToHost, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.h_chunks.p, L.d_chunks.p, 4ull * m * max_chunks, hipMemcpyDeviceToHost, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.h_total.p, L.d_total.p, 8, hipMemcpyDeviceToHost, L.stream));
+        const size_t guess = std::min<size_t>(slot * m, s.bytes + 64 * m + 4096);
+        HIP_OR_FAIL(hipMemcpyAsync(L.h_out.p, L.d_packed.p, guess, hipMemcpyDeviceToHost, L.stream));
+        HIP_OR_FAIL(hipEventRecord(L.done, L.stream));
+        L.slice = (long)k;
+        const double t1 = now_ms();
+        ov.host(t0, t1);
+        if (ov.gpu_first < 0) ov.gpu_first = t0;
+        ov.in_flight += 1;
+        return 0;
+    };
+
     std::vector<std::vector<uint8_t>> results(n_streams);
-    std::atomic<int> asm_rc{0};
     const size_t call_buffer = opt->call_buffer_size ? opt->call_buffer_size : 65536;
-    parallel_for(n_streams, opt->host_threads, [&](size_t i) {
-        const divans_host::StreamPlan& p = *plans[sizes[i]];
-        const int r = divans_host::assemble_container(p, h_packed.as<uint8_t>() + h_poff.as<uint64_t>()[i], h_psz.as<uint32_t>()[i],
-                                                      h_chunks.as<uint32_t>() + i * max_chunks, call_buffer, results[i]);
-        if (r) asm_rc = r;
-    });
-    if (asm_rc) return set_last_error(asm_rc, "container assembly failed");
+    auto complete = [&](size_t k) -> int {
+        Lane& L = lanes[k % kLanes];
+        const Slice& s = slices[k];
+        const size_t m = s.members.size();
+        const uint32_t max_chunks = (uint32_t)std::max<uint64_t>(1, (2ull * s.bound + 65535ull) / 65536ull);
+        HIP_OR_FAIL(hipEventSynchronize(L.done));
+        const uint64_t packed_total = *L.h_total.as<uint64_t>();
+        const size_t guess = std::min<size_t>(divans_gpu_lit_encode_bound(s.bound) * m, s.bytes + 64 * m + 4096);
+        if (packed_total > guess) {   // incompressible input: fetch the rest
+            HIP_OR_FAIL(hipMemcpyAsync(L.h_out.as<uint8_t>() + guess, L.d_packed.as<uint8_t>() + guess, packed_total - guess, hipMemcpyDeviceToHost, L.stream));
+            HIP_OR_FAIL(hipStreamSynchronize(L.stream));
+        }
+        ov.in_flight -= 1; ov.gpu_last = now_ms();
+        divans_gpu_codec* codec = nullptr;
+        int r = L.codec_for(probe.cfg, s.bound, opt->device, m, &codec); if (r) return r;
+        uint32_t status = 0;
+        if (divans_gpu_codec_status(codec, &status) || status) return set_last_error(DIVANS_GPU_EINVAL, "the literal coder reported an invalid model state");
+        if (!plans_done) make_plans();
+        if (plan_rc) return set_last_error(plan_rc, "a stream's command stream cannot be coded");
+        // framing: Mux replay, EOF marker, CRC trailer per stream
+        const double t0 = now_ms();
+        std::atomic<int> asm_rc{0};
+        parallel_for(m, opt->host_threads, [&](size_t j) {
+            const size_t i = s.members[j];
+            const divans_host::StreamPlan& p = *plans[sizes[i]];
+            const int rr = divans_host::assemble_container(p, L.h_out.as<uint8_t>() + L.h_ooff.as<uint64_t>()[j], L.h_osz.as<uint32_t>()[j],
+                                                           L.h_chunks.as<uint32_t>() + j * max_chunks, call_buffer, results[i]);
+            if (rr) asm_rc = rr;
+        });
+        ov.host(t0, now_ms());
+        L.slice = -1;
+        if (asm_rc) return set_last_error(asm_rc, "container assembly failed");
+        return 0;
+    };
+
+    // software pipeline: up to kLanes slices in flight; the plans are made under the first of them
+    const size_t ns = slices.size();
+    for (size_t k = 0; k < std::min<size_t>(ns, kLanes); ++k) { rc = issue(k); if (rc) return rc; }
+    if (!plans_done) make_plans();
+    for (size_t k = 0; k < ns; ++k) {
+        rc = complete(k); if (rc) return rc;
+        if (k + kLanes < ns) { rc = issue(k + kLanes); if (rc) return rc; }
+    }
+    const double t_out0 = now_ms();
     size_t pos = 0;
     for (size_t i = 0; i < n_streams; ++i) { out_offsets[i] = pos; out_sizes[i] = results[i].size(); pos += results[i].size(); }
     if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
     parallel_for(n_streams, opt->host_threads, [&](size_t i) { std::memcpy(out + out_offsets[i], results[i].data(), results[i].size()); });
     const double t_end = now_ms();
+    ov.host(t_out0, t_end);
     if (timing) {
-        timing->total_ms = t_end - t_begin; timing->gpu_ms = t_gpu1 - t_gpu0;
-        timing->host_overlapped_ms = t_host1 - t_host0; timing->host_serial_ms = t_end - t_gpu1;
+        timing->total_ms = t_end - t_begin; timing->gpu_ms = ov.gpu_last - ov.gpu_first;
+        timing->host_overlapped_ms = ov.overlapped; timing->host_serial_ms = ov.serial;
     }
     return 0;
 }
@@ -191,101 +348,145 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     if (n_streams == 0) return 0;
     const double t_begin = now_ms();
     HIP_OR_FAIL(hipSetDevice(opt->device));
-    StreamGuard stream; HIP_OR_FAIL(hipStreamCreate(&stream.s));
-    // Pipeline over slices of the batch: while the GPU decodes the LIT streams of slice k, host threads parse slice k + 1
-    // (framing, CRC, CMD coder -> decoded sizes and LIT configuration, which the GPU launch needs).
-    // a slice should still fill the persistent decode grid (28 672 streams on MI355X): small batches are one slice
-    const size_t n_slices = std::max<size_t>(1, std::min<size_t>(4, n_streams / 16384));
+    Lane lanes[kLanes];
+    int rc = 0;
+    for (auto& l : lanes) { rc = l.init(); if (rc) return rc; }
+    Overlap ov;
+    const size_t budget = device_budget();
+    // Slices in stream order (the output offsets are the running sum of the decoded sizes): about an eighth of the batch,
+    // 256 .. 8192 containers.  While the GPU decodes the slices in flight, host threads parse the next one (framing, CRC,
+    // CMD coder -> decoded sizes and LIT configuration, which the launch needs) and copy out the one that has finished.
+    const size_t per = std::min<size_t>(8192, std::max<size_t>(256, (n_streams + 7) / 8));
+    const size_t ns = (n_streams + per - 1) / per;
     std::vector<divans_host::ParsedStream> parsed(n_streams);
     std::vector<int> status(n_streams, 0);
-    double host_overlapped = 0, host_serial = 0, gpu_ms = 0;
-    auto parse_slice = [&](size_t k) {
-        const size_t b = k * n_streams / n_slices, e = (k + 1) * n_streams / n_slices;
+    size_t pos = 0;
+
+    struct Group { divans_lit_config cfg; uint32_t bound; std::vector<size_t> members; size_t in_bytes = 0, out_bytes = 0, in_base = 0, out_base = 0, idx_base = 0; };
+    std::vector<std::vector<Group>> slice_groups(ns);
+
+    auto parse = [&](size_t k) -> int {
+        const size_t b = k * per, e = std::min(n_streams, b + per);
+        const double t0 = now_ms();
         parallel_for(e - b, opt->host_threads, [&](size_t j) {
             const size_t i = b + j;
             status[i] = (int)divans_host::parse_container_host(containers[i], sizes[i], opt->skip_crc != 0, (size_t)1 << 30, parsed[i], nullptr);
         });
-    };
-    struct Group {
-        divans_lit_config cfg; std::vector<size_t> members;
-        CodecGuard codec; PinnedBuf h_in, h_off, h_sz, h_ooff, h_osz, h_out; DeviceBuf d_in, d_off, d_sz, d_ooff, d_osz, d_out;
-        size_t out_bytes = 0;
-    };
-    size_t pos = 0;
-    double t0 = now_ms();
-    parse_slice(0);
-    host_serial += now_ms() - t0;
-    for (size_t k = 0; k < n_slices; ++k) {
-        const size_t b = k * n_streams / n_slices, e = (k + 1) * n_streams / n_slices;
+        ov.host(t0, now_ms());
         for (size_t i = b; i < e; ++i)
             if (status[i] != divans_host::PARSE_OK) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ECORRUPT, "container " + std::to_string(i) + " is truncated, corrupt or not a literal-only stream"); }
-        // group the slice by LIT configuration (one codec = one configuration)
-        std::vector<std::unique_ptr<Group>> groups;
+        return 0;
+    };
+
+    auto issue = [&](size_t k) -> int {
+        Lane& L = lanes[k % kLanes];
+        const size_t b = k * per, e = std::min(n_streams, b + per);
+        const double t0 = now_ms();
+        // group the slice by LIT configuration and length class (one codec = one configuration and one table / scratch size)
+        std::vector<Group>& groups = slice_groups[k];
         for (size_t i = b; i < e; ++i) {
             out_offsets[i] = pos; out_sizes[i] = parsed[i].total; pos += parsed[i].total;
             if (parsed[i].total == 0) continue;
+            const uint32_t bound = class_bound(parsed[i].total);
             Group* g = nullptr;
-            for (auto& q : groups) if (std::memcmp(&q->cfg, &parsed[i].cfg, sizeof(divans_lit_config)) == 0) { g = q.get(); break; }
-            if (!g) { groups.emplace_back(new Group()); g = groups.back().get(); g->cfg = parsed[i].cfg; }
-            g->members.push_back(i);
+            for (auto& q : groups) if (q.bound == bound && std::memcmp(&q.cfg, &parsed[i].cfg, sizeof(divans_lit_config)) == 0) { g = &q; break; }
+            if (!g) { groups.emplace_back(); g = &groups.back(); g->cfg = parsed[i].cfg; g->bound = bound; }
+            g->members.push_back(i); g->in_bytes += parsed[i].lit.size(); g->out_bytes += parsed[i].total;
         }
         if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
-        const double tg0 = now_ms();
-        for (auto& gp : groups) {
-            Group& g = *gp;
-            const size_t m = g.members.size();
-            size_t in_bytes = 0, longest = 0; g.out_bytes = 0;
-            for (size_t i : g.members) { in_bytes += parsed[i].lit.size(); g.out_bytes += parsed[i].total; longest = std::max(longest, parsed[i].total); }
-            HIP_OR_FAIL(g.h_in.alloc(in_bytes + 64)); HIP_OR_FAIL(g.h_off.alloc(8 * m)); HIP_OR_FAIL(g.h_sz.alloc(4 * m));
-            HIP_OR_FAIL(g.h_ooff.alloc(8 * m)); HIP_OR_FAIL(g.h_osz.alloc(4 * m)); HIP_OR_FAIL(g.h_out.alloc(g.out_bytes + 64));
-            HIP_OR_FAIL(g.d_in.alloc(in_bytes + 128)); HIP_OR_FAIL(g.d_off.alloc(8 * m)); HIP_OR_FAIL(g.d_sz.alloc(4 * m));
-            HIP_OR_FAIL(g.d_ooff.alloc(8 * m)); HIP_OR_FAIL(g.d_osz.alloc(4 * m)); HIP_OR_FAIL(g.d_out.alloc(g.out_bytes + 64));
+        size_t in_total = 0, out_total = 0, m_total = 0;
+        for (auto& g : groups) {
+            if (device_bytes_per_stream(g.bound) * g.members.size() > budget * 2)
+                return set_last_error(DIVANS_GPU_ENOMEM, "a slice of the batch does not fit the device: split the call");
+            g.in_base = in_total; g.out_base = out_total; g.idx_base = m_total;
+            in_total += (g.in_bytes + 127) & ~(size_t)63; out_total += (g.out_bytes + 63) & ~(size_t)63; m_total += g.members.size();
+        }
+        HIP_OR_FAIL(L.h_in.reserve(in_total + 128)); HIP_OR_FAIL(L.h_off.reserve(8 * m_total)); HIP_OR_FAIL(L.h_sz.reserve(4 * m_total));
+        HIP_OR_FAIL(L.h_ooff.reserve(8 * m_total)); HIP_OR_FAIL(L.h_osz.reserve(4 * m_total)); HIP_OR_FAIL(L.h_out.reserve(out_total + 64));
+        HIP_OR_FAIL(L.h_flags.reserve(m_total + 64));
+        HIP_OR_FAIL(L.d_in.reserve(in_total + 128)); HIP_OR_FAIL(L.d_off.reserve(8 * m_total)); HIP_OR_FAIL(L.d_sz.reserve(4 * m_total));
+        HIP_OR_FAIL(L.d_ooff.reserve(8 * m_total)); HIP_OR_FAIL(L.d_osz.reserve(4 * m_total)); HIP_OR_FAIL(L.d_out.reserve(out_total + 64));
+        HIP_OR_FAIL(L.d_flags.reserve(m_total + 64));
+        std::memset(L.h_in.p, 0, in_total + 128);     // the kernels read whole words past a stream's last byte
+        for (auto& g : groups) {
             uint64_t ip = 0, op = 0;
-            for (size_t j = 0; j < m; ++j) {
+            std::vector<uint64_t> ioff(g.members.size());
+            for (size_t j = 0; j < g.members.size(); ++j) {
                 const divans_host::ParsedStream& ps = parsed[g.members[j]];
-                g.h_off.as<uint64_t>()[j] = ip; g.h_sz.as<uint32_t>()[j] = (uint32_t)ps.lit.size();
-                g.h_ooff.as<uint64_t>()[j] = op; g.h_osz.as<uint32_t>()[j] = (uint32_t)ps.total;
-                std::memcpy(g.h_in.as<uint8_t>() + ip, ps.lit.data(), ps.lit.size());
+                ioff[j] = ip;
+                L.h_off.as<uint64_t>()[g.idx_base + j] = ip; L.h_sz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.lit.size();
+                L.h_ooff.as<uint64_t>()[g.idx_base + j] = op; L.h_osz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.total;
                 ip += ps.lit.size(); op += ps.total;
             }
-            int rc = divans_gpu_codec_create(&g.codec.c, &g.cfg, opt->device, stream.s, (uint32_t)std::max<size_t>(longest, 16));
-            if (rc) return rc;
-            {
-                divans_gpu_info info;
-                if (divans_gpu_codec_info(g.codec.c, &info) == 0) (void)divans_gpu_codec_set_geometry(g.codec.c, std::max<uint32_t>(1, std::min<uint32_t>(info.blocks, (uint32_t)((m + 15) / 16))), 0xffffffffu);
-            }
-            HIP_OR_FAIL(hipMemsetAsync(g.d_in.as<uint8_t>() + in_bytes, 0, 64, stream.s));
-            HIP_OR_FAIL(hipMemcpyAsync(g.d_in.p, g.h_in.p, in_bytes, hipMemcpyHostToDevice, stream.s));
-            HIP_OR_FAIL(hipMemcpyAsync(g.d_off.p, g.h_off.p, 8 * m, hipMemcpyHostToDevice, stream.s));
-            HIP_OR_FAIL(hipMemcpyAsync(g.d_sz.p, g.h_sz.p, 4 * m, hipMemcpyHostToDevice, stream.s));
-            HIP_OR_FAIL(hipMemcpyAsync(g.d_ooff.p, g.h_ooff.p, 8 * m, hipMemcpyHostToDevice, stream.s));
-            HIP_OR_FAIL(hipMemcpyAsync(g.d_osz.p, g.h_osz.p, 4 * m, hipMemcpyHostToDevice, stream.s));
-            rc = divans_gpu_lit_decode_batch(g.codec.c, g.d_in.as<uint8_t>(), g.d_off.as<uint64_t>(), g.d_sz.as<uint32_t>(), (uint32_t)m,
-                                             g.d_out.as<uint8_t>(), g.d_ooff.as<uint64_t>(), g.d_osz.as<uint32_t>(), (uint32_t)std::max<size_t>(longest, 16));
-            if (rc) return rc;
-            HIP_OR_FAIL(hipMemcpyAsync(g.h_out.p, g.d_out.p, g.out_bytes, hipMemcpyDeviceToHost, stream.s));
+            parallel_for(g.members.size(), opt->host_threads, [&](size_t j) {
+                const divans_host::ParsedStream& ps = parsed[g.members[j]];
+                std::memcpy(L.h_in.as<uint8_t>() + g.in_base + ioff[j], ps.lit.data(), ps.lit.size());
+            });
         }
-        // overlapped host work: the next slice's containers
-        const double th0 = now_ms();
-        if (k + 1 < n_slices) parse_slice(k + 1);
-        host_overlapped += now_ms() - th0;
-        HIP_OR_FAIL(hipStreamSynchronize(stream.s));
-        gpu_ms += now_ms() - tg0;
-        const double ts0 = now_ms();
-        for (auto& gp : groups) {
-            Group& g = *gp;
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_in.p, L.h_in.p, in_total + 128, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_off.p, L.h_off.p, 8 * m_total, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_sz.p, L.h_sz.p, 4 * m_total, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_ooff.p, L.h_ooff.p, 8 * m_total, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.d_osz.p, L.h_osz.p, 4 * m_total, hipMemcpyHostToDevice, L.stream));
+        HIP_OR_FAIL(hipMemsetAsync(L.d_flags.p, 0, m_total + 64, L.stream));
+        for (auto& g : groups) {
+            divans_gpu_codec* codec = nullptr;
+            int r = L.codec_for(g.cfg, g.bound, opt->device, g.members.size(), &codec); if (r) return r;
+            r = divans_gpu_codec_set_stream_flags(codec, L.d_flags.as<uint8_t>() + g.idx_base); if (r) return r;
+            r = divans_gpu_lit_decode_batch(codec, L.d_in.as<uint8_t>() + g.in_base, L.d_off.as<uint64_t>() + g.idx_base, L.d_sz.as<uint32_t>() + g.idx_base,
+                                            (uint32_t)g.members.size(), L.d_out.as<uint8_t>() + g.out_base, L.d_ooff.as<uint64_t>() + g.idx_base,
+                                            L.d_osz.as<uint32_t>() + g.idx_base, g.bound);
+            if (r) return r;
+        }
+        HIP_OR_FAIL(hipMemcpyAsync(L.h_out.p, L.d_out.p, out_total, hipMemcpyDeviceToHost, L.stream));
+        HIP_OR_FAIL(hipMemcpyAsync(L.h_flags.p, L.d_flags.p, m_total, hipMemcpyDeviceToHost, L.stream));
+        HIP_OR_FAIL(hipEventRecord(L.done, L.stream));
+        const double t1 = now_ms();
+        ov.host(t0, t1);
+        if (ov.gpu_first < 0) ov.gpu_first = t0;
+        ov.in_flight += 1;
+        return 0;
+    };
+
+    auto complete = [&](size_t k) -> int {
+        Lane& L = lanes[k % kLanes];
+        const size_t b = k * per, e = std::min(n_streams, b + per);
+        HIP_OR_FAIL(hipEventSynchronize(L.done));
+        ov.in_flight -= 1; ov.gpu_last = now_ms();
+        const double t0 = now_ms();
+        std::vector<Group>& groups = slice_groups[k];
+        for (auto& g : groups) {
+            divans_gpu_codec* codec = nullptr;
+            int r = L.codec_for(g.cfg, g.bound, opt->device, g.members.size(), &codec); if (r) return r;
             uint32_t st = 0;
-            if (divans_gpu_codec_status(g.codec.c, &st)) return DIVANS_GPU_EHIP;
-            if (st & DIVANS_GPU_STATUS_BAD_STREAM) return set_last_error(DIVANS_GPU_ECORRUPT, "a LIT stream failed the decoder's integrity check");
+            if (divans_gpu_codec_status(codec, &st)) return DIVANS_GPU_EHIP;
+            if (st & DIVANS_GPU_STATUS_BAD_STREAM) {
+                size_t first = g.members.front();
+                for (size_t j = 0; j < g.members.size(); ++j) if (L.h_flags.as<uint8_t>()[g.idx_base + j]) { first = g.members[j]; out_sizes[first] = (size_t)-1; break; }
+                return set_last_error(DIVANS_GPU_ECORRUPT, "the LIT stream of container " + std::to_string(first) + " failed the decoder's integrity check");
+            }
             parallel_for(g.members.size(), opt->host_threads, [&](size_t j) {
                 const size_t i = g.members[j];
-                std::memcpy(out + out_offsets[i], g.h_out.as<uint8_t>() + g.h_ooff.as<uint64_t>()[j], parsed[i].total);
+                std::memcpy(out + out_offsets[i], L.h_out.as<uint8_t>() + g.out_base + L.h_ooff.as<uint64_t>()[g.idx_base + j], parsed[i].total);
             });
         }
         for (size_t i = b; i < e; ++i) { std::vector<uint8_t>().swap(parsed[i].lit); }
-        host_serial += now_ms() - ts0;
+        groups.clear();
+        ov.host(t0, now_ms());
+        return 0;
+    };
+
+    // software pipeline: parse k, issue k; then complete the oldest slice once kLanes are in flight
+    for (size_t k = 0; k < ns; ++k) {
+        if (k >= (size_t)kLanes) { rc = complete(k - kLanes); if (rc) return rc; }
+        rc = parse(k); if (rc) return rc;
+        rc = issue(k); if (rc) return rc;
     }
-    if (timing) { timing->total_ms = now_ms() - t_begin; timing->gpu_ms = gpu_ms; timing->host_overlapped_ms = host_overlapped; timing->host_serial_ms = host_serial; }
+    for (size_t k = ns > (size_t)kLanes ? ns - kLanes : 0; k < ns; ++k) { rc = complete(k); if (rc) return rc; }
+    if (timing) {
+        timing->total_ms = now_ms() - t_begin; timing->gpu_ms = ov.gpu_last - ov.gpu_first;
+        timing->host_overlapped_ms = ov.overlapped; timing->host_serial_ms = ov.serial;
+    }
     return 0;
 }
 

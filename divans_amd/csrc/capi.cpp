@@ -102,11 +102,12 @@ struct divans_gpu_codec {
     uint32_t blocks = 0;          // persistent grid of the model/decode kernels
     uint32_t cache_high = 0, cache_low = 0;   // per-stream LDS row caches (rows; 0 = that table is accessed in HBM/L2 directly)
     bool cache_unified = false;
-    bool packed8 = false;         // non-mixing configurations: 8 lanes per stream, two CDF entries per lane (lit_kernels_p8.hip)
     // decoder generation: 2 = lit_decode2.hip (direct-mapped row caches, LDS word ring), 1 = lit_decode_kernel of lit_kernels.hip
     uint32_t decode_gen = 2;
     uint32_t dm_log2 = 0, dm_shift = 0;   // LitBatch::dm_log2 / dm_shift
     uint32_t blocks2 = 0;                 // persistent grid of lit_decode2_kernel
+    bool user_geometry = false;           // set_geometry / set_split_cache / set_decoder were called: set_block_types keeps their choices
+    uint8_t* d_stream_flags = nullptr;    // caller-owned per-stream failure flags of the decode entry points (divans_gpu_codec_set_stream_flags)
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
@@ -218,8 +219,8 @@ static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
     b.cache_bytes_per_wg = (LIT_THREADS / 16) * (b.cache_rows_high + b.cache_rows_low) * 34u;
 }
 
-static uint32_t groups_per_block(const divans_gpu_codec* c) { return c->packed8 ? LIT_THREADS / 8 : LIT_THREADS / 16; }
-static bool use_decode2(const divans_gpu_codec* c) { return c->decode_gen == 2u && !c->packed8 && c->blocks2 != 0u; }
+static uint32_t groups_per_block(const divans_gpu_codec*) { return LIT_THREADS / 16; }
+static bool use_decode2(const divans_gpu_codec* c) { return c->decode_gen == 2u && c->blocks2 != 0u; }
 static uint32_t resident_groups(const divans_gpu_codec* c) { return std::max(c->blocks, use_decode2(c) ? c->blocks2 : 0u) * groups_per_block(c); }
 
 static int ensure_tables(divans_gpu_codec* c) {
@@ -429,9 +430,24 @@ extern "C" int divans_gpu_codec_set_block_types(divans_gpu_codec* c, uint32_t n_
     HIP_TRY(hipMemcpy(c->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     c->geom = g;
     if (c->d_tables) { HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }
-    const bool was_packed = c->packed8;
+    // the block types change the LDS the context tables take, not what the caller chose before: keep an explicitly set
+    // grid / cache organisation / decoder generation, clamped to what still fits the LDS (and to caches the new row count allows)
+    const uint32_t blocks = c->blocks, blocks2 = c->blocks2, ch = c->cache_high, cl = c->cache_low, gen = c->decode_gen, lg = c->dm_log2, sh = c->dm_shift;
+    const bool uni = c->cache_unified, user = c->user_geometry;
     configure_from_geometry(c);
-    c->packed8 = was_packed;
+    if (user) {
+        const uint32_t fit_blocks = c->blocks, fit_blocks2 = c->blocks2;
+        if (c->geom.total_rows < 0x7fffu) {
+            c->cache_high = ch; c->cache_low = cl; c->cache_unified = uni; c->dm_log2 = lg; c->dm_shift = sh;
+            const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
+            const uint32_t extra = (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
+            const uint32_t lds1 = (LIT_THREADS / 16) * (ch + (uni ? 0u : cl)) * 34u + extra, lds2 = (LIT_THREADS / 16) * lit_decode2_stream_lds(lg) + extra;
+            if (lds1 > 160u * 1024u || lds2 > 160u * 1024u) return fail(DIVANS_GPU_EINVAL, "the row caches chosen before do not fit the LDS next to this many context tables");
+            c->blocks = std::min(blocks, c->num_cus * std::max(1u, std::min(8u, (160u * 1024u) / std::max(lds1, 1u))));
+            c->blocks2 = std::min(blocks2, c->num_cus * std::max(1u, std::min(8u, (160u * 1024u) / std::max(lds2, 1u))));
+        } else { c->blocks = std::min(blocks, fit_blocks); c->blocks2 = std::min(blocks2 ? blocks2 : fit_blocks2, fit_blocks2); }
+        c->decode_gen = gen; c->user_geometry = true;
+    }
     return 0;
 }
 
@@ -451,22 +467,12 @@ extern "C" int divans_gpu_codec_set_bucket_batch(divans_gpu_codec* c, uint32_t s
     return 0;
 }
 
-extern "C" int divans_gpu_codec_set_lane_layout(divans_gpu_codec* c, uint32_t lanes_per_stream) {
-    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    if (lanes_per_stream != 8 && lanes_per_stream != 16) return fail(DIVANS_GPU_EINVAL, "lanes_per_stream must be 8 or 16");
-    if (lanes_per_stream == 8 && c->mix) return fail(DIVANS_GPU_EINVAL, "the packed 8-lane kernels do not implement prior mixing");
-    if ((lanes_per_stream == 8) != c->packed8) {   // the table slab per workgroup changes: reallocate lazily
-        if (c->d_tables) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }
-        c->packed8 = lanes_per_stream == 8;
-    }
-    return 0;
-}
-
 // Decoder generation and the geometry of lit_decode2_kernel: rows[i] of the four direct-mapped caches (high stride, high
 // context-map, low stride, low context-map rows; 0 = not cached, else a power of two in [4, 256]), their hash shifts, and
 // the persistent grid (0 = keep).
 extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    c->user_geometry = true;
     if (generation < 1u || generation > 3u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches) or 3 (second generation, 2-way caches)");
     HIP_TRY(hipSetDevice(c->device));
     const bool two_way = generation == 3u;
@@ -506,6 +512,7 @@ static bool valid_cache_rows(uint32_t r) { return r == 0 || (r >= 16 && r <= 256
 
 extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t cache_rows) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    c->user_geometry = true;
     if (cache_rows != 0xffffffffu) {
         if (!valid_cache_rows(cache_rows)) return fail(DIVANS_GPU_EINVAL, "cache_rows must be 0 or a power of two in [16, 256]");
         if (cache_rows && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
@@ -529,7 +536,7 @@ extern "C" int divans_gpu_codec_set_split_cache(divans_gpu_codec* c, uint32_t hi
     if (high_rows == 0 && low_rows != 0) return fail(DIVANS_GPU_EINVAL, "a low-nibble cache needs a high-nibble cache");
     if ((high_rows || low_rows) && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
     c->cache_high = high_rows; c->cache_low = low_rows; c->cache_unified = false;
-    c->decode_gen = 1;
+    c->decode_gen = 1; c->user_geometry = true;
     return 0;
 }
 
@@ -592,10 +599,9 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
     b.sf = c->d_sf; b.status = c->d_status;
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
-    if (d_segs && (c->packed8 || (b.cache_mode != 2u && b.cache_mode != 0u))) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache or none");
+    if (d_segs && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (c->packed8) HIP_TRY(launch_model_encode_p8(b, c->blocks, c->stream));
-    else HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
+    HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     return 0;
 }
@@ -708,16 +714,16 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
     b.in = d_in; b.in_offsets = d_in_offsets; b.in_sizes = d_in_sizes;
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes; b.status = c->d_status;
+    b.stream_bad = c->d_stream_flags;
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
-    if (d_segs && (c->packed8 || (b.cache_mode != 2u && b.cache_mode != 0u))) return fail(DIVANS_GPU_EINVAL, "segment lists need the 16-lane layout with the default (high-nibble-row) cache or none");
+    if (d_segs && !use_decode2(c) && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
     if (use_decode2(c)) {
         b.dm_log2 = lit_decode2_effective_caches(c->dm_log2, c->mix, d_segs != nullptr); b.dm_shift = c->dm_shift;
         b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    if (c->packed8) HIP_TRY(launch_decode_p8(b, c->blocks, c->stream));
-    else if (use_decode2(c)) HIP_TRY(launch_decode2(b, c->mix, c->blocks2, c->stream));
+    if (use_decode2(c)) HIP_TRY(launch_decode2(b, c->mix, c->blocks2, c->stream));
     else HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     c->timing_pending_dec = true;
@@ -754,6 +760,14 @@ extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info)
     info->table_bytes = (uint64_t)resident_groups(c) * c->geom.total_rows * 32u;
     info->scratch_bytes = c->sf_bytes;
     info->last_model_ms = c->last_model_ms; info->last_rans_ms = c->last_rans_ms; info->last_decode_ms = c->last_decode_ms;
+    return 0;
+}
+
+// Which stream failed: a device array of at least n_streams bytes the decode entry points set to 1 for every stream that fails
+// its integrity check (they never clear it; null switches it off).  The caller owns the array and its zeroing.
+extern "C" int divans_gpu_codec_set_stream_flags(divans_gpu_codec* c, uint8_t* d_flags) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    c->d_stream_flags = d_flags;
     return 0;
 }
 
@@ -991,6 +1005,10 @@ extern "C" int divans_gpu_lit_encode_host_pipelined(divans_gpu_codec* c, const u
     if ((rc = host_scratch(c, 6, sizeof(uint32_t) * n_streams, &d_sz))) return rc;
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));      // earlier work on the codec's stream may still read the staging buffers
+    // From here on copies from `in` and into the caller's output arrays are in flight on three streams: every exit -- also the
+    // early ones -- goes through drain() so that the caller can free or reuse its buffers as soon as the call returns.
+    auto drain = [&]() { (void)hipStreamSynchronize(c->s_in); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); };
+    rc = [&]() -> int {
     for (uint32_t i = 0; i < slices; ++i) {
         const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
         HIP_TRY(hipMemcpyAsync(d_in + (size_t)s0 * stream_len, in + (size_t)s0 * stream_len, (size_t)ns * stream_len, hipMemcpyHostToDevice, c->s_in));
@@ -999,10 +1017,10 @@ extern "C" int divans_gpu_lit_encode_host_pipelined(divans_gpu_codec* c, const u
     for (uint32_t i = 0; i < slices; ++i) {
         const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[i], 0));
-        rc = encode_batch_impl(c, d_in + (size_t)s0 * stream_len, nullptr, nullptr, stream_len, ns, d_slots, slot, d_off + s0, d_sz + s0, nullptr, 0);
-        if (rc) return rc;
-        rc = divans_gpu_pack_streams(c, d_slots, d_off + s0, d_sz + s0, ns, d_packed + (size_t)s0 * slot, d_poff + s0, d_total + i);
-        if (rc) return rc;
+        int r = encode_batch_impl(c, d_in + (size_t)s0 * stream_len, nullptr, nullptr, stream_len, ns, d_slots, slot, d_off + s0, d_sz + s0, nullptr, 0);
+        if (r) return r;
+        r = divans_gpu_pack_streams(c, d_slots, d_off + s0, d_sz + s0, ns, d_packed + (size_t)s0 * slot, d_poff + s0, d_total + i);
+        if (r) return r;
         HIP_TRY(hipMemcpyAsync(&c->h_totals[i], d_total + i, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(c->ev_done[i], c->stream));
     }
@@ -1013,7 +1031,7 @@ extern "C" int divans_gpu_lit_encode_host_pipelined(divans_gpu_codec* c, const u
         const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
         HIP_TRY(hipEventSynchronize(c->ev_done[i]));
         const uint64_t total = c->h_totals[i];
-        if (base + total > out_cap) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); return fail(DIVANS_GPU_ECAP, "out_cap too small for the packed streams"); }
+        if (base + total > out_cap) return fail(DIVANS_GPU_ECAP, "out_cap too small for the packed streams");
         bases[i] = base;
         HIP_TRY(hipMemcpyAsync(out_packed + base, d_packed + (size_t)s0 * slot, total, hipMemcpyDeviceToHost, c->s_out));
         HIP_TRY(hipMemcpyAsync(out_offsets + s0, d_poff + s0, sizeof(uint64_t) * ns, hipMemcpyDeviceToHost, c->s_out));
@@ -1031,6 +1049,9 @@ extern "C" int divans_gpu_lit_encode_host_pipelined(divans_gpu_codec* c, const u
     }
     *out_total = base;
     return 0;
+    }();
+    if (rc) drain();
+    return rc;
 }
 
 extern "C" int divans_gpu_lit_decode_host_pipelined(divans_gpu_codec* c, const uint8_t* in_packed, const uint64_t* in_offsets,
@@ -1057,6 +1078,8 @@ extern "C" int divans_gpu_lit_decode_host_pipelined(divans_gpu_codec* c, const u
     if ((rc = host_scratch(c, 6, sizeof(uint32_t) * n_streams, &d_sz))) return rc;
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    auto drain = [&]() { (void)hipStreamSynchronize(c->s_in); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); };
+    rc = [&]() -> int {     // see divans_gpu_lit_encode_host_pipelined: no return with a copy still in flight
     HIP_TRY(hipMemcpyAsync(d_off, in_offsets, sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice, c->s_in));
     HIP_TRY(hipMemcpyAsync(d_sz, in_sizes, sizeof(uint32_t) * n_streams, hipMemcpyHostToDevice, c->s_in));
     for (uint32_t i = 0; i < slices; ++i) {
@@ -1068,8 +1091,8 @@ extern "C" int divans_gpu_lit_decode_host_pipelined(divans_gpu_codec* c, const u
     for (uint32_t i = 0; i < slices; ++i) {
         const uint32_t s0 = i * S, ns = std::min(S, n_streams - s0);
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[i], 0));
-        rc = divans_gpu_lit_decode_batch(c, d_in, d_off + s0, d_sz + s0, ns, d_out + (size_t)s0 * stream_len, nullptr, nullptr, stream_len);
-        if (rc) return rc;
+        const int r = divans_gpu_lit_decode_batch(c, d_in, d_off + s0, d_sz + s0, ns, d_out + (size_t)s0 * stream_len, nullptr, nullptr, stream_len);
+        if (r) return r;
         HIP_TRY(hipEventRecord(c->ev_done[i], c->stream));
         HIP_TRY(hipStreamWaitEvent(c->s_out, c->ev_done[i], 0));
         HIP_TRY(hipMemcpyAsync(out + (size_t)s0 * stream_len, d_out + (size_t)s0 * stream_len, (size_t)ns * stream_len, hipMemcpyDeviceToHost, c->s_out));
@@ -1083,5 +1106,8 @@ extern "C" int divans_gpu_lit_decode_host_pipelined(divans_gpu_codec* c, const u
         return fail(DIVANS_GPU_ECORRUPT, "a coded stream is truncated, corrupt or was coded under another configuration (final rANS states / word count mismatch)");
     }
     return 0;
+    }();
+    if (rc) drain();
+    return rc;
 }
 

@@ -17,22 +17,40 @@
 
 namespace divans_host {
 
-// ---------------------------------------------------------------- CRC-32C (Castagnoli, reflected)
-uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n) {
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
-        for (uint32_t i = 0; i < 256; ++i) {
-            uint32_t c = i;
-            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
-            table[i] = c;
+// ---------------------------------------------------------------- CRC-32C (Castagnoli, reflected), src/codec/crc32.rs
+// The x86 crc32 instruction computes exactly this polynomial; the table walk is the portable path and the checker of the other.
+static uint32_t crc32c_table(uint32_t crc, const uint8_t* p, size_t n) {
+    static const struct Table {
+        uint32_t t[256];
+        Table() {
+            for (uint32_t i = 0; i < 256; ++i) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
+                t[i] = c;
+            }
         }
-        ready = true;
-    }
+    } table;
     crc = ~crc;
-    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    for (size_t i = 0; i < n; ++i) crc = table.t[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
     return ~crc;
 }
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(uint32_t crc, const uint8_t* p, size_t n) {
+    uint64_t c = (uint32_t)~crc;
+    while (n && ((uintptr_t)p & 7u)) { c = __builtin_ia32_crc32qi((uint32_t)c, *p++); --n; }
+    for (; n >= 8; n -= 8, p += 8) { uint64_t v; std::memcpy(&v, p, 8); c = __builtin_ia32_crc32di(c, v); }
+    while (n) { c = __builtin_ia32_crc32qi((uint32_t)c, *p++); --n; }
+    return ~(uint32_t)c;
+}
+#endif
+uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n) {
+#if defined(__x86_64__)
+    static const bool hw = __builtin_cpu_supports("sse4.2");
+    if (hw) return crc32c_hw(crc, p, n);
+#endif
+    return crc32c_table(crc, p, n);
+}
+uint32_t crc32c_portable(uint32_t crc, const uint8_t* p, size_t n) { return crc32c_table(crc, p, n); }
 
 // ---------------------------------------------------------------- 16-symbol CDF on the host (CMD coder only)
 struct Speed { int16_t inc, lim; };
@@ -800,3 +818,9 @@ ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int devi
 }
 
 }  // namespace divans_host
+
+// Test hook (tests/test_abi_cpu.py): both CRC-32C paths on the same bytes.
+extern "C" void divans_host_selftest_crc32c(const uint8_t* p, size_t n, uint32_t* accelerated, uint32_t* portable) {
+    if (accelerated) *accelerated = divans_host::crc32c(0, p, n);
+    if (portable) *portable = divans_host::crc32c_portable(0, p, n);
+}

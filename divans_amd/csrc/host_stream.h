@@ -67,7 +67,8 @@ struct ParsedStream { divans_lit_config cfg; size_t total = 0; std::vector<uint8
 // The host half of parse_container: framing + CRC + CMD coder; `ps` gets the LIT-coder bytes, the decoded size and the LIT configuration.
 ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed);
 
-uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n);   // src/codec/crc32.rs
+uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n);   // src/codec/crc32.rs (SSE4.2 crc32 where the CPU has it)
+uint32_t crc32c_portable(uint32_t crc, const uint8_t* p, size_t n);   // the table walk, always
 
 }  // namespace divans_host
 #endif

@@ -495,7 +495,10 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
             corrupt |= (SA != (1ull << 31)) | (SB != (1ull << 31));
         }
         corrupt |= ww.pos != ww.nwords;     // every coded word consumed, none read past the end
-        if (corrupt && li == 0 && b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
+        if (corrupt && li == 0) {
+            if (b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
+            if (b.stream_bad) b.stream_bad[s] = 1;
+        }
     }
 }
 

@@ -1,4 +1,4 @@
-// lit_device.h -- device helpers shared by the 16-lane (lit_kernels.hip) and packed 8-lane (lit_kernels_p8.hip) kernels.
+// lit_device.h -- device helpers shared by the literal-coder kernels (lit_kernels.hip, lit_decode2.hip).
 #ifndef DIVANS_LIT_DEVICE_H_
 #define DIVANS_LIT_DEVICE_H_
 #include <hip/hip_runtime.h>
@@ -191,7 +191,7 @@ __device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8
 // Walks a stream's segment list (general streams: one segment per Literal command).  `left` = bytes of the current
 // segment still to code; advance() is called when it reaches zero and installs the next segment's context.
 struct SegCursor {
-    const LitSegment* segs; uint32_t idx, end, left;
+    const LitSegment* segs; uint32_t idx, end, left; uint32_t* status;
     __device__ __forceinline__ void advance(const LitGeometry& g, uint64_t& last8, uint32_t& ctab) {
         while (left == 0u && idx < end) {
             const u32x4 sg = *(const u32x4*)(segs + idx);
@@ -199,12 +199,15 @@ struct SegCursor {
             left = sg.x;
             last8 = ((uint64_t)sg.w << 32) | sg.z;
             uint32_t t = sg.y - g.bt_first;
-            t = t < g.n_btypes ? t : g.n_btypes - 1u;     // the host sizes the tables from the block types it saw; stay inside them
+            if (t >= g.n_btypes) {       // a block type the codec holds no context table for (divans_gpu_codec_set_block_types): stay
+                t = g.n_btypes - 1u;     // inside the tables, but say so -- the stream would be coded under the wrong context map
+                if (status) atomicOr(status, LIT_STATUS_BAD_SEGMENT);
+            }
             ctab = LIT_BLOB_CTXF + t * LIT_CTXF_BYTES;
         }
     }
     __device__ __forceinline__ void start(const LitBatch& b, uint32_t s, uint64_t& last8, uint32_t& ctab) {
-        segs = b.segs; idx = b.seg_begin[s]; end = b.seg_begin[s + 1]; left = 0u;
+        segs = b.segs; idx = b.seg_begin[s]; end = b.seg_begin[s + 1]; left = 0u; status = b.status;
         advance(b.geom, last8, ctab);
     }
 };

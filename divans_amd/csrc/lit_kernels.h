@@ -60,8 +60,10 @@ struct LitBatch {
     // context-map rows), one byte each: log2(rows) + 1, 0 = that table is not cached; and the hash shift of each
     // (set = (row ^ (row >> shift)) & (rows - 1)).  cache_bytes_per_wg then covers the word rings too.
     uint32_t dm_log2, dm_shift;
+    uint8_t* stream_bad;        // optional [n_streams]: set to 1 for every stream whose decode failed its integrity check
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
+constexpr uint32_t LIT_STATUS_BAD_SEGMENT = 4u;   // a segment names a literal block type outside the codec's context tables
 constexpr uint32_t LIT_STATUS_BAD_STREAM = 2u;    // decode: a chunk did not end with both states at 2^31, or the coded words were not consumed exactly
 
 struct RansBatch {
@@ -123,8 +125,6 @@ hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream
 hipError_t launch_decode2(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 uint32_t lit_decode2_effective_caches(uint32_t dm_log2, bool mix, bool seg);   // the caches of dm_log2 a kernel instance exists for
 uint32_t lit_decode2_stream_lds(uint32_t dm_log2);   // LDS bytes one stream takes in lit_decode2_kernel (word ring + row caches)
-hipError_t launch_model_encode_p8(const LitBatch& b, uint32_t blocks, hipStream_t st);
-hipError_t launch_decode_p8(const LitBatch& b, uint32_t blocks, hipStream_t st);
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
                        uint64_t* dst_off, uint64_t* total, hipStream_t st);
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);

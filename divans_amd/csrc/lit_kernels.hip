@@ -645,7 +645,10 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
             corrupt |= (SA != (1ull << 31)) | (SB != (1ull << 31));
         }
         corrupt |= ww.pos != ww.nwords;     // every coded word consumed, none read past the end
-        if (corrupt && li == 0 && b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
+        if (corrupt && li == 0) {
+            if (b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
+            if (b.stream_bad) b.stream_bad[s] = 1;
+        }
     }
 }
 

@@ -7,6 +7,14 @@
  * SURVEY.md section 8 row f4.  Streams are literal-only (the internal command selection, raw_to_cmd/mod.rs:105-181); every
  * container is byte-identical to what divans_encode / divans_encode_flush of include/divans_ffi.h produce for the same
  * input handed over in one divans_encode call.
+ *
+ * How a call runs: the streams are binned into length classes (<= 64 KiB, then powers of two) and cut into slices (about a
+ * quarter of a class, 512 .. 8192 streams; decompression: about an eighth of the batch in stream order); up to three slices
+ * are in flight on the GPU, each on its own HIP stream with its own codec and page-locked staging buffers, while the host
+ * threads stage the next slice and assemble (compress) or parse and copy out (decompress) the others.  Device memory is sized
+ * per slice from its class bound -- roughly 64 bytes per byte of the bound and stream, never more than a sixth of the free
+ * device memory per slice -- so a long stream among many short ones only costs its own slice.  A single stream whose class does
+ * not fit that budget fails with DIVANS_GPU_ENOMEM.
  */
 #ifndef DIVANS_BATCH_H_
 #define DIVANS_BATCH_H_
@@ -36,9 +44,11 @@ void divans_batch_options_default(divans_batch_options *o);
 
 typedef struct divans_batch_timing {       /* milliseconds, wall clock */
     double total_ms;
-    double gpu_ms;            /* first copy in .. last copy out, as seen from the host (includes launch and copies) */
-    double host_overlapped_ms;/* host work done while the GPU was busy: CMD coders (compress) / container parsing (decompress) */
-    double host_serial_ms;    /* host work that had to wait for the GPU: Mux replay + framing (compress), output copies (decompress) */
+    double gpu_ms;            /* first enqueue .. last slice finished, as seen from the host (launches, copies, kernels of all slices) */
+    double host_overlapped_ms;/* host work done while at least one slice was in flight on the GPU: staging, CMD coders, Mux replay +
+                                 framing of finished slices (compress) / parsing, staging, output copies (decompress) */
+    double host_serial_ms;    /* host work with nothing in flight: the first slice's staging / parsing, the last slice's assembly or
+                                 copy-out, the final gather of the containers */
 } divans_batch_timing;
 
 /* upper bound of the container size for an n-byte input */
@@ -51,7 +61,8 @@ int divans_batch_compress(const divans_batch_options *opt, const uint8_t *const 
 
 /* n_streams complete containers -> their payloads back to back in `out`.  Streams whose PredictionMode / block type differ
  * are grouped and decoded group by group.  Returns DIVANS_GPU_ECORRUPT when a container fails its CRC, framing or the LIT
- * decoder's integrity check (out_sizes[i] of the first bad stream is set to (size_t)-1). */
+ * decoder's integrity check; out_sizes[i] of the first bad stream found is set to (size_t)-1 (for an integrity failure: the
+ * first flagged stream of the slice that was being completed; streams of earlier slices have been written to `out` by then). */
 int divans_batch_decompress(const divans_batch_options *opt, const uint8_t *const *containers, const size_t *sizes, size_t n_streams,
                             uint8_t *out, size_t out_cap, size_t *out_offsets, size_t *out_sizes, divans_batch_timing *timing);
 

@@ -106,7 +106,9 @@ typedef struct divans_lit_segment {
     uint32_t btype;    /* literal block type in force (< the count given to divans_gpu_codec_set_block_types) */
     uint64_t last8;    /* the 8 output bytes before the command, oldest in bits 0..7, newest in bits 56..63 */
 } divans_lit_segment;
-/* context tables for literal block types 0 .. n_btypes-1 (1..8) instead of the single divans_lit_config::btype */
+/* context tables for literal block types 0 .. n_btypes-1 (1..8) instead of the single divans_lit_config::btype.  A grid / cache
+ * organisation / decoder generation chosen before with the tuning calls below is kept (clamped to what the LDS holds next to
+ * the extra tables).  A segment naming a block type >= n_btypes raises DIVANS_GPU_STATUS_BAD_SEGMENT in the status word. */
 int divans_gpu_codec_set_block_types(divans_gpu_codec *c, uint32_t n_btypes);
 /* As divans_gpu_lit_encode_batch / _decode_batch; stream i's literal bytes (in command order, concatenated) are split
  * by the segments d_segs[d_seg_begin[i] .. d_seg_begin[i+1]) (device arrays; d_seg_begin has n_streams + 1 entries). */
@@ -129,7 +131,11 @@ int divans_gpu_lit_decode_segments_batch(divans_gpu_codec *c, const uint8_t *d_i
  * The host-buffer wrappers check the same word themselves and return DIVANS_GPU_EINVAL / DIVANS_GPU_ECORRUPT. */
 #define DIVANS_GPU_STATUS_BAD_MODEL 1u
 #define DIVANS_GPU_STATUS_BAD_STREAM 2u
+#define DIVANS_GPU_STATUS_BAD_SEGMENT 4u   /* a segment's literal block type lies outside the tables divans_gpu_codec_set_block_types built */
 int divans_gpu_codec_status(divans_gpu_codec *c, uint32_t *status);
+/* Which stream: `d_flags` (device memory, >= n_streams bytes, zeroed by the caller; NULL = off) receives a 1 for every stream
+ * of the following decode calls that fails that integrity check. */
+int divans_gpu_codec_set_stream_flags(divans_gpu_codec *c, uint8_t *d_flags);
 
 /* Compacts the right-aligned slots into one contiguous buffer (4-byte aligned starts):
  * d_packed_offsets[i] = exclusive prefix sum of round_up(sizes,4); returns total via *d_total (device u64). */
@@ -178,9 +184,6 @@ int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);
 /* tuning knobs: `blocks` = persistent grid of 256-thread workgroups (0 keeps the current value);
  * `cache_rows` = rows of one unified per-stream LDS row cache (0 = off, power of two in [16,256], 0xffffffff keeps). */
 int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t cache_rows);
-/* lanes of a wavefront that own one stream: 16 (one CDF entry per lane; the only layout with prior mixing) or
- * 8 (two entries per lane; non-mixing configurations only) */
-int divans_gpu_codec_set_lane_layout(divans_gpu_codec *c, uint32_t lanes_per_stream);
 /* Encoder model pass: 0 = automatic, 1 = streaming kernels (one walk per stream against its CDF table in HBM),
  * 2 = bucketed (positions grouped by the byte / context that selects their rows, one lane per bucket, rows in LDS;
  * lit_bucket.hip, lit_bucket_mix.hip).  The bucketed pass exists for configurations whose every mixing value is 4

@@ -54,7 +54,7 @@ def main():
         try:
             c = da.LiteralCodec(cfg, L)
             if lanes == 8:
-                c.set_lane_layout(8)
+                raise RuntimeError('the packed 8-lane layout was removed in round 3')
             if mode == "u":
                 c.set_geometry(cache_rows=hi)
             elif mode == "n":

@@ -64,3 +64,24 @@ def test_encode_bound_is_monotone_and_sufficient_for_worst_case_model():
         chunks = (nsym + 65535) // 65536
         assert b >= 16 * chunks + 4 * ((15 * nsym + 31) // 32)
         prev = b
+
+
+def test_host_crc32c_paths_agree():
+    """the SSE4.2 path and the table walk of divans_amd/csrc/host_stream.cpp against the known answers of src/codec/crc32.rs"""
+    import ctypes
+    import numpy as np
+    import divans_amd as da
+    L = da.load_library()
+    L.divans_host_selftest_crc32c.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.divans_host_selftest_crc32c.restype = None
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 4097, 100003):
+        for shift in (0, 1, 3):
+            buf = rng.integers(0, 256, size=n + 8, dtype=np.uint8)
+            a = ctypes.c_uint32(0); b = ctypes.c_uint32(0)
+            L.divans_host_selftest_crc32c(buf.ctypes.data + shift, n, ctypes.byref(a), ctypes.byref(b))
+            assert a.value == b.value, (n, shift)
+    kat = np.frombuffer(b"123456789", dtype=np.uint8).copy()
+    a = ctypes.c_uint32(0); b = ctypes.c_uint32(0)
+    L.divans_host_selftest_crc32c(kat.ctypes.data, kat.size, ctypes.byref(a), ctypes.byref(b))
+    assert a.value == b.value == 0xE3069283          # CRC-32C check value

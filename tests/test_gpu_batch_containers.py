@@ -44,3 +44,37 @@ def test_batch_decompress_groups_configurations_and_rejects_damage(corpus):
         da.batch_decompress([a[1], bad], 40000, da.batch_options())
     with pytest.raises(da.DivansGpuError):
         da.batch_decompress([a[1], bad], 40000, da.batch_options(skip_crc=1))
+
+
+def test_batch_one_long_stream_among_many_short_ones(corpus):
+    # length classes + slices: a 3 MB stream next to 1500 short ones neither sizes the whole batch by its length nor switches
+    # the bucketed encoder off for the others; several slices per class exercise the lane pipeline
+    import divans_amd as da
+    import workload
+    rng = np.random.default_rng(17)
+    blocks = workload.make_blocks(corpus, 7, 1500, block_len=8192)
+    lens = rng.integers(1, 8193, size=1500)
+    inputs = [blocks[i, :lens[i]] for i in range(1500)]
+    big = np.resize(corpus, 3 * 1024 * 1024 + 17)
+    inputs.insert(700, big)
+    inputs.insert(3, np.resize(corpus[50000:], 150000))
+    containers, timing = da.batch_compress(inputs, da.batch_options(host_threads=4))
+    assert timing["host_overlapped_ms"] > 0
+    for i in (0, 3, 4, 699, 700, 701, 1501):
+        ref = po.stream_compress_raw(inputs[i], po.stream_options(call_buffer_size=65536), call_inputs=[inputs[i].size])
+        assert containers[i].size == ref.size and (containers[i] == ref).all(), i
+    back, _ = da.batch_decompress(containers, sum(x.size for x in inputs), da.batch_options(host_threads=4))
+    for i, x in enumerate(inputs):
+        assert back[i].size == x.size and (back[i] == x).all(), i
+
+
+def test_batch_decompress_names_the_damaged_stream(corpus):
+    # a LIT stream whose damage passes framing (skip_crc) is caught by the decoder's integrity check, and the call says which one
+    import divans_amd as da
+    inputs = [corpus[k * 5000:k * 5000 + 4000 + k] for k in range(40)]
+    containers, _ = da.batch_compress(inputs, da.batch_options())
+    bad = [c.copy() for c in containers]
+    bad[23][bad[23].size // 2] ^= 0x04
+    with pytest.raises(da.DivansGpuError) as ei:
+        da.batch_decompress(bad, sum(x.size for x in inputs), da.batch_options(skip_crc=1))
+    assert "23" in str(ei.value)

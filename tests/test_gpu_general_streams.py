@@ -102,3 +102,26 @@ def test_segments_without_context_change_equal_plain_streams(corpus):
             got = outs["out"][int(offs[i]):int(offs[i]) + int(sz[i])].cpu().numpy()
             assert (got == po.lit_encode(ocfg, b)).all()
         codec.close()
+
+
+def test_segment_block_type_outside_the_tables_is_reported(corpus):
+    """a segment naming a literal block type the codec holds no context table for raises the BAD_SEGMENT status bit in both
+    directions and for both decoder generations (it used to be clamped silently)"""
+    import torch
+    import divans_amd as da
+    cfg = da.config_context_mixing()
+    b = corpus[1000:5000].copy()
+    segs = np.zeros(2, dtype=np.dtype([("len", "<u4"), ("btype", "<u4"), ("last8", "<u8")]))
+    segs[0] = (1000, 0, 0); segs[1] = (3000, 5, 0)          # tables exist for block types 0 and 1 only
+    d_lit, d_off, d_sz, d_sb, d_segs, longest = _segment_tensors(torch, [(b, segs)])
+    codec = da.LiteralCodec(cfg, 4000)
+    codec.set_block_types(2)
+    outs = codec.alloc_encode_outputs(1, 4000)
+    codec.encode_segments_batch(d_lit, d_off, d_sz, 1, longest, d_sb, d_segs, outs)
+    assert codec.status() & 4
+    back = torch.zeros(4000 + 64, dtype=torch.uint8, device=d_lit.device)
+    for gen in (1, 2, 3):
+        codec.set_decoder(gen)
+        codec.decode_segments_batch(outs["out"], outs["offsets"], outs["sizes"], 1, longest, d_sb, d_segs, back, d_off, d_sz)
+        assert codec.status() & 4, gen
+    codec.close()

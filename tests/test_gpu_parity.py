@@ -18,15 +18,13 @@ def _oracle_cfg(cfg_name):
     return po.config_simple() if cfg_name == "simple" else po.config_context_mixing()
 
 
-def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0, split=None, lanes=None, encode_path=None):
+def _compare(cfg_name, blocks, cache_rows=None, blocks_grid=0, split=None, encode_path=None):
     n, L = blocks.shape
     da, codec = _codec(cfg_name, max(L, 1))
     if encode_path is None and (cache_rows is not None or split is not None):
         encode_path = 1          # the row caches belong to the streaming kernels: keep their encoder in the comparison
     if encode_path is not None:
         codec.set_encode_path(encode_path)
-    if lanes is not None:
-        codec.set_lane_layout(lanes)
     if cache_rows is not None or blocks_grid:
         codec.set_geometry(blocks=blocks_grid, cache_rows=cache_rows)
     if split is not None:
@@ -446,17 +444,6 @@ def test_bucketed_encoder_only_where_it_applies():
         with pytest.raises(da.DivansGpuError):
             codec.set_encode_path(2)
         codec.close()
-
-
-@pytest.mark.parametrize("lanes", [8, 16])
-@pytest.mark.parametrize("split", [(0, 0), (16, 0), (64, 0)])
-def test_lane_layouts_bit_exact(lanes, split, corpus, shuffle384):
-    # the packed 8-lane and the 16-lane kernels must produce the same bytes as the oracle, with and without the cache
-    blocks = workload.make_blocks(corpus, 500, 90, block_len=33000)     # crosses the 32 768-byte chunk edge
-    blocks[7] = np.resize(shuffle384, 33000)
-    blocks[8] = np.random.default_rng(3).integers(0, 256, 33000, dtype=np.uint8)
-    blocks[9] = 0
-    _compare("simple", blocks, blocks_grid=2, split=split, lanes=lanes, encode_path=1)
 
 
 @pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
