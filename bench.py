@@ -365,6 +365,7 @@ def main():
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
     ap.add_argument("--host-data", action="store_true", help="build the input with tests/workload.py on the host instead of on the GPU (same bytes; "
                     "keeps the tens of thousands of small torch kernels of the GPU generator out of profiler runs)")
+    ap.add_argument("--input-cache", default="", help="with --host-data: directory that keeps the generated blocks between runs (profiler passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--diag-data", choices=["corpus", "zeros", "random", "repeat1k"], default="corpus",
@@ -432,10 +433,23 @@ def main():
             barrier(); scatter_s = time.perf_counter() - t0
             mg = {"scatter_ms": round(sharding.max_over_ranks(scatter_s, dev) * 1e3, 3)}
         elif args.host_data:
+            # profiler runs: no generator kernels on the GPU; the blocks are built once on the host and kept in a file
+            cache = os.path.join(args.input_cache, f"divans_blocks_{first}_{N}_{L}.npy") if args.input_cache else None
             d_in = torch.empty((N, L), dtype=torch.uint8, device=dev)
-            for c0 in range(0, N, 2048):
-                c1 = min(N, c0 + 2048)
-                d_in[c0:c1].copy_(torch.from_numpy(workload.make_blocks(corpus, first + c0, c1 - c0, block_len=L)))
+            if cache and os.path.exists(cache):
+                host = np.load(cache, mmap_mode="r")
+                for c0 in range(0, N, 4096):
+                    d_in[c0:min(N, c0 + 4096)].copy_(torch.from_numpy(np.ascontiguousarray(host[c0:min(N, c0 + 4096)])))
+            else:
+                host = np.lib.format.open_memmap(cache, mode="w+", dtype=np.uint8, shape=(N, L)) if cache else None
+                for c0 in range(0, N, 2048):
+                    c1 = min(N, c0 + 2048)
+                    blk = workload.make_blocks(corpus, first + c0, c1 - c0, block_len=L)
+                    if host is not None:
+                        host[c0:c1] = blk
+                    d_in[c0:c1].copy_(torch.from_numpy(blk))
+                if host is not None:
+                    host.flush()
         else:
             d_in = device_blocks(torch, corpus_t, first, N, L)
         # the GPU generator must be the committed workload (tests/workload.py), byte for byte

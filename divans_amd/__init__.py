@@ -174,7 +174,7 @@ def exported_symbols():
 
 def exported_batch_symbols():
     """Entry points include/divans_batch.h declares."""
-    return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress"]
+    return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress", "divans_batch_release"]
 
 
 def exported_ir_symbols():

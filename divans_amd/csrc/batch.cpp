@@ -14,12 +14,19 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "host_stream.h"
 
@@ -40,16 +47,77 @@ divans_host::StreamOptions to_stream_options(const divans_batch_options& o) {
     return so;
 }
 
+// How many threads the host half may use: what the process is actually granted -- CPU affinity and the cgroup's CPU quota --
+// not the machine's logical CPU count (a container that shows 256 CPUs and grants 16 would oversubscribe 16-fold).
+int usable_threads() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0}; long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+            const long q = std::atol(quota);
+            if (q > 0) n = std::min<long>(n, std::max<long>(1, (q + period - 1) / period));
+        }
+        std::fclose(f);
+    }
+    return std::min(n, 64);
+}
+
+// A persistent pool: the calls below run dozens of short parallel sections per call (per slice: staging, assembly, copy-out),
+// and creating the threads each time costs more than the sections themselves.
+class ThreadPool {
+public:
+    explicit ThreadPool(int workers) { for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); }); }
+    ~ThreadPool() {
+        { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    int workers() const { return (int)threads_.size(); }
+    // body(i) for i in [0, n) on at most `width` threads (the caller is one of them); returns when all are done
+    void run(size_t n, int width, const std::function<void(size_t)>& body) {
+        if (n == 0) return;
+        const int helpers = (int)std::min<size_t>((size_t)std::max(0, std::min(width, workers() + 1) - 1), n - 1);
+        if (helpers == 0) { for (size_t i = 0; i < n; ++i) body(i); return; }
+        std::unique_lock<std::mutex> l(mu_);
+        body_ = &body; n_ = n; next_.store(0); wanted_ = helpers; active_ = 0; epoch_ += 1;
+        l.unlock();
+        cv_.notify_all();
+        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) body(i);
+        l.lock();
+        done_cv_.wait(l, [this] { return wanted_ == 0 && active_ == 0; });
+        body_ = nullptr;
+    }
+private:
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(mu_);
+            cv_.wait(l, [&] { return stop_ || (epoch_ != seen && wanted_ > 0); });
+            if (stop_) return;
+            seen = epoch_;
+            wanted_ -= 1; active_ += 1;
+            const std::function<void(size_t)>* body = body_; const size_t n = n_;
+            l.unlock();
+            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*body)(i);
+            l.lock();
+            active_ -= 1;
+            if (wanted_ == 0 && active_ == 0) done_cv_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_; std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)>* body_ = nullptr; size_t n_ = 0; std::atomic<size_t> next_{0};
+    int wanted_ = 0, active_ = 0; unsigned long epoch_ = 0; bool stop_ = false;
+};
+ThreadPool& thread_pool() { static ThreadPool p(usable_threads() - 1); return p; }
+
 template <typename F>
 void parallel_for(size_t n, int threads, F&& body) {
-    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n, 1));
-    std::atomic<size_t> next{0};
-    auto work = [&]() { for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i); };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
+    const int width = threads > 0 ? threads : usable_threads();
+    const std::function<void(size_t)> fn = std::forward<F>(body);
+    thread_pool().run(n, width, fn);
 }
 
 // grow-only buffers: a lane reuses them from slice to slice
@@ -96,10 +164,11 @@ struct Slice { uint32_t bound = 0; std::vector<size_t> members; size_t bytes = 0
 // two-model pass: DESIGN.md section 2), rounded up
 size_t device_bytes_per_stream(uint32_t bound) { return (size_t)bound * 64u + (1u << 16); }
 
-constexpr int kLanes = 3;
+constexpr int kLanes = 8;
 
-// Streams of one class go into slices of about a quarter of the class (at least 512, at most 8192 streams, never more than the
-// device budget allows): enough slices to pipeline, few enough that each still fills a good part of the GPU.
+// Compression: the encoder passes are organised by throughput (sort / bucket chains / unsort / rANS fill the GPU whatever the
+// slice size, so concurrent slices would only queue behind each other): a class is cut into TWO slices (at least 256, at most
+// 16384 streams each, never more than the device budget allows) -- the host assembles the first while the GPU codes the second.
 void make_slices(const std::vector<size_t>& order, const std::vector<uint32_t>& bound_of, const size_t* sizes, size_t budget_bytes,
                  std::vector<Slice>& slices) {
     size_t i = 0;
@@ -108,7 +177,7 @@ void make_slices(const std::vector<size_t>& order, const std::vector<uint32_t>& 
         size_t j = i;
         while (j < order.size() && bound_of[order[j]] == bound) ++j;
         const size_t n_class = j - i;
-        size_t per = std::min<size_t>(8192, std::max<size_t>(512, (n_class + 3) / 4));
+        size_t per = std::min<size_t>(16384, std::max<size_t>(256, (n_class + 1) / 2));
         per = std::max<size_t>(1, std::min(per, budget_bytes / device_bytes_per_stream(bound)));
         for (size_t b = i; b < j; b += per) {
             Slice s; s.bound = bound;
@@ -132,13 +201,14 @@ struct CodecKey {
 
 struct Lane {
     hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-    std::map<CodecKey, divans_gpu_codec*> codecs;
+    struct Entry { divans_gpu_codec* c; uint32_t full_grid; };   // full_grid: the persistent grid the codec chose for a full GPU
+    std::map<CodecKey, Entry> codecs;
     PinnedBuf h_in, h_off, h_sz, h_ooff, h_osz, h_out, h_chunks, h_total, h_flags;
     DeviceBuf d_in, d_off, d_sz, d_slots, d_ooff, d_osz, d_packed, d_poff, d_total, d_chunks, d_out, d_flags;
     long slice = -1;                 // slice in flight on this lane
     ~Lane() {
         if (stream) (void)hipStreamSynchronize(stream);
-        for (auto& kv : codecs) divans_gpu_codec_destroy(kv.second);
+        for (auto& kv : codecs) divans_gpu_codec_destroy(kv.second.c);
         if (done) (void)hipEventDestroy(done);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -154,16 +224,38 @@ struct Lane {
             divans_gpu_codec* c = nullptr;
             const int rc = divans_gpu_codec_create(&c, &cfg, device, stream, bound);
             if (rc) return rc;
-            it = codecs.emplace(key, c).first;
+            divans_gpu_info info;
+            if (divans_gpu_codec_info(c, &info)) { divans_gpu_codec_destroy(c); return DIVANS_GPU_EHIP; }
+            it = codecs.emplace(key, Entry{c, info.blocks}).first;
         }
-        // a small slice does not need the full persistent grid's worth of CDF tables
+        // a small slice does not need the full persistent grid's worth of CDF tables; a later, larger one gets the grid back
+        const uint32_t want = (uint32_t)std::max<size_t>(1, std::min<size_t>(it->second.full_grid, (n_streams + 15) / 16));
         divans_gpu_info info;
-        if (divans_gpu_codec_info(it->second, &info) == 0 && info.blocks > (n_streams + 15) / 16)
-            (void)divans_gpu_codec_set_geometry(it->second, (uint32_t)std::max<size_t>(1, (n_streams + 15) / 16), 0xffffffffu);
-        *out = it->second;
+        if (divans_gpu_codec_info(it->second.c, &info) == 0 && info.blocks != want)
+            (void)divans_gpu_codec_set_geometry(it->second.c, want, 0xffffffffu);
+        *out = it->second.c;
         return 0;
     }
 };
+
+// The lanes live from call to call (streams, codecs with their tables and scratch, page-locked staging buffers are expensive to
+// create): one pool per process, handed to one call at a time; divans_batch_release() returns everything.
+struct LanePool {
+    std::mutex mu;
+    int device = -1;
+    std::unique_ptr<Lane[]> lanes;
+    int acquire(int dev, Lane** out) {
+        if (!lanes || device != dev) {
+            lanes.reset();
+            std::unique_ptr<Lane[]> fresh(new Lane[kLanes]);
+            for (int i = 0; i < kLanes; ++i) { const int rc = fresh[i].init(); if (rc) return rc; }
+            lanes = std::move(fresh); device = dev;
+        }
+        *out = lanes.get();
+        return 0;
+    }
+};
+LanePool& pool() { static LanePool p; return p; }
 
 // wall-clock bookkeeping of the overlap: host work counts as overlapped while at least one slice is in flight on the GPU
 struct Overlap {
@@ -211,8 +303,10 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bound_of[a] < bound_of[b]; });
     std::vector<Slice> slices;
     make_slices(order, bound_of, sizes, device_budget(), slices);
-    Lane lanes[kLanes];
-    for (auto& l : lanes) { rc = l.init(); if (rc) return rc; }
+    std::lock_guard<std::mutex> pool_lock(pool().mu);
+    Lane* lanes = nullptr;
+    rc = pool().acquire(opt->device, &lanes); if (rc) return rc;
+    struct Drain { Lane* l; ~Drain() { for (int i = 0; i < kLanes; ++i) if (l[i].stream) (void)hipStreamSynchronize(l[i].stream); } } drain{lanes};   // no early return with copies in flight
     Overlap ov;
 
     // the CMD coder of every stream sees lengths and options only: one plan per distinct length, made while the first slices run
@@ -243,7 +337,9 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         const double t0 = now_ms();
         HIP_OR_FAIL(L.h_in.reserve(s.bytes + 64)); HIP_OR_FAIL(L.h_off.reserve(8 * m)); HIP_OR_FAIL(L.h_sz.reserve(4 * m));
         HIP_OR_FAIL(L.h_ooff.reserve(8 * m)); HIP_OR_FAIL(L.h_osz.reserve(4 * m)); HIP_OR_FAIL(L.h_total.reserve(8));
-        HIP_OR_FAIL(L.h_chunks.reserve(4ull * m * max_chunks)); HIP_OR_FAIL(L.h_out.reserve(slot * m + 64));
+        HIP_OR_FAIL(L.h_chunks.reserve(4ull * m * max_chunks));
+        const size_t guess = std::min<size_t>(slot * m, s.bytes / 8 * 5 + 64 * m + 4096);    // page-locked memory is expensive: what packed streams usually need (5/8 of the input)
+        HIP_OR_FAIL(L.h_out.reserve(guess + 64));
         HIP_OR_FAIL(L.d_in.reserve(s.bytes + 64)); HIP_OR_FAIL(L.d_off.reserve(8 * m)); HIP_OR_FAIL(L.d_sz.reserve(4 * m));
         HIP_OR_FAIL(L.d_slots.reserve(slot * m + 64)); HIP_OR_FAIL(L.d_ooff.reserve(8 * m)); HIP_OR_FAIL(L.d_osz.reserve(4 * m));
         HIP_OR_FAIL(L.d_packed.reserve(slot * m + 64)); HIP_OR_FAIL(L.d_poff.reserve(8 * m)); HIP_OR_FAIL(L.d_total.reserve(8));
@@ -272,7 +368,6 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         HIP_OR_FAIL(hipMemcpyAsync(L.h_osz.p, L.d_osz.p, 4 * m, hipMemcpyDeviceToHost, L.stream));
         HIP_OR_FAIL(hipMemcpyAsync(L.h_chunks.p, L.d_chunks.p, 4ull * m * max_chunks, hipMemcpyDeviceToHost, L.stream));
         HIP_OR_FAIL(hipMemcpyAsync(L.h_total.p, L.d_total.p, 8, hipMemcpyDeviceToHost, L.stream));
-        const size_t guess = std::min<size_t>(slot * m, s.bytes + 64 * m + 4096);
         HIP_OR_FAIL(hipMemcpyAsync(L.h_out.p, L.d_packed.p, guess, hipMemcpyDeviceToHost, L.stream));
         HIP_OR_FAIL(hipEventRecord(L.done, L.stream));
         L.slice = (long)k;
@@ -292,9 +387,10 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         const uint32_t max_chunks = (uint32_t)std::max<uint64_t>(1, (2ull * s.bound + 65535ull) / 65536ull);
         HIP_OR_FAIL(hipEventSynchronize(L.done));
         const uint64_t packed_total = *L.h_total.as<uint64_t>();
-        const size_t guess = std::min<size_t>(divans_gpu_lit_encode_bound(s.bound) * m, s.bytes + 64 * m + 4096);
-        if (packed_total > guess) {   // incompressible input: fetch the rest
-            HIP_OR_FAIL(hipMemcpyAsync(L.h_out.as<uint8_t>() + guess, L.d_packed.as<uint8_t>() + guess, packed_total - guess, hipMemcpyDeviceToHost, L.stream));
+        const size_t guess = std::min<size_t>(divans_gpu_lit_encode_bound(s.bound) * m, s.bytes / 8 * 5 + 64 * m + 4096);
+        if (packed_total > guess) {   // incompressible input: a larger staging buffer, the whole slice again
+            HIP_OR_FAIL(L.h_out.reserve(packed_total + 64));
+            HIP_OR_FAIL(hipMemcpyAsync(L.h_out.p, L.d_packed.p, packed_total, hipMemcpyDeviceToHost, L.stream));
             HIP_OR_FAIL(hipStreamSynchronize(L.stream));
         }
         ov.in_flight -= 1; ov.gpu_last = now_ms();
@@ -348,15 +444,17 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     if (n_streams == 0) return 0;
     const double t_begin = now_ms();
     HIP_OR_FAIL(hipSetDevice(opt->device));
-    Lane lanes[kLanes];
-    int rc = 0;
-    for (auto& l : lanes) { rc = l.init(); if (rc) return rc; }
+    std::lock_guard<std::mutex> pool_lock(pool().mu);
+    Lane* lanes = nullptr;
+    int rc = pool().acquire(opt->device, &lanes); if (rc) return rc;
+    struct Drain { Lane* l; ~Drain() { for (int i = 0; i < kLanes; ++i) if (l[i].stream) (void)hipStreamSynchronize(l[i].stream); } } drain{lanes};   // no early return with copies in flight
     Overlap ov;
     const size_t budget = device_budget();
-    // Slices in stream order (the output offsets are the running sum of the decoded sizes): about an eighth of the batch,
-    // 256 .. 8192 containers.  While the GPU decodes the slices in flight, host threads parse the next one (framing, CRC,
-    // CMD coder -> decoded sizes and LIT configuration, which the launch needs) and copy out the one that has finished.
-    const size_t per = std::min<size_t>(8192, std::max<size_t>(256, (n_streams + 7) / 8));
+    // Slices in stream order (the output offsets are the running sum of the decoded sizes): one per lane, 128 .. 8192
+    // containers.  While the GPU decodes the slices in flight (concurrently: a stream is a serial chain of tens of
+    // milliseconds), host threads parse the next one (framing, CRC, CMD coder -> decoded sizes and LIT configuration, which
+    // the launch needs) and copy out the ones that have finished.
+    const size_t per = std::min<size_t>(8192, std::max<size_t>(128, (n_streams + kLanes - 1) / kLanes));
     const size_t ns = (n_streams + per - 1) / per;
     std::vector<divans_host::ParsedStream> parsed(n_streams);
     std::vector<int> status(n_streams, 0);
@@ -488,6 +586,13 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
         timing->host_overlapped_ms = ov.overlapped; timing->host_serial_ms = ov.serial;
     }
     return 0;
+}
+
+// Frees what the batch calls keep between calls (HIP streams, codecs, device scratch, page-locked staging buffers).
+void divans_batch_release(void) {
+    std::lock_guard<std::mutex> pool_lock(pool().mu);
+    pool().lanes.reset();
+    pool().device = -1;
 }
 
 }  // extern "C"

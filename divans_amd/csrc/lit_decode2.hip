@@ -25,7 +25,6 @@ namespace divans_hip {
 namespace {
 
 // LDS is addressed with 32-bit byte addresses (address space 3): no generic-pointer arithmetic in the byte loop
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_read16(uint32_t a) { return *(const lds_u16*)(uintptr_t)a; }
@@ -53,7 +52,6 @@ struct RowSlot { uint32_t row; uint32_t addr; bool missed; };   // missed: the r
 
 struct Table2 {
     __amdgpu_buffer_rsrc_t rsrc;
-    i32x4 rsrc_words;    // the same descriptor as four dwords, for the loads issued from inline asm
     uint32_t lane_off;   // row-of-lanes slab offset + 2 * lane-in-row
     __device__ __forceinline__ int gload(uint32_t row) const {
         return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, 0);
@@ -69,7 +67,7 @@ struct Table2 {
     // byte loop waits (wait_async) only when some stream of the wave did miss.
     __device__ __forceinline__ int gload_async(uint32_t row) const {
         int v;
-        asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" : "=v"(v) : "v"(lane_off + (row << 5)), "s"(rsrc_words) : "memory");
+        asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" : "=v"(v) : "v"(lane_off + (row << 5)), "s"(rsrc) : "memory");
         return v;
     }
     // Every access of the coder is a read-modify-write of a whole row: a cached row is always dirty, a miss writes the
@@ -388,12 +386,13 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
     Table2 tb;
     {
         const uint32_t slab = g.total_rows * 32u;           // bytes of one stream's table
-        tb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab),
-                                                    0, (LIT_THREADS / 16) * slab, 0x00020000);
-        tb.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
+        // the slab pointer is uniform but its 64-bit product is computed on the VALU: read it back explicitly, or every buffer
+        // access below is wrapped in a waterfall loop (the descriptor would count as divergent)
         const uint64_t base = (uint64_t)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab);
-        tb.rsrc_words = i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)base), __builtin_amdgcn_readfirstlane((int)((uint32_t)(base >> 32) & 0xffffu)),
-                              __builtin_amdgcn_readfirstlane((int)((LIT_THREADS / 16) * slab)), 0x00020000};
+        const uint64_t ubase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        tb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ubase, 0, __builtin_amdgcn_readfirstlane((int)((LIT_THREADS / 16) * slab)), 0x00020000);
+        tb.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
     const uint32_t stream_base = lds_base + (threadIdx.x >> 4) * (b.cache_bytes_per_wg / (LIT_THREADS / 16));

@@ -8,13 +8,15 @@
  * container is byte-identical to what divans_encode / divans_encode_flush of include/divans_ffi.h produce for the same
  * input handed over in one divans_encode call.
  *
- * How a call runs: the streams are binned into length classes (<= 64 KiB, then powers of two) and cut into slices (about a
- * quarter of a class, 512 .. 8192 streams; decompression: about an eighth of the batch in stream order); up to three slices
- * are in flight on the GPU, each on its own HIP stream with its own codec and page-locked staging buffers, while the host
- * threads stage the next slice and assemble (compress) or parse and copy out (decompress) the others.  Device memory is sized
- * per slice from its class bound -- roughly 64 bytes per byte of the bound and stream, never more than a sixth of the free
- * device memory per slice -- so a long stream among many short ones only costs its own slice.  A single stream whose class does
- * not fit that budget fails with DIVANS_GPU_ENOMEM.
+ * How a call runs: the streams are binned into length classes (<= 64 KiB, then powers of two).  Compression cuts every class
+ * into two slices (the encoder passes fill the GPU whatever the slice size): the host assembles the first while the GPU codes
+ * the second.  Decompression cuts the batch into eight slices in stream order, all in flight at once, each on its own HIP stream
+ * with its own codec and page-locked staging buffers -- a decoded stream is a serial chain of tens of milliseconds however few
+ * of them run, so the slices' kernels run side by side -- while the host threads parse the next slice and copy out the finished
+ * ones.  Device memory is sized per slice from
+ * its class bound -- roughly 64 bytes per byte of the bound and stream, never more than a sixteenth of the free device memory per
+ * slice -- so a long stream among many short ones only costs its own slice.  A single stream whose class does not fit that
+ * budget fails with DIVANS_GPU_ENOMEM.
  */
 #ifndef DIVANS_BATCH_H_
 #define DIVANS_BATCH_H_
@@ -65,6 +67,11 @@ int divans_batch_compress(const divans_batch_options *opt, const uint8_t *const 
  * first flagged stream of the slice that was being completed; streams of earlier slices have been written to `out` by then). */
 int divans_batch_decompress(const divans_batch_options *opt, const uint8_t *const *containers, const size_t *sizes, size_t n_streams,
                             uint8_t *out, size_t out_cap, size_t *out_offsets, size_t *out_sizes, divans_batch_timing *timing);
+
+/* The batch calls keep their eight lanes (HIP streams, codecs with their tables and scratch, page-locked staging buffers) alive
+ * between calls -- creating them costs more than coding a few thousand streams -- and run one call at a time per process.
+ * This returns everything; the next call builds the lanes again. */
+void divans_batch_release(void);
 
 #ifdef __cplusplus
 }

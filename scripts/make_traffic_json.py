@@ -10,10 +10,12 @@ for spec in sys.argv[2:]:
     config, summary, cmd, streams, block = spec.split(":")
     vals = {}
     for line in open(summary):
-        m = re.match(r"(.{60}) (FETCH_SIZE|WRITE_SIZE)\s+avg=(\S+) n=(\d+)", line)
+        m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE)\s+avg=(\S+) n=(\d+)", line)
         if not m or "divans" not in m.group(1):
             continue
         short = re.sub(r"^void ", "", m.group(1).strip()).split("<")[0].split("(")[0].replace("divans_hip::", "")
+        if short.startswith("lit_decode2_kernel") or short == "lit_decode_kernel":
+            short = "lit_decode_kernel"          # bench.py's name for whichever decode kernel generation ran
         vals.setdefault(short, {})[m.group(2)] = float(m.group(3)) * 1024.0      # counters are in KiB
     out["configs"][config] = {"command": open(cmd).read().strip(), "streams": int(streams), "block_bytes": int(block), "config": config,
                               "kernels": {k: {"fetch_bytes": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE"),
