@@ -83,7 +83,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(_HERE, "libdivans_hip.so")
+    # DIVANS_HIP_LIBRARY: a differently built libdivans_hip.so (kernel experiments, scripts/build_variants.sh); never a fallback
+    return os.environ.get("DIVANS_HIP_LIBRARY") or os.path.join(_HERE, "libdivans_hip.so")
 
 
 def load_library():

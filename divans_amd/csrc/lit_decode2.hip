@@ -20,6 +20,14 @@
 
 #include "lit_device.h"
 
+// experiment switches (scripts/build_variants.sh); the defaults are the product
+#ifndef DIVANS_D2_ASYNC
+#define DIVANS_D2_ASYNC 1
+#endif
+#ifndef DIVANS_D2_W7
+#define DIVANS_D2_W7 1
+#endif
+
 namespace divans_hip {
 
 namespace {
@@ -314,8 +322,8 @@ __device__ __forceinline__ MixRows fetch_mix2(const LitGeometry& g, const LdsVie
     const RowSel rs = select_rows2<HIGH, MM, NEED8>(g, lv.mix, ctx, hist, hi_nib);
     constexpr bool ST_C = (CM & (HIGH ? CM_HS : CM_LS)) != 0, CM_C = (CM & (HIGH ? CM_HC : CM_LC)) != 0;
     MixRows r;
-    r.st = tb.template load<ST_C, (CM & CM_2WAY) != 0, HIGH>(HIGH ? cc.hs : cc.ls, rs.stride_row, r.sref);
-    r.cm = tb.template load<CM_C, (CM & CM_2WAY) != 0, HIGH>(HIGH ? cc.hc : cc.lc, rs.cm_row, r.cref);
+    r.st = tb.template load<ST_C, (CM & CM_2WAY) != 0, HIGH && DIVANS_D2_ASYNC>(HIGH ? cc.hs : cc.ls, rs.stride_row, r.sref);
+    r.cm = tb.template load<CM_C, (CM & CM_2WAY) != 0, HIGH && DIVANS_D2_ASYNC>(HIGH ? cc.hc : cc.lc, rs.cm_row, r.cref);
     r.is_default = (MM < 0 || MM == 2) && rs.is_default;
     return r;
 }
@@ -351,7 +359,7 @@ __device__ __forceinline__ Fetched2 fetch2(const LitGeometry& g, const LdsView& 
                                            const History<NEED8>& hist, uint32_t hi_nib) {
     const RowSel rs = select_rows2<HIGH, MM, NEED8>(g, lv.mix, ctx, hist, hi_nib);
     Fetched2 f;
-    f.value = tb.template load<(CM & (HIGH ? CM_HS : CM_LS)) != 0, (CM & CM_2WAY) != 0, HIGH>(HIGH ? cc.hs : cc.ls, rs.stride_row, f.ref);
+    f.value = tb.template load<(CM & (HIGH ? CM_HS : CM_LS)) != 0, (CM & CM_2WAY) != 0, HIGH && DIVANS_D2_ASYNC>(HIGH ? cc.hs : cc.ls, rs.stride_row, f.ref);
     f.is_default = (MM < 0 || MM == 2) && rs.is_default;
     return f;
 }
@@ -441,7 +449,7 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
                         // a state that dropped below 2^31 takes 4 more bytes right before it is used again (ans.rs:432-440)
                         if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li);
                         // the rows requested one nibble ahead, if a stream of this wave missed its cache
-                        if ((CM & (CM_HS | CM_HC)) && __ballot(mrowH.sref.missed || mrowH.cref.missed) != 0ull) wait_async(mrowH.st, mrowH.cm);
+                        if (DIVANS_D2_ASYNC && (CM & (CM_HS | CM_HC)) && __ballot(mrowH.sref.missed || mrowH.cref.missed) != 0ull) wait_async(mrowH.st, mrowH.cm);
                         const MixSearched mh = search_mix2(mrowH, SA, nh, rbase);
                         const uint32_t hi = (uint32_t)mh.s.sym;
                         MixRows mrowL = fetch_mix2<false, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, hi);
@@ -465,7 +473,7 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
                     } else {
                         // rowH (this byte's high-nibble row) was requested while the previous byte was being finished
                         if (SA < (1ull << 31)) SA = (SA << 32) | ww.next(li);
-                        if ((CM & CM_HS) && __ballot(rowH.ref.missed) != 0ull) wait_async(rowH.value);
+                        if (DIVANS_D2_ASYNC && (CM & CM_HS) && __ballot(rowH.ref.missed) != 0ull) wait_async(rowH.value);
                         const int cvh = rowH.is_default ? 4 * li1 : rowH.value;
                         const uint32_t slot_a = (uint32_t)SA & 0x7fffu;
                         const Searched sh = search2(cvh, slot_a, rbase);
@@ -522,8 +530,13 @@ static LitKernel pick_decode2_cm(int mm, bool ctxc) {
     const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 2 + (ctxc ? 1 : 0);
     switch (key) {
     case 0: return lit_decode2_kernel_any<-1, false, MIX, SEG, CM>; case 1: return lit_decode2_kernel_any<-1, true, MIX, SEG, CM>;
+#if DIVANS_D2_W7
     case 2: return lit_decode2_kernel_w7<0, false, MIX, SEG, CM>;  case 3: return lit_decode2_kernel_w7<0, true, MIX, SEG, CM>;
     case 4: return lit_decode2_kernel_w7<4, false, MIX, SEG, CM>;  default: return lit_decode2_kernel_w7<4, true, MIX, SEG, CM>;
+#else
+    case 2: return lit_decode2_kernel_any<0, false, MIX, SEG, CM>;  case 3: return lit_decode2_kernel_any<0, true, MIX, SEG, CM>;
+    case 4: return lit_decode2_kernel_any<4, false, MIX, SEG, CM>;  default: return lit_decode2_kernel_any<4, true, MIX, SEG, CM>;
+#endif
     }
 }
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Experiment builds of libdivans_hip.so with the decode2 switches flipped (gpurun_exp/*.so travel to the GPU box; *.so is git-ignored).
+# usage: scripts/build_variants.sh   then   DIVANS_HIP_LIBRARY=gpurun_exp/libdivans_noasync.so python scripts/decode2_sweep.py ...
+set -e
+cd "$(dirname "$0")/.."
+python divans_amd/build.py > /dev/null
+mkdir -p gpurun_exp
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+OBJS=$(ls divans_amd/build/*.o | grep -v lit_decode2)
+build () {  # name, extra flags
+  /opt/rocm/bin/hipcc $FLAGS $2 -x hip -c divans_amd/csrc/lit_decode2.hip -o gpurun_exp/lit_decode2_$1.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_exp/libdivans_$1.so $OBJS gpurun_exp/lit_decode2_$1.o
+  rm gpurun_exp/lit_decode2_$1.o
+}
+build noasync "-DDIVANS_D2_ASYNC=0" &
+build now7 "-DDIVANS_D2_W7=0" &
+build noasync_now7 "-DDIVANS_D2_ASYNC=0 -DDIVANS_D2_W7=0" &
+wait
+ls -la gpurun_exp

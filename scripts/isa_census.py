@@ -90,7 +90,7 @@ def executed(tag, config):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03a"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03b"
     out = []
     tmp = "/tmp/isa_census"
     os.makedirs(tmp, exist_ok=True)
