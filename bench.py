@@ -288,6 +288,9 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
         "encode_MBps": round(raw / 1e6 / (avg(rec["enc"]) / 1e3), 2), "decode_MBps": round(raw / 1e6 / (avg(rec["dec"]) / 1e3), 2),
         "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
         "roofline": roofline_of(kern, alg, load_traffic(name, N, L)),
+        # HBM the codec holds besides the caller's buffers: the encoder's work arrays (+ the decoder's CDF tables)
+        "encoder_work_bytes_per_input_byte": round(codec.info().scratch_bytes / raw, 2),
+        "table_bytes": int(codec.info().table_bytes),
     }
     return res, codec, outs
 
@@ -505,7 +508,8 @@ def main():
         total_bytes = total_streams * L
         rec = {"value": round(total_bytes / 1e6 / (elapsed / K), 2), "steps": K, "ms_per_step": round(elapsed * 1e3 / K, 3),
                "bit_exact": bool(ok_all), "checked_vs_oracle": res["checked_vs_oracle"], "compressed_ratio": round(coded_all / float(total_bytes), 4),
-               "encode_MBps": res["encode_MBps"], "decode_MBps": res["decode_MBps"], "kernel_ms": res["kernel_ms"], "roofline": res["roofline"]}
+               "encode_MBps": res["encode_MBps"], "decode_MBps": res["decode_MBps"], "kernel_ms": res["kernel_ms"], "roofline": res["roofline"],
+               "encoder_work_bytes_per_input_byte": res["encoder_work_bytes_per_input_byte"], "table_bytes": res["table_bytes"]}
         if m:
             rec["multi_gpu"] = m
         return rec, ok_all
@@ -530,6 +534,7 @@ def main():
                 "compressed_ratio": rec["compressed_ratio"],
                 "encode_MBps": rec["encode_MBps"], "decode_MBps": rec["decode_MBps"],
                 "kernel_ms": rec["kernel_ms"], "roofline": rec["roofline"],
+                "encoder_work_bytes_per_input_byte": rec["encoder_work_bytes_per_input_byte"], "table_bytes": rec["table_bytes"],
             }
             if "multi_gpu" in rec:
                 line["multi_gpu"] = rec["multi_gpu"]

@@ -129,6 +129,8 @@ def load_library():
     L.divans_gpu_host_free.argtypes = [vp]
     L.divans_gpu_host_free.restype = None
     L.divans_gpu_lit_model_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    L.divans_gpu_lit_encode_batch_chunks.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp, vp, vp, u32]
+    L.divans_gpu_lit_encode_batch_chunks.restype = ctypes.c_int
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
     L.divans_gpu_selftest_cdf_ops.argtypes = [vp, vp, u32, vp]
@@ -374,9 +376,17 @@ class LiteralCodec:
                     offsets=t.empty(n_streams, dtype=t.int64, device=dev),
                     sizes=t.empty(n_streams, dtype=t.int32, device=dev))
 
-    def encode_batch(self, d_in, n_streams, stream_len, outputs, in_offsets=None, in_sizes=None):
+    def encode_batch(self, d_in, n_streams, stream_len, outputs, in_offsets=None, in_sizes=None, chunk_bytes=None):
         """d_in: uint8 tensor of n_streams*stream_len bytes (stream i = rows i), or ragged streams located by the
-        int64 `in_offsets` / int32 `in_sizes` device tensors (then stream_len = the longest).  Fills outputs in place."""
+        int64 `in_offsets` / int32 `in_sizes` device tensors (then stream_len = the longest).  Fills outputs in place.
+        chunk_bytes: optional int32 device tensor [n_streams, max_chunks] that receives the coded size of every 65 536-symbol chunk."""
+        if chunk_bytes is not None:
+            _check(self._lib.divans_gpu_lit_encode_batch_chunks(
+                self._h, d_in.data_ptr(), in_offsets.data_ptr() if in_offsets is not None else None,
+                in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams),
+                outputs["out"].data_ptr(), int(outputs["slot"]), outputs["offsets"].data_ptr(),
+                outputs["sizes"].data_ptr(), chunk_bytes.data_ptr(), int(chunk_bytes.shape[1])), "divans_gpu_lit_encode_batch_chunks")
+            return
         _check(self._lib.divans_gpu_lit_encode_batch(
             self._h, d_in.data_ptr(), in_offsets.data_ptr() if in_offsets is not None else None,
             in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams),

@@ -127,6 +127,7 @@ struct divans_gpu_codec {
     std::vector<hipEvent_t> ev_in, ev_done;
     uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;
     float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
+    std::vector<hipEvent_t> ev_rans; size_t rans_pairs = 0;   // around the rANS launches of the last encode call
     bool timing_pending_enc = false, timing_pending_dec = false;
 };
 
@@ -335,6 +336,7 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     for (void* q : c->host_scratch) if (q) (void)hipFree(q);
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_rans) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_in) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_done) if (e) (void)hipEventDestroy(e);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
@@ -375,9 +377,8 @@ static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b
 static int ensure_bucket_mix(divans_gpu_codec* c, uint32_t n_streams, MixBucketBatch& b) {
     const size_t pl = bucket_slot(c);
     const size_t n = n_streams;
-    const size_t sz_rec = n * pl * 8u, sz_pos = n * ((size_t)c->max_stream_len + BUCKET_SLOT_PAD) * 8u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 6u * 4u,
-                 sz_inv = n * pl * 2u, sz_sorted = n * pl * 2u;
-    const size_t need = 256u + 2u * sz_rec + 4u * sz_pos + sz_desc + sz_tasks + sz_inv + sz_sorted;
+    const size_t sz_rec = n * pl * 8u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 6u * 4u, sz_inv = n * pl * 2u, sz_sorted = n * pl * 2u;
+    const size_t need = 256u + 4u * sz_rec + sz_desc + sz_tasks + sz_inv + sz_sorted;
     if (need > c->bk_bytes) {
         if (c->d_bk) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_bk)); c->d_bk = nullptr; c->bk_bytes = 0; }
         if (hipMalloc(&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed two-model encoder work arrays) failed");
@@ -385,26 +386,24 @@ static int ensure_bucket_mix(divans_gpu_codec* c, uint32_t n_streams, MixBucketB
     }
     uint8_t* p = c->d_bk;
     b.counters = (uint32_t*)p; p += 256;
-    b.rec_high = (bk_u32x2*)p; p += sz_rec;
-    b.rec_low = (bk_u32x2*)p; p += sz_rec;
-    for (int i = 0; i < 4; ++i) { b.pos[i] = (bk_u32x2*)p; p += sz_pos; }
+    for (int i = 0; i < 4; ++i) { b.pos[i] = (bk_u32x2*)p; p += sz_rec; }
     b.desc = (uint32_t*)p; p += sz_desc;
     b.tasks = (uint32_t*)p; p += sz_tasks;
-    b.inv = (uint16_t*)p; p += sz_inv;
+    b.inv = (uint16_t*)p; p += sz_inv;       // inv and sorted stay adjacent: together they are the rANS pass's scratch (SfView::spare)
     b.sorted = (uint16_t*)p;
     return 0;
 }
 
-// Scratch of the chunk-parallel rANS pass: one chunk bound per stream plus a size word.  After the bucketed model pass
-// its sorted-order pair array is dead (bucket_unsort_kernel has read it) and is reused; otherwise a separate allocation.
-static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, RansBatch& r) {
+// What a model pass leaves for the rANS pass: the (start | freq << 16) pairs of `count` streams, `stride` u32 apart, and
+// work memory of the pass that is dead by then (the bucketed passes' inv + sorted arrays).
+struct SfView { uint32_t* sf = nullptr; uint32_t stride = 0; uint8_t* spare = nullptr; size_t spare_bytes = 0; };
+
+// Scratch of the chunk-parallel rANS pass: one chunk bound per stream plus a size word.  After a bucketed model pass it
+// lives in that pass's dead work arrays; otherwise in a separate allocation.
+static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, const SfView& v, RansBatch& r) {
     const uint64_t stride = divans_gpu_lit_encode_bound(32768);
     const size_t need = (size_t)n_streams * stride + (size_t)n_streams * 4u + 64u;
-    uint8_t* base = nullptr;
-    if (use_bucket(c) && c->d_bk) {
-        const size_t pl = bucket_slot(c);
-        if ((size_t)n_streams * pl * 8u >= need && c->bk_bytes >= 256u + need) base = c->d_bk + 256;   // BucketBatch::sfs, see ensure_bucket
-    }
+    uint8_t* base = v.spare_bytes >= need ? v.spare : nullptr;
     if (!base) {
         if (need > c->rs_bytes) {
             if (c->d_rs) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_rs)); c->d_rs = nullptr; c->rs_bytes = 0; }
@@ -550,22 +549,29 @@ extern "C" size_t divans_gpu_lit_encode_bound(size_t n) {
     return (bytes + 15) & ~(size_t)15;
 }
 
-// Encoder pass 1: fills c->d_sf with (start | freq << 16) per nibble, position order.  Records ev[0], ev[1] around it.
+// Encoder pass 1: (start | freq << 16) per nibble, position order.  `after(first, count, view)` is called once the model kernels
+// of streams [first, first + count) are enqueued (the two-model bucketed pass works through the batch in sub-batches whose
+// work arrays it reuses, so whatever consumes the pairs has to be enqueued in between); the bucketed passes leave the pairs in
+// their own work arrays (the unsort is in place), the streaming kernels in c->d_sf.  Records ev[0] before the first kernel.
+template <class After>
 static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes,
-                      uint32_t stream_len, uint32_t n_streams, const uint32_t* d_seg_begin = nullptr, const divans_lit_segment* d_segs = nullptr) {
-    int rc = ensure_sf(c, n_streams); if (rc) return rc;
+                      uint32_t stream_len, uint32_t n_streams, const uint32_t* d_seg_begin, const divans_lit_segment* d_segs, After&& after) {
+    int rc = 0;
+    SfView view;
     if (use_bucket(c) && n_streams < (1u << 24) && !d_segs) {   // segment lists (context reloads between Literal commands) go through the streaming kernels
         BucketBatch k;
         std::memset(&k, 0, sizeof(k));
         rc = ensure_bucket(c, n_streams, k); if (rc) return rc;
         k.in = d_in; k.in_offsets = d_in_offsets; k.in_sizes = d_in_sizes;
         k.n_streams = n_streams; k.stream_len = stream_len; k.max_stream_len = c->max_stream_len;
-        k.pieces = bucket_pieces(c); k.slot = bucket_slot(c); k.sf_stride = 2u * c->max_stream_len;
-        k.sf = c->d_sf; k.inc = c->geom.inc0; k.lim = c->geom.lim0;
+        k.pieces = bucket_pieces(c); k.slot = bucket_slot(c);
+        k.sf = (uint32_t*)k.sfs; k.sf_stride = 2u * k.slot;     // bucket_unsort_kernel works in place
+        k.inc = c->geom.inc0; k.lim = c->geom.lim0;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         HIP_TRY(launch_bucket_model(k, c->num_cus * 4u, c->stream));
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        return 0;
+        view.sf = k.sf; view.stride = k.sf_stride;
+        view.spare = (uint8_t*)k.inv; view.spare_bytes = (size_t)n_streams * k.slot * 3u;
+        return after(0u, n_streams, view);
     }
     if (use_bucket_mix(c) && !d_segs) {
         MixBucketBatch k;
@@ -576,20 +582,24 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
         while ((rc = ensure_bucket_mix(c, sub, k)) == DIVANS_GPU_ENOMEM && sub > 1024u) { (void)hipGetLastError(); sub = (sub + 1u) / 2u; }
         if (rc) return rc;
         k.blob = c->d_blob; k.stream_len = stream_len; k.max_stream_len = c->max_stream_len; k.pieces = bucket_pieces(c);
-        k.slot = bucket_slot(c); k.pos_stride = c->max_stream_len + BUCKET_SLOT_PAD;
+        k.slot = bucket_slot(c); k.pos_stride = k.slot;
+        k.sf = (uint32_t*)k.pos[0]; k.sf_stride = 2u * k.slot;  // mix_weights_kernel writes the pairs over the stride model's high records
         k.inc0 = c->geom.inc0; k.lim0 = c->geom.lim0; k.inc2 = c->geom.inc2; k.lim2 = c->geom.lim2; k.inc3 = c->geom.inc3; k.lim3 = c->geom.lim3;
+        view.sf = k.sf; view.stride = k.sf_stride;
+        view.spare = (uint8_t*)k.inv;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         for (uint32_t s0 = 0; s0 < n_streams; s0 += sub) {
             k.n_streams = std::min(sub, n_streams - s0);
             k.in = d_in_offsets ? d_in : d_in + (size_t)s0 * stream_len;
             k.in_offsets = d_in_offsets ? d_in_offsets + s0 : nullptr;
             k.in_sizes = d_in_sizes ? d_in_sizes + s0 : nullptr;
-            k.sf = c->d_sf + (size_t)s0 * 2u * c->max_stream_len;
             HIP_TRY(launch_bucket_mix_model(k, c->num_cus, c->stream));
+            view.spare_bytes = (size_t)sub * k.slot * 4u;
+            rc = after(s0, k.n_streams, view); if (rc) return rc;
         }
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         return 0;
     }
+    rc = ensure_sf(c, n_streams); if (rc) return rc;
     rc = ensure_tables(c); if (rc) return rc;
     LitBatch b;
     std::memset(&b, 0, sizeof(b));
@@ -602,7 +612,18 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
     if (d_segs && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    view.sf = c->d_sf; view.stride = 2u * c->max_stream_len;
+    return after(0u, n_streams, view);
+}
+
+// event pairs around the rANS launches of one encode call (one pair per sub-batch of the model pass)
+static int rans_event_pair(divans_gpu_codec* c, size_t i, hipEvent_t*& pair) {
+    while (c->ev_rans.size() < 2u * (i + 1u)) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        c->ev_rans.push_back(e);
+    }
+    pair = &c->ev_rans[2u * i];
     return 0;
 }
 
@@ -632,17 +653,29 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     if (out_slot % 16 != 0 || out_slot < divans_gpu_lit_encode_bound(d_in_sizes ? c->max_stream_len : stream_len))
         return fail(DIVANS_GPU_ECAP, "out_slot must be a multiple of 16 and >= divans_gpu_lit_encode_bound()");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, d_seg_begin, d_segs); if (rc) return rc;
-    RansBatch r;
-    r.sf = c->d_sf; r.n_streams = n_streams; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
-    r.in_sizes = d_in_sizes; r.out = d_out; r.out_slot = out_slot; r.out_offsets = d_out_offsets; r.out_sizes = d_out_sizes;
-    r.status = c->d_status; r.chunk_bytes = d_chunk_bytes; r.max_chunks = max_chunks;
-    r.scratch = nullptr; r.scratch_stride = 0; r.chunk0_sizes = nullptr;
-    if (c->max_stream_len > 32768u && c->max_stream_len <= 65536u) {   // two chunks per stream slot: one lane per chunk
-        rc = ensure_rans_scratch(c, n_streams, r); if (rc) return rc;
-    }
-    HIP_TRY(launch_rans_encode(r, c->stream));
+    const bool chunk_lanes = c->max_stream_len > 32768u && c->max_stream_len <= 65536u;   // two chunks per stream slot: one lane per chunk
+    size_t pairs = 0;
+    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, d_seg_begin, d_segs,
+                        [&](uint32_t first, uint32_t count, const SfView& v) -> int {
+        RansBatch r;
+        r.sf = v.sf; r.sf_stride = v.stride; r.n_streams = count; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
+        r.in_sizes = d_in_sizes ? d_in_sizes + first : nullptr;
+        r.out = d_out + (uint64_t)first * out_slot; r.out_base = (uint64_t)first * out_slot; r.out_slot = out_slot;
+        r.out_offsets = d_out_offsets + first; r.out_sizes = d_out_sizes + first;
+        r.status = c->d_status; r.chunk_bytes = d_chunk_bytes ? d_chunk_bytes + (size_t)first * max_chunks : nullptr; r.max_chunks = max_chunks;
+        r.scratch = nullptr; r.scratch_stride = 0; r.chunk0_sizes = nullptr;
+        if (chunk_lanes) { int rr = ensure_rans_scratch(c, count, v, r); if (rr) return rr; }
+        hipEvent_t* pair = nullptr;
+        int rr = rans_event_pair(c, pairs, pair); if (rr) return rr;
+        HIP_TRY(hipEventRecord(pair[0], c->stream));
+        HIP_TRY(launch_rans_encode(r, c->stream));
+        HIP_TRY(hipEventRecord(pair[1], c->stream));
+        ++pairs;
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    c->rans_pairs = pairs;
     c->timing_pending_enc = true;
     return 0;
 }
@@ -672,10 +705,17 @@ extern "C" int divans_gpu_lit_model_batch(divans_gpu_codec* c, const uint8_t* d_
     if ((d_in_offsets == nullptr) != (d_in_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
     if (stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "stream_len exceeds the codec's max_stream_len");
     HIP_TRY(hipSetDevice(c->device));
-    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams); if (rc) return rc;
+    const size_t row = (size_t)2u * c->max_stream_len * sizeof(uint32_t);
+    int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, nullptr, nullptr,
+                        [&](uint32_t first, uint32_t count, const SfView& v) -> int {
+        HIP_TRY(hipMemcpy2DAsync(d_pairs + (size_t)first * 2u * c->max_stream_len, row, v.sf, (size_t)v.stride * sizeof(uint32_t), row, count,
+                                 hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    });
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    c->rans_pairs = 0;
     c->timing_pending_enc = true;
-    HIP_TRY(hipMemcpyAsync(d_pairs, c->d_sf, (size_t)n_streams * 2u * c->max_stream_len * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -745,8 +785,14 @@ extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info)
     HIP_TRY(hipSetDevice(c->device));
     if (c->timing_pending_enc) {
         HIP_TRY(hipEventSynchronize(c->ev[2]));
-        HIP_TRY(hipEventElapsedTime(&c->last_model_ms, c->ev[0], c->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&c->last_rans_ms, c->ev[1], c->ev[2]));
+        float total = 0.f, rans = 0.f;
+        HIP_TRY(hipEventElapsedTime(&total, c->ev[0], c->ev[2]));
+        for (size_t i = 0; i < c->rans_pairs; ++i) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, c->ev_rans[2u * i], c->ev_rans[2u * i + 1u]));
+            rans += t;
+        }
+        c->last_rans_ms = rans; c->last_model_ms = total - rans;
         c->timing_pending_enc = false;
     }
     if (c->timing_pending_dec) {
@@ -758,7 +804,7 @@ extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info)
     info->resident_groups = resident_groups(c);
     info->blocks = c->blocks; info->threads = LIT_THREADS;
     info->table_bytes = (uint64_t)resident_groups(c) * c->geom.total_rows * 32u;
-    info->scratch_bytes = c->sf_bytes;
+    info->scratch_bytes = c->sf_bytes + c->bk_bytes + c->rs_bytes;
     info->last_model_ms = c->last_model_ms; info->last_rans_ms = c->last_rans_ms; info->last_decode_ms = c->last_decode_ms;
     return 0;
 }
@@ -834,7 +880,7 @@ extern "C" int divans_gpu_selftest_rans_pairs(divans_gpu_codec* c, const uint32_
     if (e == hipSuccess) {
         RansBatch r;
         std::memset(&r, 0, sizeof(r));
-        r.sf = d_sf; r.n_streams = 1; r.stream_len = len; r.max_stream_len = len; r.in_sizes = nullptr;
+        r.sf = d_sf; r.n_streams = 1; r.stream_len = len; r.max_stream_len = len; r.sf_stride = 2u * len; r.in_sizes = nullptr;
         r.out = d_out; r.out_slot = slot; r.out_offsets = d_off; r.out_sizes = d_sz; r.status = c->d_status;
         e = launch_rans_encode(r, c->stream);   // scratch == null: the one-lane-per-stream kernel, any number of chunks
     }

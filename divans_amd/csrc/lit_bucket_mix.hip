@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
 
     bool has_task = false, fresh_finish = false, exhausted = false;
     uint32_t piece = 0, left = 0, idx = 0;
-    u32x2* cur_h = b.rec_high; u32x2* cur_l = b.rec_low; const uint16_t* cur_sorted = b.sorted;
+    u32x2* const rec_h = b.pos[2 * MODEL]; u32x2* const rec_l = b.pos[2 * MODEL + 1];
+    u32x2* cur_h = rec_h; u32x2* cur_l = rec_l; const uint16_t* cur_sorted = b.sorted;
     uint32_t nt_stage = 0, nt_tid = 0;
     u32x4 nd0 = {0u, 0u, 0u, 0u}, nd1 = {0u, 0u, 0u, 0u};
     uint32_t win_cur = 0, win_end = 0, nxt_val = 0, nxt_w = 0;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
                 *(u32x4*)mydesc = nd0; *(u32x4*)(mydesc + 4) = nd1;
                 for (uint32_t r = 0; r < G::NR; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
                 const size_t slot = (size_t)(nt_tid >> 8) * pl;
-                cur_h = b.rec_high + slot; cur_l = b.rec_low + slot; cur_sorted = b.sorted + slot;
+                cur_h = rec_h + slot; cur_l = rec_l + slot; cur_sorted = b.sorted + slot;
                 piece = 0u; left = 0u; has_task = true; nt_stage = 0u;
             }
         }
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(64) void mix_weights_kernel(const MixBucketBatch b)
             const uint32_t j = i * 8u + mj, p = p0 + 2u * mq;
             const uint32_t slen = s0 + j < b.n_streams ? (b.in_sizes ? b.in_sizes[s0 + j] : b.stream_len) : 0u;
             if (p < slen)   // an odd stream's last quad carries one stale pair: it stays inside the (even) slot and is never read
-                *(u32x4*)(b.sf + 2u * ((size_t)(s0 + j) * b.max_stream_len + p)) = *(const u32x4*)(lds_out + j * MW_OUT_STRIDE + mq * 16u);
+                *(u32x4*)(b.sf + (size_t)(s0 + j) * b.sf_stride + 2u * p) = *(const u32x4*)(lds_out + j * MW_OUT_STRIDE + mq * 16u);
         }
         if (c + 1u < chunks) { MW_STAGE(buf ^ 1u) }
         __syncthreads();
@@ -376,7 +377,7 @@ hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hi
     BucketBatch v;                       // the view the shared task-list and unsort kernels take
     v.in = b.in; v.in_offsets = b.in_offsets; v.in_sizes = b.in_sizes;
     v.n_streams = b.n_streams; v.stream_len = b.stream_len; v.max_stream_len = b.max_stream_len; v.pieces = b.pieces;
-    v.slot = b.slot; v.sf_stride = 2u * b.pos_stride;
+    v.slot = b.slot; v.sf_stride = 2u * b.pos_stride;   // pos_stride == slot: the unsort below is in place
     v.sorted = nullptr; v.inv = b.inv; v.desc = b.desc; v.sfs = nullptr; v.sf = nullptr; v.tasks = b.tasks; v.counters = b.counters;
     v.inc = 0; v.lim = 0;
     for (int model = 0; model < 2; ++model) {
@@ -395,9 +396,9 @@ hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hi
             launch_bucket_tasks(v, st);
             hipLaunchKernelGGL(mix_chain_kernel<1>, dim3(num_cus * MX_CHAIN_WAVES), dim3(64), MxGeom<1>::LDS_BYTES, st, b);
         }
-        v.sfs = b.rec_high; v.sf = (uint32_t*)b.pos[2 * model];
+        v.sfs = b.pos[2 * model]; v.sf = (uint32_t*)b.pos[2 * model];
         launch_bucket_unsort(v, st);
-        v.sfs = b.rec_low; v.sf = (uint32_t*)b.pos[2 * model + 1];
+        v.sfs = b.pos[2 * model + 1]; v.sf = (uint32_t*)b.pos[2 * model + 1];
         launch_bucket_unsort(v, st);
     }
     hipLaunchKernelGGL(mix_weights_kernel, dim3((b.n_streams + 31u) / 32u), dim3(64), 0, st, b);

@@ -68,6 +68,9 @@ constexpr uint32_t LIT_STATUS_BAD_STREAM = 2u;    // decode: a chunk did not end
 
 struct RansBatch {
     const uint32_t* sf; uint32_t n_streams, stream_len, max_stream_len; const uint32_t* in_sizes;
+    uint32_t sf_stride;         // u32 elements per stream in sf (a multiple of 4): 2 * max_stream_len, or the work-array slot when the
+                                // model pass left the pairs in place (BucketBatch::sfs / MixBucketBatch::pos[0])
+    uint64_t out_base;          // added to the offsets written to out_offsets: `out` points at the first slot of a sub-batch
     uint8_t* out; uint64_t out_slot; uint64_t* out_offsets; uint32_t* out_sizes; uint32_t* status;
     uint32_t* chunk_bytes; uint32_t max_chunks;   // optional [n_streams][max_chunks] coded size of every 65 536-symbol chunk
     // chunk-parallel variant (streams of at most two chunks): chunk 0 is coded into scratch + (s + 1) * scratch_stride
@@ -104,16 +107,19 @@ struct MixBucketBatch {
     uint32_t pieces;            // 8 KiB pieces per stream slot, at most 8
     uint32_t slot;              // elements per stream in sorted / inv / rec_high / rec_low (see BucketBatch::slot)
     uint32_t pos_stride;        // elements per stream in pos[]
+    uint32_t sf_stride;         // u32 elements per stream in sf
     const uint8_t* blob;        // configuration tables (LIT_BLOB_LUT1CLASS, LIT_BLOB_CTXF of the one block type)
     uint16_t* sorted;           // [n_streams][pieces * 8192] byte | high-row slot << 8, every piece ordered by (key, position)
     uint16_t* inv;              // [n_streams][pieces * 8192] slot of a position inside its sorted piece
     uint32_t* desc;             // [n_streams][256 keys][8 pieces] first slot | count << 16
     uint32_t* tasks;            // [6 size classes][n_streams * 256]
     uint32_t* counters;
-    bk_u32x2* rec_high;         // [n_streams][pieces * 8192] sorted order: {cdf[sym] | cdf[sym-1] << 16, cdf[15]} of the high nibble's row
-    bk_u32x2* rec_low;          //   ... of the low nibble's row, both BEFORE the row is blended with the symbol
-    bk_u32x2* pos[4];           // the same records in position order [n_streams][max_stream_len]: stride high, stride low, cm high, cm low
-    uint32_t* sf;               // [n_streams][2 * max_stream_len] what rans_encode_kernel reads
+    // [n_streams][slot] records {cdf[sym] | cdf[sym-1] << 16, cdf[15]} of a nibble's row BEFORE the row is blended with the
+    // symbol: stride high, stride low, cm high, cm low.  The chains write them in sorted order; bucket_unsort_kernel puts every
+    // piece back into position order in place (it holds a whole piece in LDS before it writes)
+    bk_u32x2* pos[4];
+    uint32_t* sf;               // [n_streams][sf_stride] what rans_encode_kernel reads; may be pos[0] (mix_weights_kernel reads a
+                                // chunk of all four planes before it writes that chunk's pairs)
     int32_t inc0, lim0, inc2, lim2, inc3, lim3;   // literal_adaptation[0] (stride rows), [2] (cm low), [3] (cm high)
 };
 hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hipStream_t st);

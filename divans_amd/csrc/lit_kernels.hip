@@ -404,7 +404,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
     if (s >= b.n_streams) return;
     const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
     const uint32_t nsym = 2u * len;
-    const uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;   // 16-byte aligned: max_stream_len*8 bytes per stream
+    const uint32_t* sf = b.sf + (size_t)s * b.sf_stride;   // 16-byte aligned: sf_stride is a multiple of 4
     uint8_t* slot_end = b.out + (uint64_t)(s + 1) * b.out_slot;
     uint32_t* wp = (uint32_t*)slot_end;
     uint32_t* chunk_top = wp;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
             chunk_top = wp;
         }
     }
-    uint64_t off = (uint64_t)((uint8_t*)wp - b.out);
+    uint64_t off = (uint64_t)((uint8_t*)wp - b.out) + b.out_base;
     b.out_offsets[s] = off;
     b.out_sizes[s] = (uint32_t)(slot_end - (uint8_t*)wp);
     if (bad) atomicOr(b.status, LIT_STATUS_BAD_MODEL);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode2_kernel(const RansBa
     uint32_t size = 0, bad = 0;
     if (live && beg < nsym) {
         const uint32_t end = beg + 65536u < nsym ? beg + 65536u : nsym;
-        const uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
+        const uint32_t* sf = b.sf + (size_t)s * b.sf_stride;
         uint8_t* top = ck ? slot_end : b.scratch + (uint64_t)(s + 1) * b.scratch_stride;
         uint32_t* wp = rans_encode_chunk(sf, beg, end, (uint32_t*)top, bad);
         size = (uint32_t)(top - (uint8_t*)wp);
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode2_kernel(const RansBa
     if (live && ck == 0u) {
         const uint32_t total = size + other;
         b.out_sizes[s] = total;
-        b.out_offsets[s] = (uint64_t)(slot_end - b.out) - total;
+        b.out_offsets[s] = (uint64_t)(slot_end - b.out) - total + b.out_base;
         b.chunk0_sizes[s] = size;
     }
     if (bad) atomicOr(b.status, LIT_STATUS_BAD_MODEL);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void rans_stitch_kernel(const RansBatch b) {
     for (uint32_t s = wave; s < b.n_streams; s += nw) {
         const uint32_t words = b.chunk0_sizes[s] >> 2;
         const uint32_t* src = (const uint32_t*)(b.scratch + (uint64_t)(s + 1) * b.scratch_stride) - words;
-        uint32_t* dst = (uint32_t*)(b.out + b.out_offsets[s]);
+        uint32_t* dst = (uint32_t*)(b.out + (b.out_offsets[s] - b.out_base));
         for (uint32_t i = lane; i < words; i += 64u) dst[i] = __builtin_nontemporal_load(src + i);
     }
 }

@@ -177,7 +177,7 @@ typedef struct divans_gpu_info {
     uint32_t resident_groups;      /* streams decoded concurrently (16-lane groups in the persistent grid) */
     uint32_t blocks, threads;      /* launch geometry of the model/decode kernels */
     uint64_t table_bytes;          /* HBM bytes of the CDF tables */
-    uint64_t scratch_bytes;        /* HBM bytes of the start/freq spill (encode) */
+    uint64_t scratch_bytes;        /* HBM bytes of the encoder's work memory: bucketed-pass work arrays, start/freq spill, rANS chunk scratch */
     float last_model_ms, last_rans_ms, last_decode_ms; /* hipEvent timings of the last batch calls */
 } divans_gpu_info;
 int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);

@@ -430,6 +430,47 @@ def test_bucketed_encoder_many_streams_both_paths_agree(cfg_name, corpus):
     codec.close()
 
 
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_encoder_sub_batches_of_two_chunk_streams(cfg_name, corpus):
+    # 64 KiB slots: the chunk-parallel rANS pass keeps its scratch in the model pass's dead work arrays and reads the pairs
+    # where the in-place unsort left them; the two-model pass runs 70 streams as sub-batches of 24, 24, 22 and the rANS pass
+    # of each sub-batch is enqueued before the next one reuses the arrays.  Ragged: one- and two-chunk streams mixed.
+    import torch
+    import divans_amd as da
+    dev = torch.device("cuda", 0)
+    n, L = 70, 65536
+    blocks = workload.make_blocks(corpus, 5, n, block_len=L)
+    lens = (20000 + np.arange(n) * 7919 % (L - 20000 + 1)).astype(np.int32)
+    lens[:6] = [L, 32768, 32769, 1, 0, L - 1]
+    starts = np.arange(n, dtype=np.int64) * L
+    d_in = torch.from_numpy(np.concatenate([blocks.reshape(-1), np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(starts).to(dev); d_sz = torch.from_numpy(lens).to(dev)
+    codec = da.LiteralCodec(da.config_simple() if cfg_name == "simple" else da.config_context_mixing(), L)
+    codec.set_bucket_batch(24)
+    got = []
+    for path in (2, 1):
+        codec.set_encode_path(path)
+        outs = codec.alloc_encode_outputs(n)
+        chunks = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
+        codec.encode_batch(d_in, n, L, outs, in_offsets=d_off, in_sizes=d_sz, chunk_bytes=chunks)
+        pairs = codec.model_batch(d_in, n, L, in_offsets=d_off, in_sizes=d_sz)
+        torch.cuda.synchronize()
+        assert codec.status() == 0
+        got.append((outs["offsets"].cpu().numpy(), outs["sizes"].cpu().numpy(), outs["out"].cpu().numpy(), chunks.cpu().numpy(), pairs.cpu().numpy()))
+    (o2, s2, b2, c2, p2), (o1, s1, b1, c1, p1) = got
+    assert (s2 == s1).all() and (o2 == o1).all()
+    for i in range(n):
+        assert (b2[o2[i]:o2[i] + s2[i]] == b1[o1[i]:o1[i] + s1[i]]).all(), i
+        nch = (2 * int(lens[i]) + 65535) // 65536
+        assert (c2[i, :nch] == c1[i, :nch]).all() and int(c2[i, :nch].sum()) == int(s2[i]), i
+        assert (p2[i, :2 * lens[i]] == p1[i, :2 * lens[i]]).all(), i
+    ocfg = _oracle_cfg(cfg_name)
+    for i in (0, 1, 2, 3, 5, 23, 24, 47, 48, 69):
+        ref = po.lit_encode(ocfg, blocks[i][:lens[i]])
+        assert s2[i] == ref.size and (b2[o2[i]:o2[i] + s2[i]] == ref).all(), i
+    codec.close()
+
+
 def test_bucketed_encoder_only_where_it_applies():
     import ctypes
     import divans_amd as da
