@@ -279,7 +279,7 @@ static void configure_from_geometry(divans_gpu_codec* c) {
     c->dm_shift |= 0x80000000u;   // 2-way organisation (generation 3): fewer misses than direct mapped at the same time per byte
     {
         const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
-        const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) +
+        const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) + 256u /* byte ranks */ +
                                     (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
         const uint32_t fit = (160u * 1024u) / lds_per_wg;
         c->blocks2 = c->num_cus * std::max(1u, std::min(7u, fit));
@@ -493,7 +493,7 @@ extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t genera
         c->dm_shift = sh | (two_way ? 0x80000000u : 0u);
     }
     const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
-    const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) +
+    const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) + 256u /* byte ranks */ +
                                 (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
     const uint32_t fit = (160u * 1024u) / lds_per_wg;
     if (fit == 0u) return fail(DIVANS_GPU_EINVAL, "these caches do not fit the 160 KB of LDS");

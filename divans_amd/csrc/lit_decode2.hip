@@ -27,18 +27,48 @@
 #ifndef DIVANS_D2_W7
 #define DIVANS_D2_W7 1
 #endif
+#ifndef DIVANS_D2_PERM          // stride-1 instances: index the tables by a text-frequency rank of the previous byte (BytePerm)
+#define DIVANS_D2_PERM 1
+#endif
+#ifndef DIVANS_D2_LOAD_AUX      // cache-policy bits of the row loads / stores that go to memory: 1 = sc0, 2 = nt, 16 = sc1
+#define DIVANS_D2_LOAD_AUX 0
+#endif
+#ifndef DIVANS_D2_STORE_AUX
+#define DIVANS_D2_STORE_AUX 0
+#endif
 
 namespace divans_hip {
 
 namespace {
 
 // LDS is addressed with 32-bit byte addresses (address space 3): no generic-pointer arithmetic in the byte loop
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_read16(uint32_t a) { return *(const lds_u16*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_write16(uint32_t a, uint32_t v) { *(lds_u16*)(uintptr_t)a = (uint16_t)v; }
+__device__ __forceinline__ uint32_t lds_read8(uint32_t a) { return *(const lds_u8*)(uintptr_t)a; }
 __device__ __forceinline__ uint32_t lds_read32(uint32_t a) { return *(const lds_u32*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_write32(uint32_t a, uint32_t v) { *(lds_u32*)(uintptr_t)a = v; }
+
+// Which 128-byte line of a stream's table a row shares with three others is free to choose (the table is private to the launch,
+// any bijection of the row index decodes the same bytes), and it decides how many of the stream's row accesses the L2 can serve:
+// with 28 672 resident streams a stream owns about 1 KB of it, eight lines.  The stride-1 tables are indexed by the previous
+// byte; its four neighbours in a line are the next byte values in THIS order instead of numeric order -- lower-case letters by
+// their usual English frequency first, then the separators, capitals, digits, everything else numerically -- so that the bytes
+// text keeps coming back to sit together (an LRU model of 1 KB per stream misses 51 % instead of 67 % of the low-row accesses
+// of the benchmark text; for data without such a skew the order is as good as any other).
+struct BytePerm {
+    uint8_t rank[256];
+    constexpr BytePerm() : rank{} {
+        const char order[] = " etaoinshrdlcumwfgypbvkjxqz\n,.;'\"-!?:()TAISOWHBCMNEPDLFRGYUVKJQXZ0123456789";
+        bool used[256] = {};
+        uint32_t n = 0;
+        for (uint32_t i = 0; i + 1u < sizeof(order); ++i) { const uint8_t b = (uint8_t)order[i]; if (!used[b]) { used[b] = true; rank[b] = (uint8_t)n++; } }
+        for (uint32_t b = 0; b < 256u; ++b) if (!used[b]) rank[b] = (uint8_t)n++;
+    }
+};
+__device__ const BytePerm kBytePerm{};
 
 constexpr uint32_t kRingWords = 32u;
 constexpr uint32_t kRingBytes = kRingWords * 4u;
@@ -62,10 +92,10 @@ struct Table2 {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t lane_off;   // row-of-lanes slab offset + 2 * lane-in-row
     __device__ __forceinline__ int gload(uint32_t row) const {
-        return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, 0);
+        return (int)__builtin_amdgcn_raw_buffer_load_b16(rsrc, lane_off + (row << 5), 0, DIVANS_D2_LOAD_AUX);
     }
     __device__ __forceinline__ void gstore(uint32_t row, int v) const {
-        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, rsrc, lane_off + (row << 5), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, rsrc, lane_off + (row << 5), 0, DIVANS_D2_STORE_AUX);
     }
     // A high-nibble row fetched on a cache miss is requested one nibble ahead and first used at the top of the next byte.  The
     // vector-memory counter covers loads AND stores (and a store may be acknowledged before an older load has returned, so only
@@ -194,9 +224,12 @@ struct WordRing {
 template <bool NEED8>
 struct History {
     uint64_t last8; uint32_t p1, p2;
-    __device__ __forceinline__ void set(uint64_t v) { last8 = v; p1 = (uint32_t)(v >> 56); p2 = (uint32_t)(v >> 48) & 0xffu; }
-    __device__ __forceinline__ void push(uint32_t byte) {
+    uint32_t pb;         // rank of p1 in BytePerm's order (stride-1 instances), read from the LDS copy at perm_off
+    uint32_t perm_off;
+    __device__ __forceinline__ void set(uint64_t v, bool perm) { last8 = v; p1 = (uint32_t)(v >> 56); p2 = (uint32_t)(v >> 48) & 0xffu; if (perm) pb = lds_read8(perm_off + p1); }
+    __device__ __forceinline__ void push(uint32_t byte, bool perm) {
         p2 = p1; p1 = byte;
+        if (perm) pb = lds_read8(perm_off + byte);
         if (NEED8) last8 = (last8 >> 8) | ((uint64_t)byte << 56);
     }
     __device__ __forceinline__ uint32_t stride_byte(uint32_t offset_bits) const { return NEED8 ? (uint32_t)(last8 >> (56u - offset_bits)) & 0xffu : p1; }
@@ -213,7 +246,7 @@ __device__ __forceinline__ RowSel select_rows2(const LitGeometry& g, const uint8
     const uint32_t opt1 = (mm_opts == 1) ? 0xfu : 0u;
     uint32_t stride_offset = 0;
     if (mm_opts >= 4) { uint32_t x = mm_opts ^ 4u; stride_offset = (x < 7u ? x : 7u) << 3; }
-    const uint32_t sb = h.stride_byte(stride_offset);
+    const uint32_t sb = (DIVANS_D2_PERM && MM == 4) ? h.pb : h.stride_byte(stride_offset);
     uint32_t b, c, width;
     if (HIGH) { b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx; }
     else { b = ((mm & sb) | (~mm & ctx)) & 0xffu; c = (hi_nib & fast_cm) | ((ctx & opt1) << 4); width = g.low_width; }
@@ -403,6 +436,12 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
         tb.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    constexpr bool PERM = DIVANS_D2_PERM && MM == 4;
+    const uint32_t perm_off = lds_base + (uint32_t)(lv.mix - lv.base);   // behind the configuration tables (lit_lds_bytes2; MM >= 0: no mixing mask there)
+    if (PERM) {
+        if (threadIdx.x < 64u) lds_write32(perm_off + 4u * threadIdx.x, ((const uint32_t*)kBytePerm.rank)[threadIdx.x]);
+        __syncthreads();
+    }
     const uint32_t stream_base = lds_base + (threadIdx.x >> 4) * (b.cache_bytes_per_wg / (LIT_THREADS / 16));
     const Caches cc = make_caches<(CM & CM_2WAY) != 0>(b, stream_base, li);
     MixLanes ml;
@@ -420,11 +459,12 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
         int nh = 1 << 14, nl = 1 << 14;     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
         constexpr bool NEED8 = SEG || !(MM == 0 || MM == 4);
         History<NEED8> hist;
+        hist.perm_off = perm_off;
         uint64_t seg_last8 = 0;
         uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
         SegCursor sc;
         if (SEG) sc.start(b, s, seg_last8, ctab);
-        hist.set(seg_last8);
+        hist.set(seg_last8, PERM);
         uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];   // lut1 class of the byte before the previous one
         uint64_t SA = 0, SB = 0;      // state_a decodes high nibbles, state_b low nibbles (two symbols per byte)
         bool corrupt = false;
@@ -459,9 +499,9 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
                         const MixSearched mlo = search_mix2(mrowL, SB, nl, rbase);
                         const uint32_t lo = (uint32_t)mlo.s.sym;
                         const uint32_t byte = (hi << 4) | lo;
-                        hist.push(byte);
+                        hist.push(byte, PERM);
                         if (SEG) {   // the next Literal command starts from the ring buffer's last 8 bytes and its own block type
-                            if (--sc.left == 0u) { seg_last8 = hist.last8; sc.advance(g, seg_last8, ctab); hist.set(seg_last8); }
+                            if (--sc.left == 0u) { seg_last8 = hist.last8; sc.advance(g, seg_last8, ctab); hist.set(seg_last8, PERM); }
                         }
                         if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];
                         ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, hist.p1, k1);
@@ -486,8 +526,8 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
                         const Searched sl = search2(cvl, slot_b, rbase);
                         const uint32_t lo = (uint32_t)sl.sym;
                         const uint32_t byte = (hi << 4) | lo;
-                        hist.push(byte);
-                        if (SEG) { if (--sc.left == 0u) { seg_last8 = hist.last8; sc.advance(g, seg_last8, ctab); hist.set(seg_last8); } }
+                        hist.push(byte, PERM);
+                        if (SEG) { if (--sc.left == 0u) { seg_last8 = hist.last8; sc.advance(g, seg_last8, ctab); hist.set(seg_last8, PERM); } }
                         if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];
                         ctx_cur = context_of<CTXC>(g, lv.ctx, ctab, hist.p1, k1);
                         rowH = fetch2<true, MM, NEED8, CM>(g, lv, tb, cc, ctx_cur, hist, 0u);   // next byte's row (harmless past the end)
@@ -583,6 +623,7 @@ uint32_t lit_lds_bytes2(const LitBatch& b) {
     uint32_t bytes = b.cache_bytes_per_wg;
     if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTXF + LIT_CTXF_BYTES * b.geom.n_btypes;
     if (!(b.geom.mm_uniform == 0 || b.geom.mm_uniform == 4)) bytes += 8192u;
+    if (DIVANS_D2_PERM && b.geom.mm_uniform == 4) bytes += 256u;   // BytePerm's ranks
     return bytes;
 }
 

@@ -12,8 +12,18 @@ build () {  # name, extra flags
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_exp/libdivans_$1.so $OBJS gpurun_exp/lit_decode2_$1.o
   rm gpurun_exp/lit_decode2_$1.o
 }
-build noasync "-DDIVANS_D2_ASYNC=0" &
-build now7 "-DDIVANS_D2_W7=0" &
-build noasync_now7 "-DDIVANS_D2_ASYNC=0 -DDIVANS_D2_W7=0" &
+if [ "$1" = "noperm" ]; then
+  build noperm "-DDIVANS_D2_PERM=0" &
+elif [ "$1" = "cache_policy" ]; then
+  build ldnt "-DDIVANS_D2_LOAD_AUX=2" &
+  build stnt "-DDIVANS_D2_STORE_AUX=2" &
+  build ldstnt "-DDIVANS_D2_LOAD_AUX=2 -DDIVANS_D2_STORE_AUX=2" &
+  build stsc1 "-DDIVANS_D2_STORE_AUX=16" &
+  build ldsc0 "-DDIVANS_D2_LOAD_AUX=1" &
+else
+  build noasync "-DDIVANS_D2_ASYNC=0" &
+  build now7 "-DDIVANS_D2_W7=0" &
+  build noasync_now7 "-DDIVANS_D2_ASYNC=0 -DDIVANS_D2_W7=0" &
+fi
 wait
 ls -la gpurun_exp
