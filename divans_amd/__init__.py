@@ -132,6 +132,8 @@ def load_library():
     L.divans_gpu_lit_encode_batch_chunks.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp, vp, vp, u32]
     L.divans_gpu_lit_encode_batch_chunks.restype = ctypes.c_int
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
+    L.divans_gpu_speed_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    L.divans_gpu_speed_supported.restype = ctypes.c_int
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
     L.divans_gpu_selftest_cdf_ops.argtypes = [vp, vp, u32, vp]
     L.divans_gpu_selftest_rans_pairs.argtypes = [vp, vp, u32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
@@ -168,7 +170,7 @@ def exported_symbols():
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
-        "divans_gpu_selftest_division", "divans_gpu_codec_status", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
+        "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_codec_status", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
         "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
@@ -262,6 +264,11 @@ def config_context_mixing():
     c = LitConfig()
     load_library().divans_lit_config_context_mixing(ctypes.byref(c))
     return c
+
+
+def speed_supported(inc, lim):
+    """True when (inc, lim) is a literal_adaptation speed the GPU coder accepts (no row count ever leaves i16 under it)."""
+    return bool(load_library().divans_gpu_speed_supported(int(inc), int(lim)))
 
 
 def encode_bound(n):

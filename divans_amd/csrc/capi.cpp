@@ -131,6 +131,29 @@ struct divans_gpu_codec {
     bool timing_pending_enc = false, timing_pending_dec = false;
 };
 
+// A speed the kernels can run: every count of a row stays inside i16 for ever.  blend (probability/frequentist_cdf.rs:74-85) adds
+// `inc` to cdf[15] on every update whatever the symbol and then takes a quarter off once if the total reached `lim`, so the total
+// follows ONE trajectory from the default row's 64 -- with a large `inc` it settles near 4 * inc, far above `lim` -- and the
+// other entries stay below it.  The reference's i16 arithmetic wraps where this leaves 32767 (its row total turns negative and
+// the (start, freq) it derives stop describing a distribution); the kernels' 32-bit lanes do not, so such speeds are refused
+// instead of coded differently.
+extern "C" int divans_gpu_speed_supported(int32_t inc, int32_t lim) {
+    if (inc < 0 || lim <= 0 || inc > 0x4000 || lim > 0x4000) return 0;     // probability/interface.rs:341-365 (debug_asserts)
+    std::vector<uint8_t> seen(32768, 0);
+    int32_t v = 64;
+    while (!seen[v]) {
+        seen[v] = 1;
+        int32_t a = v + inc;
+        if (a > 0x7fff) return 0;
+        if (a >= lim) {
+            if (a + 16 > 0x7fff) return 0;              // the bias of entry 15 (CDF_BIAS)
+            a += 16; a -= a >> 2;
+        }
+        v = a;
+    }
+    return 1;
+}
+
 // Tables are built for the literal block types [bt_first, bt_first + n_btypes): one for a batch of single-segment
 // streams (cfg.btype), all of 0..max for streams with BlockSwitchLiteral commands between their segments.
 static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint32_t n_btypes, LitGeometry& g, std::vector<uint8_t>& blob) {
@@ -140,10 +163,8 @@ static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint
     if (cfg.context_mixing >= 15) return fail(DIVANS_GPU_EINVAL, "context_mixing must be < 15 (codec/interface.rs:359)");
     for (int i = 0; i < 4; ++i) {
         const divans_speed s = cfg.literal_adaptation[i];
-        // probability/interface.rs:341-365 debug_asserts inc,lim <= 0x4000; the kernels additionally rely on
-        // lim+inc+16 staying inside i16 so neither the count nor the renormalisation bias can wrap (blend_row)
-        if (s.inc < 0 || s.lim <= 0 || s.inc > 0x4000 || s.lim > 0x4000 || (int)s.inc + (int)s.lim + 16 > 0x7fff)
-            return fail(DIVANS_GPU_EINVAL, "literal_adaptation speed outside the supported range");
+        if (!divans_gpu_speed_supported(s.inc, s.lim))
+            return fail(DIVANS_GPU_EINVAL, "literal_adaptation speed outside the supported range (divans_gpu_speed_supported)");
     }
     const uint32_t mix_off = LIT_BLOB_CTXF + LIT_CTXF_BYTES * n_btypes;
     blob.assign(mix_off + DIVANS_GPU_NUM_MIXING_VALUES, 0);

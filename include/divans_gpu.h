@@ -211,6 +211,12 @@ int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, ui
  * returns the number of mismatches over every (cdf<<15)/max with 1<=max<32768, 0<=cdf<=max. */
 int divans_gpu_selftest_division(divans_gpu_codec *c, uint64_t *mismatches);
 
+/* 1 when divans_gpu_codec_create accepts (inc, lim) as a literal_adaptation speed: inc, lim within the reference's own bounds
+ * (src/probability/interface.rs:341-365) and no count of a row ever leaves i16 under it -- FrequentistCDF16::blend
+ * (src/probability/frequentist_cdf.rs:74-85) wraps there, after which a row's total is negative and what the reference codes with
+ * it is no longer a distribution; the GPU coder refuses such speeds rather than code them differently.  Host-only, needs no device. */
+int divans_gpu_speed_supported(int32_t inc, int32_t lim);
+
 /* Test entry points: device primitives in isolation, so that the reference's own unit tests can be run against them.
  * cdf_ops: a script of n_ops operations {kind, a, b, c} (4 x u32 each) on two CDF rows and one Weights object, one
  *   16 x i32 record per operation in `out`:  0/1 blend row 0/1 (a = symbol, b = inc, c = lim) -> the row;

@@ -85,3 +85,42 @@ def test_host_crc32c_paths_agree():
     a = ctypes.c_uint32(0); b = ctypes.c_uint32(0)
     L.divans_host_selftest_crc32c(kat.ctypes.data, kat.size, ctypes.byref(a), ctypes.byref(b))
     assert a.value == b.value == 0xE3069283          # CRC-32C check value
+
+
+def test_speed_supported_means_no_i16_wrap():
+    """divans_gpu_speed_supported (host-only) against the Python restatement's FrequentistCDF16::blend with its i16 wrapping:
+    an accepted speed never takes a count of a row out of i16 -- the kernels' 32-bit arithmetic and the reference's wrapping
+    arithmetic are then the same thing -- and the speeds it refuses are the ones under which the reference wraps."""
+    import numpy as np
+    import divans_amd as da
+    import ref_restatement as rr
+
+    def wraps(inc, lim, steps=400):
+        rng = np.random.default_rng(inc * 65537 + lim)
+        a = rr.Cdf(); plain = list(a.cdf)                    # plain: the same update in unbounded integers
+        for sym in rng.integers(0, 16, steps):
+            a.blend(int(sym), (inc, lim))
+            for i in range(int(sym), 16):
+                plain[i] += inc
+            if plain[15] >= lim:
+                plain = [(c + i + 1) - ((c + i + 1) >> 2) for i, c in enumerate(plain)]
+            if a.cdf != plain:
+                return True
+        return False
+
+    palette = [(0, 1024), (2, 1024), (1, 128), (1, 16384), (2, 2048), (4, 1024), (1, 0x4000), (4, 0xa00), (0x10, 0x2000), (0x20, 0x1000),
+               (0x30, 0x4000), (0x60, 0x4000), (0x80, 0x4000), (0x180, 0x4000)]       # probability/interface.rs:303-328
+    for inc, lim in palette:
+        assert da.speed_supported(inc, lim) and not wraps(inc, lim), (inc, lim)
+    for inc, lim in [(0x4000, 0x4000), (0x3000, 0x1000), (0x2000, 0x100), (0x4000, 1), (8180, 64), (0x3ff0, 0x4000)]:
+        assert not da.speed_supported(inc, lim) and wraps(inc, lim), (inc, lim)
+    for inc, lim in [(-1, 100), (1, 0), (0x4001, 100), (1, 0x4001)]:
+        assert not da.speed_supported(inc, lim)
+    rng = np.random.default_rng(11)
+    checked = 0
+    for _ in range(300):
+        inc = int(rng.integers(0, 0x4001)) >> int(rng.integers(0, 6)); lim = max(1, int(rng.integers(1, 0x4001)) >> int(rng.integers(0, 6)))
+        if da.speed_supported(inc, lim):
+            assert not wraps(inc, lim), (inc, lim)
+            checked += 1
+    assert checked > 50

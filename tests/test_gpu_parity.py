@@ -239,11 +239,41 @@ def test_brotli_derived_prediction_mode(btype, context_mixing, corpus):
 
 
 def test_unsupported_speed_is_rejected():
+    # speeds under which the reference's i16 row totals wrap (divans_gpu_speed_supported): (0x3000, 0x1000) climbs towards
+    # 4 * inc although inc + lim is small
     import divans_amd as da
-    g = da.config_simple()
-    g.literal_adaptation[0].inc = 0x4000; g.literal_adaptation[0].lim = 0x4000   # inc + lim would wrap an i16 CDF total
-    with pytest.raises(da.DivansGpuError):
-        da.LiteralCodec(g, 1024)
+    for inc, lim in [(0x4000, 0x4000), (0x3000, 0x1000), (8180, 64)]:
+        g = da.config_simple()
+        g.literal_adaptation[0].inc = inc; g.literal_adaptation[0].lim = lim
+        with pytest.raises(da.DivansGpuError):
+            da.LiteralCodec(g, 1024)
+
+
+@pytest.mark.parametrize("mixing", [0, 2])
+@pytest.mark.parametrize("encode_path", [1, 2])
+def test_speeds_whose_total_stays_above_lim(mixing, encode_path, corpus, random_then_unicode):
+    # large increments: the row total settles near 4 * inc, far above lim, and every update renormalises -- accepted as long as it
+    # stays inside i16 (the oracle's arithmetic wraps like the reference's, so agreement here means nothing wrapped)
+    import divans_amd as da
+    rng = np.random.default_rng(77 + mixing)
+    for speeds in ([(8000, 64), (8100, 16384), (4096, 16384), (8160, 1)], [(8100, 16384), (8000, 64), (8160, 1), (4096, 16384)]):
+        for sp in speeds:
+            assert da.speed_supported(*sp)
+        g, o = _random_config(rng, da, mixing, 0, [4], speeds)     # LSB6: the bucketed passes apply
+        L = 9000
+        blocks = np.stack([corpus[3000:3000 + L], random_then_unicode[100000:100000 + L], np.resize(np.frombuffer(b"abcabcabd", dtype=np.uint8), L),
+                           rng.integers(0, 256, L, dtype=np.uint8)])
+        codec = da.LiteralCodec(g, L)
+        codec.set_encode_path(encode_path)
+        packed, offs, sizes = codec.encode_host(blocks, L)
+        for i in range(blocks.shape[0]):
+            ref = po.lit_encode(o, blocks[i])
+            got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
+            assert got.size == ref.size and (got == ref).all(), (speeds, i)
+        for gen in (1, 3):
+            codec.set_decoder(gen)
+            assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), gen
+        codec.close()
 
 
 @pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
