@@ -492,7 +492,9 @@ class Mux {
 class CallSink {
   public:
     CallSink(std::vector<uint8_t>& out, size_t call_buffer) : out_(out), buf_(call_buffer ? call_buffer : 65536) {}
-    size_t room() { if (used_ == buf_) used_ = 0; return buf_ - used_; }   // a full buffer = NeedsMoreOutput, the caller returns with a new one
+    // A full buffer does not by itself end the call: the codec goes back to its caller only where a drain cannot finish or the
+    // Mux / header need room (new_call() at exactly those points); until then it keeps coding and the Mux keeps the bytes.
+    size_t room() const { return buf_ - used_; }
     uint8_t* reserve(size_t n) { out_.resize(out_.size() + n); return out_.data() + out_.size() - n; }
     void commit(size_t reserved, size_t used) { out_.resize(out_.size() - (reserved - used)); used_ += used; }
     void new_call() { used_ = 0; }
@@ -500,8 +502,23 @@ class CallSink {
     std::vector<uint8_t>& out_; size_t buf_, used_ = 0;
 };
 
-// drain_or_fill_static_buffer for an encoder, codec/interface.rs:868-895
-static void drain(Mux& mux, CallSink& sink, int id, const std::vector<uint8_t>& coder_out, size_t avail_end, size_t& drained) {
+// The application around the compressor (c/example.c:26-60): a call that returns NEEDS_MORE_OUTPUT is followed by another call with
+// an empty buffer.  Once an encode call has taken all of its input, that next call is the next piece's divans_encode or
+// divans_encode_flush, which first finishes the frozen commands (divans_compressor.rs:189-207): the NewCall step that follows in
+// the plan has then already happened.
+struct Calls {
+    CallSink& sink; bool input_done = false, next_call_started = false;
+    explicit Calls(CallSink& s) : sink(s) {}
+    void returns_for_output() { sink.new_call(); if (input_done) { input_done = false; next_call_started = true; } }
+    void next_call() { if (next_call_started) next_call_started = false; else sink.new_call(); input_done = false; }
+};
+
+// drain_or_fill_static_buffer for an encoder, codec/interface.rs:868-895: linearize what the Mux will give, make room in the
+// stream's buffer, pop; with coder bytes left and the caller's buffer full it reports NeedsMoreOutput -- which every caller hands
+// to the application (`retry`: the re-entered call repeats the drain) except code_nibble_array after the last byte of a Literal
+// (literal.rs:376-390: the command completes and the LIT coder keeps its bytes until the next LIT drain).
+static void drain(Mux& mux, Calls& calls, int id, const std::vector<uint8_t>& coder_out, size_t avail_end, size_t& drained, bool retry = true) {
+    CallSink& sink = calls.sink;
     while (drained < avail_end) {
         const size_t room = sink.room();
         uint8_t* p = sink.reserve(room);
@@ -512,6 +529,10 @@ static void drain(Mux& mux, CallSink& sink, int id, const std::vector<uint8_t>& 
         const size_t take = std::min(avail_end - drained, b.buf.size() - b.end);
         std::memcpy(b.buf.data() + b.end, coder_out.data() + drained, take);
         b.end += take; drained += take;
+        if (drained < avail_end && sink.room() == 0) {
+            if (!retry) return;
+            calls.returns_for_output();
+        }
     }
 }
 
@@ -580,7 +601,7 @@ int lit_config_from_prediction_mode(const StreamOptions& opt, const PredictionMo
 // Where the reference would emit ring bytes it never refilled (input ending inside the span a lap first writes at the end
 // of the ring: the index is reset regardless, :70-72), only the bytes actually written are emitted.
 struct RingEvents {
-    enum Kind { PredictionMode, Literal, NewCall };
+    enum Kind { PredictionMode, Literal, NewCall, InputDone };
     struct Event { Kind kind; size_t len; };
     std::vector<Event> events;
     size_t ring, decode = 0, output = 0, fresh_tail = 0;
@@ -609,6 +630,7 @@ struct RingEvents {
             }
             const bool full = decode == ring || decode + 1 == output;
             if (!full) break;
+            if (bytes == 0) events.push_back({InputDone, 0});   // what this flush emits is coded with the call's input all taken
             flush();
             if (bytes == 0) break;
         }
@@ -656,6 +678,7 @@ int plan_stream(const StreamOptions& opt, size_t n, const std::vector<size_t>* c
     uint64_t lit_syms = 0; uint32_t chunk_idx = 0;
     for (const RingEvents::Event& ev : ring.events) {
         if (ev.kind == RingEvents::NewCall) { plan.steps.push_back({StreamPlan::NewCall, 0}); continue; }
+        if (ev.kind == RingEvents::InputDone) { plan.steps.push_back({StreamPlan::InputDone, 0}); continue; }
         if (ev.kind == RingEvents::PredictionMode) {
             model.command_type(nc, 7);
             if (!model.prediction_mode(nc, &pm)) return DIVANS_GPU_EINVAL;
@@ -665,17 +688,20 @@ int plan_stream(const StreamOptions& opt, size_t n, const std::vector<size_t>* c
         model.command_type(nc, 3);
         uint32_t len_out;
         if (!model.literal_length(nc, (uint32_t)ev.len, len_out)) return DIVANS_GPU_EINVAL;
+        nc.before();
+        plan.steps.push_back({StreamPlan::LitDrain, 0});   // encode_or_decode_content_bytes drains the LIT coder before the first nibble (:426-433)
         // every 65 536th LIT symbol flushes a chunk, drained right after that nibble (literal.rs:309-315,368-374)
         const uint64_t end_syms = lit_syms + 2 * (uint64_t)ev.len;
         while ((lit_syms / 65536 + 1) * 65536 <= end_syms) {
             lit_syms = (lit_syms / 65536 + 1) * 65536;
-            plan.steps.push_back({StreamPlan::LitChunk, chunk_idx++});
+            plan.steps.push_back({lit_syms == end_syms ? StreamPlan::LitChunkLast : StreamPlan::LitChunk, chunk_idx++});
         }
         lit_syms = end_syms;
     }
     // DivansCodec::flush, codec/mod.rs:424-554: EOF nibble, EncodedShutdownNode, ShutdownCoder(0), ShutdownCoder(1), CoderBufferDrain
     model.command_type(nc, 0xf);
     nc.before();
+    plan.steps.push_back({StreamPlan::LitDrain, 0});   // EncodedShutdownNode: both coders drained
     cmd.flush();
     nc.before();
     if (lit_syms % 65536) plan.steps.push_back({StreamPlan::LitChunk, chunk_idx++});   // the partial last chunk
@@ -691,20 +717,30 @@ int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_si
     out.clear();
     Mux mux;
     CallSink sink(out, call_buffer);
+    Calls calls(sink);
     {   // header in the first encode() call, divans_compressor.rs:126-131,150-174
         uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)plan.window, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         size_t done = 0;
-        while (done < 16) { const size_t room = sink.room(), k = std::min<size_t>(16 - done, room); std::memcpy(sink.reserve(k), hdr + done, k); sink.commit(k, k); done += k; }
+        while (done < 16) {
+            if (sink.room() == 0) calls.returns_for_output();
+            const size_t room = sink.room(), k = std::min<size_t>(16 - done, room); std::memcpy(sink.reserve(k), hdr + done, k); sink.commit(k, k); done += k;
+        }
     }
     std::vector<uint8_t> lit_copy(lit, lit + lit_size);
     size_t cmd_drained = 0, lit_drained = 0, lit_avail = 0;
     for (const StreamPlan::Step& st : plan.steps) {
-        if (st.kind == StreamPlan::NewCall) sink.new_call();
-        else if (st.kind == StreamPlan::CmdAvail) drain(mux, sink, 0, plan.cmd, st.value, cmd_drained);
-        else { lit_avail += chunk_bytes[st.value]; if (lit_avail > lit_size) return DIVANS_GPU_EINVAL; drain(mux, sink, 1, lit_copy, lit_avail, lit_drained); }
+        if (st.kind == StreamPlan::NewCall) calls.next_call();
+        else if (st.kind == StreamPlan::InputDone) calls.input_done = true;
+        else if (st.kind == StreamPlan::CmdAvail) drain(mux, calls, 0, plan.cmd, st.value, cmd_drained);
+        else if (st.kind == StreamPlan::LitDrain) drain(mux, calls, 1, lit_copy, lit_avail, lit_drained);
+        else {
+            lit_avail += chunk_bytes[st.value]; if (lit_avail > lit_size) return DIVANS_GPU_EINVAL;
+            drain(mux, calls, 1, lit_copy, lit_avail, lit_drained, st.kind != StreamPlan::LitChunkLast);
+        }
     }
     if (lit_avail != lit_size || cmd_drained != plan.cmd.size()) return DIVANS_GPU_EINVAL;
     while (mux.eof != 3) {                          // MuxDrain
+        if (sink.room() == 0) calls.returns_for_output();
         const size_t room = sink.room();
         uint8_t* p = sink.reserve(room);
         const size_t k = mux.close(p, room);

@@ -45,8 +45,12 @@ int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, si
 // A stream split into the half that needs no literal data (CMD coder bytes, the order in which coder bytes reach the Mux)
 // and the half that does (assemble_container): the first runs on host threads while the GPU codes the literals.
 struct StreamPlan {
-    enum Kind : uint8_t { CmdAvail, LitChunk, NewCall };
-    struct Step { Kind kind; uint32_t value; };   // CmdAvail: CMD bytes available so far; LitChunk: chunk index whose bytes arrive; NewCall: fresh caller buffer
+    // CmdAvail: the CMD coder holds `value` bytes in all, drained before its next nibble; LitChunk: chunk `value` of the LIT coder
+    // completes and is drained; LitChunkLast: it completes on the LAST byte of its Literal command, where the drain's status is
+    // dropped (codec/literal.rs:376-390); LitDrain: a point where the LIT coder is drained again (start of a Literal's content,
+    // DivansCodec::flush); NewCall: the application's next call; InputDone: the current encode call has taken all of its input
+    enum Kind : uint8_t { CmdAvail, LitChunk, LitChunkLast, LitDrain, NewCall, InputDone };
+    struct Step { Kind kind; uint32_t value; };
     size_t n = 0; int window = 22;
     divans_lit_config cfg;                        // what the LIT coder runs under (from the stream's PredictionMode)
     std::vector<uint8_t> cmd;

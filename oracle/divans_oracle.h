@@ -190,7 +190,9 @@ typedef struct {                     /* what the codec's own PredictionModeConte
     const uint8_t *mixing_values;        /* 8192 */
 } orc_prediction_mode_result;
 enum { ORC_CMD_PREDICTION_MODE = 7, ORC_CMD_BLOCK_SWITCH_LITERAL = 4, ORC_CMD_LITERAL = 3,
-       ORC_CMD_NEW_CALL = 100 /* not a command: the current encode()/flush() call returns, the next one brings a fresh output buffer */ };
+       ORC_CMD_NEW_CALL = 100, /* not a command: the current encode()/flush() call returns, the next one brings a fresh output buffer */
+       ORC_CMD_INPUT_DONE = 101 /* not a command: the current encode() call has taken all of its input; if it now runs out of output,
+                                   the application's NEXT call (the following ORC_CMD_NEW_CALL) is the one that resumes it */ };
 typedef struct {
     int kind;
     orc_prediction_mode pm;

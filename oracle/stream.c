@@ -236,8 +236,11 @@ static void sink_reserve(sink *s, size_t extra) {
     while (nc < s->len + extra) nc *= 2;
     s->data = (uint8_t *)realloc(s->data, nc); s->cap = nc;
 }
-/* remaining room in the current call; a full buffer means the call returned NeedsMoreOutput and the caller came back */
-static size_t sink_room(sink *s) { if (s->call_used == s->call_buf) s->call_used = 0; return s->call_buf - s->call_used; }
+/* remaining room in the current call's buffer.  A full buffer does NOT by itself end the call: the codec only goes back to its
+ * caller where a drain cannot finish or the Mux / header / trailer need room (sink_new_call at exactly those points); until then
+ * it keeps coding and the Mux keeps the bytes (drain_or_fill_static_buffer, codec/interface.rs:868-896). */
+static size_t sink_room(sink *s) { return s->call_buf - s->call_used; }
+static void sink_new_call(sink *s) { s->call_used = 0; }
 static uint8_t *sink_ptr(sink *s, size_t want) { sink_reserve(s, want); return s->data + s->len; }
 static void sink_commit(sink *s, size_t n) { s->len += n; s->call_used += n; }
 
@@ -518,10 +521,24 @@ typedef struct {
     orc_mux mux; sink out; uint32_t crc;
     orc_ans_encoder cmd, lit;
     size_t cmd_drained, lit_drained;   /* bytes of enc.out already handed to the mux */
+    int input_done, next_call_started; /* see call_returns */
 } enc_ctx;
 
 /* drain_or_fill_static_buffer for an encoder, codec/interface.rs:868-895 */
-static void drain_coder(enc_ctx *e, int id) {
+/* The call returns NEEDS_MORE_OUTPUT and the application comes back with an empty buffer; what it comes back WITH decides whether
+ * a call boundary follows later: once an encode call has taken all of its input (input_done), the application's next call is the
+ * next piece's divans_encode or divans_encode_flush (c/example.c:31-46), which first finishes the frozen commands
+ * (divans_compressor.rs:189-207) -- the ORC_CMD_NEW_CALL marker that follows has then already happened. */
+static void call_returns(enc_ctx *e) {
+    sink_new_call(&e->out);
+    if (e->input_done) { e->input_done = 0; e->next_call_started = 1; }
+}
+/* drain_or_fill_static_buffer (codec/interface.rs:868-896) for an encoder: linearize what the Mux will give, make room in the
+ * stream's buffer, pop; with the coder still holding bytes and the caller's buffer full it reports NeedsMoreOutput.  `retry`: the
+ * caller of the drain hands that to the application and the re-entered call repeats the drain; 0 = the one place where the
+ * status is dropped (after the LAST byte of a Literal, literal.rs:376-390: the command completes, the LIT coder keeps its bytes
+ * until the next LIT drain).  Returns 1 when the coder is empty. */
+static int drain_coder(enc_ctx *e, int id, int retry) {
     orc_ans_encoder *enc = id == 0 ? &e->cmd : &e->lit;
     size_t *drained = id == 0 ? &e->cmd_drained : &e->lit_drained;
     while (*drained < enc->out.len) {
@@ -535,11 +552,14 @@ static void drain_coder(enc_ctx *e, int id) {
         size_t take = avail < space ? avail : space;
         memcpy(b->buf + b->end, enc->out.data + *drained, take);
         b->end += take; *drained += take;
-        /* NeedsMoreOutput with a full caller buffer returns to the caller, who comes back with a fresh one:
-         * sink_room() models that by starting a new call buffer */
+        if (*drained < enc->out.len && sink_room(&e->out) == 0) {
+            if (!retry) return 0;
+            call_returns(e);
+        }
     }
+    return 1;
 }
-static void drain_cmd_cb(void *p) { drain_coder((enc_ctx *)p, 0); }
+static void drain_cmd_cb(void *p) { (void)drain_coder((enc_ctx *)p, 0, 1); }
 
 static void lit_config_from_pm(orc_lit_config *cfg, const orc_prediction_mode_result *r, uint8_t btype, uint8_t mixing) {
     memcpy(cfg->literal_context_map, r->literal_context_map, sizeof(cfg->literal_context_map));
@@ -576,6 +596,7 @@ static size_t stream_compress_impl(const orc_stream_options *o, const orc_stream
         uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         size_t written = 0;
         while (written < 16) {
+            if (sink_room(&e.out) == 0) call_returns(&e);
             size_t room = sink_room(&e.out), n = 16 - written < room ? 16 - written : room;
             memcpy(sink_ptr(&e.out, n), hdr + written, n);
             sink_commit(&e.out, n); written += n;
@@ -601,26 +622,31 @@ static size_t stream_compress_impl(const orc_stream_options *o, const orc_stream
             cfg->btype = btype;
             orc_lit_state_reconfigure(ls, cfg);
         } else if (cm->kind == ORC_CMD_NEW_CALL) {
-            e.out.call_used = 0;
+            if (e.next_call_started) e.next_call_started = 0;     /* it began when the previous call ran out of output, see call_returns */
+            else sink_new_call(&e.out);
+            e.input_done = 0;
+        } else if (cm->kind == ORC_CMD_INPUT_DONE) {
+            e.input_done = 1;
         } else if (cm->kind == ORC_CMD_LITERAL) {
             if (cm->len == 0) { bad = 1; break; }
             code_command_type(c, &cc, drain_cmd_cb, &e, 3);
             uint32_t len_out;
             if (code_literal_length(c, &cc, drain_cmd_cb, &e, (uint32_t)cm->len, &len_out)) { bad = 1; break; }
-            drain_coder(&e, 1);                        /* literal.rs:426-433 */
-            for (size_t i = 0; i < cm->len; ++i) {     /* code_nibble_array drains the LIT coder after every nibble */
-                orc_lit_encode_bytes(ls, &e.lit, cm->data + i, 1);
-                drain_coder(&e, 1);
+            (void)drain_coder(&e, 0, 1); (void)drain_coder(&e, 1, 1);   /* literal.rs:496-520 (CMD), :426-433 (LIT) before the content */
+            for (size_t i = 0; i < cm->len; ++i) {     /* code_nibble_array drains the LIT coder after every nibble; a chunk only */
+                orc_lit_encode_bytes(ls, &e.lit, cm->data + i, 1);        /* ever completes on a low nibble (65 536 symbols, 2 per byte) */
+                (void)drain_coder(&e, 1, i + 1 != cm->len);
             }
         } else bad = 1;
     }
     if (!bad) {
         /* DivansCodec::flush, codec/mod.rs:424-554 */
         code_command_type(c, &cc, drain_cmd_cb, &e, 0xf);
-        drain_coder(&e, 0); drain_coder(&e, 1);          /* EncodedShutdownNode */
+        (void)drain_coder(&e, 0, 1); (void)drain_coder(&e, 1, 1);   /* EncodedShutdownNode */
         orc_ans_flush_chunk(&e.cmd); orc_ans_flush_chunk(&e.lit);   /* ShutdownCoder(0), (1) */
-        drain_coder(&e, 0); drain_coder(&e, 1);          /* CoderBufferDrain */
+        (void)drain_coder(&e, 0, 1); (void)drain_coder(&e, 1, 1);   /* CoderBufferDrain */
         while (e.mux.eof != 3) {                         /* MuxDrain */
+            if (sink_room(&e.out) == 0) call_returns(&e);
             size_t room = sink_room(&e.out);
             size_t n = mux_serialize_close(&e.mux, sink_ptr(&e.out, room), room);
             sink_commit(&e.out, n);
@@ -686,6 +712,7 @@ static void raw_sim_stream(raw_sim *r, size_t *pos, size_t call_end) {   /* Diva
             *pos += mc; r->dec += mc;
         }
         if (r->dec == r->ring || r->dec + 1 == r->outi) {     /* ring_buffer_full */
+            if (*pos == call_end) r->cmds[r->n++].kind = ORC_CMD_INPUT_DONE;   /* what follows is coded with the call's input all taken */
             raw_sim_flush(r);
             if (*pos != call_end) continue;
         }
@@ -699,7 +726,7 @@ size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, s
     memset(&r, 0, sizeof(r));
     r.ring = (size_t)1 << w; r.in = in;
     size_t ncalls = o->call_inputs ? o->n_call_inputs : 1;
-    r.cmds = (orc_stream_command *)calloc(2 * (n / (r.ring - 1) + 2) + ncalls + 8, sizeof(orc_stream_command));
+    r.cmds = (orc_stream_command *)calloc(2 * (n / (r.ring - 1) + 2) + 2 * ncalls + 8, sizeof(orc_stream_command));
     static uint8_t cmap[64], dmap[4], mixing[ORC_NUM_MIXING_VALUES];
     for (int i = 0; i < 64; ++i) cmap[i] = (uint8_t)(i & 0x3f);
     for (int i = 0; i < 4; ++i) dmap[i] = (uint8_t)(i & 3);
