@@ -89,6 +89,12 @@ DivansResult divans_set_option(struct DivansCompressorState* s, DivansOptionSele
     }
 }
 
+// Not in the reference's ABI: tells a caller that its settings asked for the brotli front end (the reference's default does) and
+// that this library codes the stream with the internal command selection instead -- valid, decodable by the reference, larger.
+uint8_t divans_compressor_uses_internal_command_selection_instead_of_brotli(const struct DivansCompressorState* s) {
+    return s && s->opt.use_brotli != 0 ? 1 : 0;
+}
+
 static bool start(DivansCompressorState* s) {
     s->started = true;
     // BrotliCompressionSetting (src/ffi/compressor.rs:168-210): the reference's default (UseBrotliCommandSelection) and

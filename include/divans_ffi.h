@@ -68,6 +68,10 @@ DivansResult divans_encode(struct DivansCompressorState *state, const uint8_t *i
 DivansResult divans_encode_flush(struct DivansCompressorState *state, uint8_t *output_buf_ptr, size_t output_size,
                                  size_t *output_offset);                                              /* mod.rs:94-108 */
 void divans_free_compressor(struct DivansCompressorState *mfd);                                       /* mod.rs:159-169 */
+/* Extension (not in c/divans/ffi.h): 1 when the state's options select the brotli front end -- DIVANS_OPTION_USE_BROTLI_COMMAND_SELECTION
+ * 1 (the reference's default) or 2 -- which this library replaces by the internal command selection (see the scope note above):
+ * the caller gets a valid .divans stream, not the one the reference would have produced.  0 after option 5 was set to 0. */
+uint8_t divans_compressor_uses_internal_command_selection_instead_of_brotli(const struct DivansCompressorState *state);
 
 struct DivansDecompressorState *divans_new_decompressor(void);                                        /* mod.rs:178-187 */
 struct DivansDecompressorState *divans_new_serial_decompressor(void);                                 /* mod.rs:189-198 */

@@ -124,3 +124,20 @@ def test_speed_supported_means_no_i16_wrap():
             assert not wraps(inc, lim), (inc, lim)
             checked += 1
     assert checked > 50
+
+
+def test_ffi_reports_the_command_selection_downgrade():
+    """ADVICE r02: the per-stream ABI replaces the brotli front end (the reference's default) by the internal command selection;
+    a caller can ask.  Host-only: no stream is coded."""
+    import divans_amd as da
+    L = da.load_library()
+    L.divans_new_compressor.restype = ctypes.c_void_p
+    L.divans_set_option.argtypes = [ctypes.c_void_p, ctypes.c_uint8, ctypes.c_uint32]; L.divans_set_option.restype = ctypes.c_uint8
+    q = L.divans_compressor_uses_internal_command_selection_instead_of_brotli
+    q.argtypes = [ctypes.c_void_p]; q.restype = ctypes.c_uint8
+    L.divans_free_compressor.argtypes = [ctypes.c_void_p]
+    st = L.divans_new_compressor()
+    assert q(st) == 1                                   # default = UseBrotliCommandSelection (src/ffi/compressor.rs:168-178)
+    assert L.divans_set_option(st, 5, 0) == 0 and q(st) == 0
+    assert L.divans_set_option(st, 5, 2) == 0 and q(st) == 1
+    L.divans_free_compressor(st)
