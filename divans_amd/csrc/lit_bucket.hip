@@ -152,9 +152,10 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     const u32x4 def0 = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
     const u32x4 def1 = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
 
-    // per-lane chain state
-    bool has_task = false, fresh_finish = false, exhausted = false;
-    uint32_t piece = 0, left = 0, idx = 0;
+    // per-lane chain state.  A bucket is up to eight runs of consecutive sorted slots, one per 8 KiB piece that holds some of its
+    // positions; the task's descriptors are compacted to the non-empty ones when the lane takes it (mydesc[0 .. nruns)).
+    bool has_task = false, exhausted = false;
+    uint32_t run_i = 0, nruns = 0, left = 0, idx = 0;
     u32x2* cur_sfs = b.sfs; const uint8_t* cur_sorted = b.sorted;   // the current bucket's stream slot
     uint32_t nt_stage = 0, nt_tid = 0;
     u32x4 nd0 = {0u, 0u, 0u, 0u}, nd1 = {0u, 0u, 0u, 0u};
@@ -162,85 +163,90 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
     uint32_t win_cur = 0, win_end = 0, nxt_val = 0, nxt_w = 0;
     const uint32_t long_end = lists.ends[3];     // tasks of at least 2048 positions come first
     bool nxt_pending = false, drained = false;
-    // four bytes in flight per lane: requested one loop iteration before they are coded
-    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    uint32_t e4 = 0, e5 = 0, e6 = 0, e7 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    // The chain is bound by the vector-memory path, not by its arithmetic (profiles/r03c_chain_role_experiment.txt), so a lane
+    // moves its bytes eight at a time: ONE aligned 8-byte load per iteration covers the sorted slots [base, base + 8), of which
+    // the run owns [first, first + cnt); it is requested one iteration before it is coded.  The (start, freq) pairs of a group
+    // leave at the top of the NEXT iteration -- four 16-byte stores for a full group -- through inline asm: the compiler then sees
+    // one load per iteration and waits for it with vmcnt(0) at a point where the only other operations in flight are stores a whole
+    // iteration old (a store is acknowledged out of order with loads, so no smaller count would prove the load complete).
+    u32x2 e_next = {0u, 0u}; uint32_t m_next = 0;           // meta: base | first << 16 | cnt << 20 | BK_VALID
+    u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0, pv4 = pv0, pv5 = pv0, pv6 = pv0, pv7 = pv0;
+    uint32_t m_prev = 0; u32x2* sfs_prev = b.sfs;
 
-    // Every step issues exactly one byte load (from a harmless address when the lane has nothing to fetch) and the
-    // pair store goes out through inline asm: the compiler then sees only in-order loads on vmcnt and waits with
-    // vmcnt(3) for a byte requested four steps earlier instead of draining the queue (a visible store next to the
-    // loads makes it fall back to vmcnt(0) on this target).  The hidden stores can only make that wait stricter.
 #define BK_OPAQUE(X) asm volatile("" : "+v"(X))
-#define BK_STEP(E, A, PV, PA, POS)                                                                                 \
-    {                                                                                                   \
-        BK_OPAQUE(E);  /* keeps the compiler from touching the byte (and waiting for it) before this point */ \
-        PA = A;                                                                                         \
-        if (A & BK_VALID) {                                                                             \
-            const uint32_t byte_ = E >> ((A >> 13) & 24u);   /* A bits 16-17: which byte of the aligned word */ \
-            const uint32_t hi = (byte_ >> 4) & 15u, lo = byte_ & 15u;                                   \
-            uint32_t* rowl = my + 8u * (1u + hi);                                                       \
-            BkRow H = bk_read(my, tab, hi), L = bk_read(rowl, tab, lo);                                 \
-            const u32x2 v = {bk_pack(H, hi), bk_pack(L, lo)};                                           \
-            H.w0 += H.a0; H.w1 += H.a1; L.w0 += L.a0; L.w1 += L.a1;   /* frequentist_cdf.rs:75-78 */    \
-            if ((int)(H.w1.w >> 16) >= lim) bk_renorm(H);                                               \
-            if ((int)(L.w1.w >> 16) >= lim) bk_renorm(L);                                               \
-            *(u32x4*)my = H.w0; *(u32x4*)(my + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
-            PV = v;                                                                                     \
-        }                                                                                               \
-        /* fetch side, branch-free: next piece of the bucket when the current one is used up (an empty piece costs \
-           the lane this step), then one more byte */                                                   \
-        {                                                                                               \
-            const bool adv = has_task && left == 0u, more = piece < b.pieces;                           \
-            const uint32_t d = mydesc[piece & 7u];                                                      \
-            if (adv && more) { left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece; }       \
-            if (adv && !more) { has_task = false; fresh_finish = true; }                                \
-        }                                                                                               \
-        /* slot idx is only taken by step idx % 8 of an iteration: its pairs then fill aligned sectors */        \
-        const bool fetch_ = has_task && left != 0u && (idx & 7u) == POS;                                \
-        const uint8_t* lp = fetch_ ? cur_sorted + (idx & ~3u) : b.sorted;                               \
-        const uint32_t nxt_a = fetch_ ? (idx | ((idx & 3u) << 16) | BK_VALID) : 0u;                     \
-        idx += fetch_ ? 1u : 0u; left -= fetch_ ? 1u : 0u;                                              \
-        E = *(const uint32_t*)lp; A = nxt_a;   /* whole aligned word: no extension op on the loaded register */ \
+#define BK_BYTE(K, WORD, PV)                                                                            \
+    if (((K - first) & 15u) < cnt) {                                                                    \
+        const uint32_t byte_ = (WORD >> (8u * (K & 3u))) & 0xffu;                                       \
+        const uint32_t hi = byte_ >> 4, lo = byte_ & 15u;                                               \
+        uint32_t* rowl = my + 8u * (1u + hi);                                                           \
+        BkRow H = bk_read(my, tab, hi), L = bk_read(rowl, tab, lo);                                     \
+        const u32x2 v = {bk_pack(H, hi), bk_pack(L, lo)};                                               \
+        H.w0 += H.a0; H.w1 += H.a1; L.w0 += L.a0; L.w1 += L.a1;   /* frequentist_cdf.rs:75-78 */        \
+        if ((int)(H.w1.w >> 16) >= lim) bk_renorm(H);                                                   \
+        if ((int)(L.w1.w >> 16) >= lim) bk_renorm(L);                                                   \
+        *(u32x4*)my = H.w0; *(u32x4*)(my + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
+        PV = v;                                                                                         \
     }
 
     for (;;) {
-        // eight steps per iteration (eight words in flight per lane); slot idx is taken by step idx % 8, and the pairs leave
-        // after the eighth step as two groups of four: a 32-byte run each when the four are neighbours in the sorted order
-        // (the usual case inside a bucket; both together then fill one aligned 64 bytes), single pairs otherwise
-#define BK_STORE4(PV0, PA0, PV1, PA1, PV2, PA2, PV3, PA3)                                               \
-        {                                                                                               \
-            const uint32_t i0 = PA0 & 0xffffu;                                                          \
-            const bool run4 = (PA0 & PA1 & PA2 & PA3 & BK_VALID) && (PA1 & 0xffffu) == i0 + 1u && (PA2 & 0xffffu) == i0 + 2u && (PA3 & 0xffffu) == i0 + 3u; \
-            if (run4) {                                                                                 \
-                const u32x4 lo = {PV0.x, PV0.y, PV1.x, PV1.y}, hi = {PV2.x, PV2.y, PV3.x, PV3.y};       \
-                bk_store_quad((u32x4*)(cur_sfs + i0), lo); bk_store_quad((u32x4*)(cur_sfs + i0 + 2u), hi); \
-            } else {                                                                                    \
-                if (PA0 & BK_VALID) bk_store_pair(cur_sfs + i0, PV0);                                   \
-                if (PA1 & BK_VALID) bk_store_pair(cur_sfs + (PA1 & 0xffffu), PV1);                      \
-                if (PA2 & BK_VALID) bk_store_pair(cur_sfs + (PA2 & 0xffffu), PV2);                      \
-                if (PA3 & BK_VALID) bk_store_pair(cur_sfs + (PA3 & 0xffffu), PV3);                      \
-            }                                                                                           \
+        u32x2 e = e_next; const uint32_t m = m_next;
+        // 1. the previous group's pairs leave (their registers are free again below)
+        if (m_prev & BK_VALID) {
+            u32x2* dst = sfs_prev + (m_prev & 0xffffu);
+            const uint32_t pf = (m_prev >> 16) & 15u, pc = (m_prev >> 20) & 15u;
+            if (pc == 8u) {
+                const u32x4 q0 = {pv0.x, pv0.y, pv1.x, pv1.y}, q1 = {pv2.x, pv2.y, pv3.x, pv3.y};
+                const u32x4 q2 = {pv4.x, pv4.y, pv5.x, pv5.y}, q3 = {pv6.x, pv6.y, pv7.x, pv7.y};
+                bk_store_quad((u32x4*)dst, q0); bk_store_quad((u32x4*)(dst + 2), q1);
+                bk_store_quad((u32x4*)(dst + 4), q2); bk_store_quad((u32x4*)(dst + 6), q3);
+            } else {
+                if (((0u - pf) & 15u) < pc) bk_store_pair(dst + 0, pv0);
+                if (((1u - pf) & 15u) < pc) bk_store_pair(dst + 1, pv1);
+                if (((2u - pf) & 15u) < pc) bk_store_pair(dst + 2, pv2);
+                if (((3u - pf) & 15u) < pc) bk_store_pair(dst + 3, pv3);
+                if (((4u - pf) & 15u) < pc) bk_store_pair(dst + 4, pv4);
+                if (((5u - pf) & 15u) < pc) bk_store_pair(dst + 5, pv5);
+                if (((6u - pf) & 15u) < pc) bk_store_pair(dst + 6, pv6);
+                if (((7u - pf) & 15u) < pc) bk_store_pair(dst + 7, pv7);
+            }
+        }
+        // 2. the next group of the run is requested (every lane issues exactly one load, from a harmless address if it has nothing
+        //    to fetch), the next run of the bucket taken when this one is used up
+        {
+            const bool adv = has_task && left == 0u, more = run_i < nruns;
+            const uint32_t d = mydesc[run_i & 7u];
+            if (adv && more) { left = d >> 16; idx = d & 0xffffu; ++run_i; }
+            if (adv && !more) has_task = false;
         }
         {
-            u32x2 pv0 = {0u, 0u}, pv1 = pv0, pv2 = pv0, pv3 = pv0, pv4 = pv0, pv5 = pv0, pv6 = pv0, pv7 = pv0;
-            uint32_t pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7;
-            BK_STEP(e0, a0, pv0, pa0, 0u) BK_STEP(e1, a1, pv1, pa1, 1u) BK_STEP(e2, a2, pv2, pa2, 2u) BK_STEP(e3, a3, pv3, pa3, 3u)
-            BK_STEP(e4, a4, pv4, pa4, 4u) BK_STEP(e5, a5, pv5, pa5, 5u) BK_STEP(e6, a6, pv6, pa6, 6u) BK_STEP(e7, a7, pv7, pa7, 7u)
-            BK_STORE4(pv0, pa0, pv1, pa1, pv2, pa2, pv3, pa3)
-            BK_STORE4(pv4, pa4, pv5, pa5, pv6, pa6, pv7, pa7)
+            const bool fetch_ = has_task && left != 0u;
+            const uint32_t base = idx & ~7u, first_ = idx & 7u;
+            const uint32_t cnt_ = left < 8u - first_ ? left : 8u - first_;
+            const uint8_t* lp = fetch_ ? cur_sorted + base : b.sorted;
+            e_next = *(const u32x2*)lp;
+            m_next = fetch_ ? (base | (first_ << 16) | (cnt_ << 20) | BK_VALID) : 0u;
+            idx += fetch_ ? cnt_ : 0u; left -= fetch_ ? cnt_ : 0u;
         }
-#undef BK_STORE4
-        // a lane whose bucket ended at least one full iteration ago (all its bytes coded) takes its prefetched task
-        const bool bytes_in_flight = fresh_finish;   // bytes requested in this iteration are coded in the next one
-        if (!has_task) {
-            if (fresh_finish) fresh_finish = false;
-            else if (nt_stage == 3u) {
-                BK_OPAQUE(nd0); BK_OPAQUE(nd1);
-                *(u32x4*)mydesc = nd0; *(u32x4*)(mydesc + 4) = nd1;
-                for (uint32_t r = 0; r < 17u; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
-                cur_sfs = b.sfs + (size_t)(nt_tid >> 8) * pl; cur_sorted = b.sorted + (size_t)(nt_tid >> 8) * pl;
-                piece = 0u; left = 0u; has_task = true; nt_stage = 0u;
-            }
+        // 3. this iteration's group
+        BK_OPAQUE(e);      /* keeps the compiler from touching the bytes (and waiting for them) before this point */
+        m_prev = m; sfs_prev = cur_sfs;
+        if (m & BK_VALID) {
+            const uint32_t first = (m >> 16) & 15u, cnt = (m >> 20) & 15u;
+            BK_BYTE(0u, e.x, pv0) BK_BYTE(1u, e.x, pv1) BK_BYTE(2u, e.x, pv2) BK_BYTE(3u, e.x, pv3)
+            BK_BYTE(4u, e.y, pv4) BK_BYTE(5u, e.y, pv5) BK_BYTE(6u, e.y, pv6) BK_BYTE(7u, e.y, pv7)
+        }
+        // 4. a lane whose bucket is finished -- the group coded above was its last: nothing of it is still to be requested or
+        //    coded, only the pairs of that group wait for step 1 (with sfs_prev) -- takes its prefetched task
+        if (!has_task && !(m_next & BK_VALID) && nt_stage == 3u) {
+            BK_OPAQUE(nd0); BK_OPAQUE(nd1);
+            uint32_t n = 0;
+            const uint32_t dsc[8] = {nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, nd1.z, nd1.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) if (dsc[j] >> 16) { mydesc[n] = dsc[j] + j * BK_PIECE; ++n; }   // first slot + piece base < 65536
+            nruns = n; run_i = 0u;
+            for (uint32_t r = 0; r < 17u; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
+            cur_sfs = b.sfs + (size_t)(nt_tid >> 8) * pl; cur_sorted = b.sorted + (size_t)(nt_tid >> 8) * pl;
+            left = 0u; has_task = true; nt_stage = 0u;
         }
         // task prefetch pipeline, one stage per iteration so that no load is waited for in the iteration that issued it
         const bool want = nt_stage == 0u && !exhausted;
@@ -278,10 +284,10 @@ __global__ __launch_bounds__(64) void bucket_chain_kernel(const BucketBatch b) {
             if (lane == 0u) nxt_val = atomicAdd(&b.counters[BK_CLAIM], want_w);
             nxt_pending = true;
         }
-        const bool done = !has_task && !bytes_in_flight && nt_stage == 0u && exhausted;
+        const bool done = !has_task && !(m_next & BK_VALID) && !(m_prev & BK_VALID) && nt_stage == 0u && exhausted;
         if (__ballot(!done) == 0ull) break;
     }
-#undef BK_STEP
+#undef BK_BYTE
 #undef BK_OPAQUE
 }
 
