@@ -18,8 +18,9 @@
 namespace divans_hip {
 
 // Chain waves per CU.  The stride model's 24 rows per lane allow three; the context model's 17 would allow four, but three
-// are faster (30.9 vs 35.7 ms per 32 768 streams, two: 32.2): with 16 bytes of records leaving per lane and step the
-// waves of a CU queue up behind its vector-memory path (TA busy 80 %), and a fourth wave only lengthens the queue.
+// were faster in round 2 (30.9 vs 35.7 ms per 32 768 streams, two: 32.2): with 16 bytes of records leaving per lane and step the
+// waves of a CU queue up behind its vector-memory path (TA busy 80 %), and a fourth wave only lengthens the queue.  With the
+// 16-byte payload loads of round 3 three and four measure the same.
 constexpr uint32_t MX_CHAIN_WAVES = 3;
 
 template <int MODEL> struct MxGeom {
@@ -159,8 +160,10 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
     const u32x4 def0 = {4u | (8u << 16), 12u | (16u << 16), 20u | (24u << 16), 28u | (32u << 16)};
     const u32x4 def1 = {36u | (40u << 16), 44u | (48u << 16), 52u | (56u << 16), 60u | (64u << 16)};
 
-    bool has_task = false, fresh_finish = false, exhausted = false;
-    uint32_t piece = 0, left = 0, idx = 0;
+    // Same loop as bucket_chain_kernel (see there): a bucket's runs compacted to the non-empty ones, ONE aligned 16-byte load of
+    // eight sorted payloads per iteration requested an iteration ahead, the records of a group stored at the top of the next one.
+    bool has_task = false, exhausted = false;
+    uint32_t run_i = 0, nruns = 0, left = 0, idx = 0;
     u32x2* const rec_h = b.pos[2 * MODEL]; u32x2* const rec_l = b.pos[2 * MODEL + 1];
     u32x2* cur_h = rec_h; u32x2* cur_l = rec_l; const uint16_t* cur_sorted = b.sorted;
     uint32_t nt_stage = 0, nt_tid = 0;
@@ -168,80 +171,87 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
     uint32_t win_cur = 0, win_end = 0, nxt_val = 0, nxt_w = 0;
     const uint32_t long_end = lists.ends[3];     // tasks of at least 2048 positions come first
     bool nxt_pending = false, drained = false;
-    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    uint32_t e4 = 0, e5 = 0, e6 = 0, e7 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    u32x4 e_next = {0u, 0u, 0u, 0u}; uint32_t m_next = 0;   // meta: base | first << 16 | cnt << 20 | BK_VALID
+    u32x2 h0 = {0u, 0u}, h1 = h0, h2 = h0, h3 = h0, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
+    u32x2 l0 = h0, l1 = h0, l2 = h0, l3 = h0, l4 = h0, l5 = h0, l6 = h0, l7 = h0;
+    uint32_t m_prev = 0; u32x2* h_prev = rec_h; u32x2* l_prev = rec_l;
 
 #define MX_OPAQUE(X) asm volatile("" : "+v"(X))
-#define MX_STEP(E, A, RH, RL, PA, POS)                                                                      \
+#define MX_POS(K, WORD, RH, RL)                                                                         \
+    if (((K - first) & 15u) < cnt) {                                                                    \
+        const uint32_t pay = (WORD >> (16u * (K & 1u))) & 0xffffu;                                      \
+        const uint32_t hi = (pay >> 4) & 15u, lo = pay & 15u;                                           \
+        uint32_t* rowh = MODEL == 0 ? my + ((pay >> 5) & 0x38u) : my;   /* 8 dwords x slot (bits 8..10) */ \
+        uint32_t* rowl = my + 8u * (G::NH + hi);                                                        \
+        BkRow H = bk_read(rowh, tabh, hi), L = bk_read(rowl, tabl, lo);                                 \
+        const u32x2 vh = {(uint32_t)H.chi | (hi ? (uint32_t)H.cprev << 16 : 0u), H.w1.w >> 16};         \
+        const u32x2 vl = {(uint32_t)L.chi | (lo ? (uint32_t)L.cprev << 16 : 0u), L.w1.w >> 16};         \
+        H.w0 += H.a0; H.w1 += H.a1; L.w0 += L.a0; L.w1 += L.a1;   /* frequentist_cdf.rs:75-78 */        \
+        if ((int)(H.w1.w >> 16) >= limh) bk_renorm(H);                                                  \
+        if ((int)(L.w1.w >> 16) >= liml) bk_renorm(L);                                                  \
+        *(u32x4*)rowh = H.w0; *(u32x4*)(rowh + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
+        RH = vh; RL = vl;                                                                               \
+    }
+#define MX_STORE8(DST, R0, R1, R2, R3, R4, R5, R6, R7)                                                  \
     {                                                                                                   \
-        MX_OPAQUE(E);                                                                                   \
-        PA = A;                                                                                         \
-        if (A & BK_VALID) {                                                                             \
-            const uint32_t pay = E >> ((A >> 12) & 16u);     /* A bit 16: which half of the aligned word */ \
-            const uint32_t hi = (pay >> 4) & 15u, lo = pay & 15u;                                       \
-            uint32_t* rowh = MODEL == 0 ? my + ((pay >> 5) & 0x38u) : my;   /* 8 dwords x slot (bits 8..10) */ \
-            uint32_t* rowl = my + 8u * (G::NH + hi);                                                    \
-            BkRow H = bk_read(rowh, tabh, hi), L = bk_read(rowl, tabl, lo);                             \
-            const u32x2 vh = {(uint32_t)H.chi | (hi ? (uint32_t)H.cprev << 16 : 0u), H.w1.w >> 16};     \
-            const u32x2 vl = {(uint32_t)L.chi | (lo ? (uint32_t)L.cprev << 16 : 0u), L.w1.w >> 16};     \
-            H.w0 += H.a0; H.w1 += H.a1; L.w0 += L.a0; L.w1 += L.a1;   /* frequentist_cdf.rs:75-78 */    \
-            if ((int)(H.w1.w >> 16) >= limh) bk_renorm(H);                                              \
-            if ((int)(L.w1.w >> 16) >= liml) bk_renorm(L);                                              \
-            *(u32x4*)rowh = H.w0; *(u32x4*)(rowh + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
-            RH = vh; RL = vl;                                                                           \
+        u32x2* dst = DST + (m_prev & 0xffffu);                                                          \
+        if (pc == 8u) {                                                                                 \
+            const u32x4 q0 = {R0.x, R0.y, R1.x, R1.y}, q1 = {R2.x, R2.y, R3.x, R3.y};                   \
+            const u32x4 q2 = {R4.x, R4.y, R5.x, R5.y}, q3 = {R6.x, R6.y, R7.x, R7.y};                   \
+            bk_store_quad((u32x4*)dst, q0); bk_store_quad((u32x4*)(dst + 2), q1);                       \
+            bk_store_quad((u32x4*)(dst + 4), q2); bk_store_quad((u32x4*)(dst + 6), q3);                 \
+        } else {                                                                                        \
+            if (((0u - pf) & 15u) < pc) bk_store_pair(dst + 0, R0);                                     \
+            if (((1u - pf) & 15u) < pc) bk_store_pair(dst + 1, R1);                                     \
+            if (((2u - pf) & 15u) < pc) bk_store_pair(dst + 2, R2);                                     \
+            if (((3u - pf) & 15u) < pc) bk_store_pair(dst + 3, R3);                                     \
+            if (((4u - pf) & 15u) < pc) bk_store_pair(dst + 4, R4);                                     \
+            if (((5u - pf) & 15u) < pc) bk_store_pair(dst + 5, R5);                                     \
+            if (((6u - pf) & 15u) < pc) bk_store_pair(dst + 6, R6);                                     \
+            if (((7u - pf) & 15u) < pc) bk_store_pair(dst + 7, R7);                                     \
         }                                                                                               \
-        {                                                                                               \
-            const bool adv = has_task && left == 0u, more = piece < b.pieces;                           \
-            const uint32_t d = mydesc[piece & 7u];                                                      \
-            if (adv && more) { left = d >> 16; idx = piece * BK_PIECE + (d & 0xffffu); ++piece; }       \
-            if (adv && !more) { has_task = false; fresh_finish = true; }                                \
-        }                                                                                               \
-        /* slot idx is only taken by step idx % 8 of an iteration: its records then fill aligned sectors */   \
-        const bool fetch_ = has_task && left != 0u && (idx & 7u) == POS;                                \
-        const uint16_t* lp = fetch_ ? cur_sorted + (idx & ~1u) : b.sorted;                              \
-        const uint32_t nxt_a = fetch_ ? (idx | ((idx & 1u) << 16) | BK_VALID) : 0u;                     \
-        idx += fetch_ ? 1u : 0u; left -= fetch_ ? 1u : 0u;                                              \
-        E = *(const uint32_t*)lp; A = nxt_a;                                                            \
     }
 
     for (;;) {
-#define MX_STORE4(H0, L0, PA0, H1, L1, PA1, H2, L2, PA2, H3, L3, PA3)                                   \
-        {                                                                                               \
-            const uint32_t i0 = PA0 & 0xffffu;                                                          \
-            const bool run4 = (PA0 & PA1 & PA2 & PA3 & BK_VALID) && (PA1 & 0xffffu) == i0 + 1u && (PA2 & 0xffffu) == i0 + 2u && (PA3 & 0xffffu) == i0 + 3u; \
-            if (run4) {                                                                                 \
-                const u32x4 ha = {H0.x, H0.y, H1.x, H1.y}, hb = {H2.x, H2.y, H3.x, H3.y};               \
-                const u32x4 la = {L0.x, L0.y, L1.x, L1.y}, lb = {L2.x, L2.y, L3.x, L3.y};               \
-                bk_store_quad((u32x4*)(cur_h + i0), ha); bk_store_quad((u32x4*)(cur_h + i0 + 2u), hb); \
-                bk_store_quad((u32x4*)(cur_l + i0), la); bk_store_quad((u32x4*)(cur_l + i0 + 2u), lb); \
-            } else {                                                                                    \
-                if (PA0 & BK_VALID) { bk_store_pair(cur_h + i0, H0); bk_store_pair(cur_l + i0, L0); }   \
-                if (PA1 & BK_VALID) { bk_store_pair(cur_h + (PA1 & 0xffffu), H1); bk_store_pair(cur_l + (PA1 & 0xffffu), L1); } \
-                if (PA2 & BK_VALID) { bk_store_pair(cur_h + (PA2 & 0xffffu), H2); bk_store_pair(cur_l + (PA2 & 0xffffu), L2); } \
-                if (PA3 & BK_VALID) { bk_store_pair(cur_h + (PA3 & 0xffffu), H3); bk_store_pair(cur_l + (PA3 & 0xffffu), L3); } \
-            }                                                                                           \
+        u32x4 e = e_next; const uint32_t m = m_next;
+        if (m_prev & BK_VALID) {                        // 1. the previous group's records leave
+            const uint32_t pf = (m_prev >> 16) & 15u, pc = (m_prev >> 20) & 15u;
+            MX_STORE8(h_prev, h0, h1, h2, h3, h4, h5, h6, h7)
+            MX_STORE8(l_prev, l0, l1, l2, l3, l4, l5, l6, l7)
         }
-        {   // slot idx is taken by step idx % 8; the records leave after the eighth step, 32 aligned bytes per plane and group of four
-            u32x2 h0 = {0u, 0u}, h1 = h0, h2 = h0, h3 = h0, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
-            u32x2 l0 = h0, l1 = h0, l2 = h0, l3 = h0, l4 = h0, l5 = h0, l6 = h0, l7 = h0;
-            uint32_t pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7;
-            MX_STEP(e0, a0, h0, l0, pa0, 0u) MX_STEP(e1, a1, h1, l1, pa1, 1u) MX_STEP(e2, a2, h2, l2, pa2, 2u) MX_STEP(e3, a3, h3, l3, pa3, 3u)
-            MX_STEP(e4, a4, h4, l4, pa4, 4u) MX_STEP(e5, a5, h5, l5, pa5, 5u) MX_STEP(e6, a6, h6, l6, pa6, 6u) MX_STEP(e7, a7, h7, l7, pa7, 7u)
-            MX_STORE4(h0, l0, pa0, h1, l1, pa1, h2, l2, pa2, h3, l3, pa3)
-            MX_STORE4(h4, l4, pa4, h5, l5, pa5, h6, l6, pa6, h7, l7, pa7)
+        {                                               // 2. the next group of the run is requested, the next run taken
+            const bool adv = has_task && left == 0u, more = run_i < nruns;
+            const uint32_t d = mydesc[run_i & 7u];
+            if (adv && more) { left = d >> 16; idx = d & 0xffffu; ++run_i; }
+            if (adv && !more) has_task = false;
         }
-#undef MX_STORE4
-        const bool bytes_in_flight = fresh_finish;
-        if (!has_task) {
-            if (fresh_finish) fresh_finish = false;
-            else if (nt_stage == 3u) {
-                MX_OPAQUE(nd0); MX_OPAQUE(nd1);
-                *(u32x4*)mydesc = nd0; *(u32x4*)(mydesc + 4) = nd1;
-                for (uint32_t r = 0; r < G::NR; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
-                const size_t slot = (size_t)(nt_tid >> 8) * pl;
-                cur_h = rec_h + slot; cur_l = rec_l + slot; cur_sorted = b.sorted + slot;
-                piece = 0u; left = 0u; has_task = true; nt_stage = 0u;
-            }
+        {
+            const bool fetch_ = has_task && left != 0u;
+            const uint32_t base = idx & ~7u, first_ = idx & 7u;
+            const uint32_t cnt_ = left < 8u - first_ ? left : 8u - first_;
+            const uint16_t* lp = fetch_ ? cur_sorted + base : b.sorted;
+            e_next = *(const u32x4*)lp;
+            m_next = fetch_ ? (base | (first_ << 16) | (cnt_ << 20) | BK_VALID) : 0u;
+            idx += fetch_ ? cnt_ : 0u; left -= fetch_ ? cnt_ : 0u;
+        }
+        MX_OPAQUE(e);                                   // 3. this iteration's group
+        m_prev = m; h_prev = cur_h; l_prev = cur_l;
+        if (m & BK_VALID) {
+            const uint32_t first = (m >> 16) & 15u, cnt = (m >> 20) & 15u;
+            MX_POS(0u, e.x, h0, l0) MX_POS(1u, e.x, h1, l1) MX_POS(2u, e.y, h2, l2) MX_POS(3u, e.y, h3, l3)
+            MX_POS(4u, e.z, h4, l4) MX_POS(5u, e.z, h5, l5) MX_POS(6u, e.w, h6, l6) MX_POS(7u, e.w, h7, l7)
+        }
+        if (!has_task && !(m_next & BK_VALID) && nt_stage == 3u) {   // 4. a finished lane takes its prefetched task
+            MX_OPAQUE(nd0); MX_OPAQUE(nd1);
+            uint32_t n = 0;
+            const uint32_t dsc[8] = {nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, nd1.z, nd1.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) if (dsc[j] >> 16) { mydesc[n] = dsc[j] + j * BK_PIECE; ++n; }
+            nruns = n; run_i = 0u;
+            for (uint32_t r = 0; r < G::NR; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
+            const size_t slot = (size_t)(nt_tid >> 8) * pl;
+            cur_h = rec_h + slot; cur_l = rec_l + slot; cur_sorted = b.sorted + slot;
+            left = 0u; has_task = true; nt_stage = 0u;
         }
         const bool want = nt_stage == 0u && !exhausted;
         if (nt_stage == 2u) nt_stage = 3u;
@@ -278,10 +288,11 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
             if (lane == 0u) nxt_val = atomicAdd(&b.counters[BK_CLAIM], want_w);
             nxt_pending = true;
         }
-        const bool done = !has_task && !bytes_in_flight && nt_stage == 0u && exhausted;
+        const bool done = !has_task && !(m_next & BK_VALID) && !(m_prev & BK_VALID) && nt_stage == 0u && exhausted;
         if (__ballot(!done) == 0ull) break;
     }
-#undef MX_STEP
+#undef MX_POS
+#undef MX_STORE8
 #undef MX_OPAQUE
 }
 
