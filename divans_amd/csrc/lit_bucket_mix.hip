@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BK_SORT_THREADS) void mix_sort_kernel(const MixBuck
 
 // ---------------------------------------------------------------------------------------------
 // 3. chains: one lane per bucket, rows in LDS, raw counts out.  Same skeleton as bucket_chain_kernel (task window,
-//    eight loads in flight per lane, hidden stores); see there for why it is written the way it is.
+//    one 16-byte payload load per iteration, stores hidden from the compiler and delayed by an iteration); see there for why.
 // ---------------------------------------------------------------------------------------------
 template <int MODEL>
 __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {

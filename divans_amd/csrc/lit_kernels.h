@@ -105,7 +105,7 @@ struct MixBucketBatch {
     const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
     uint32_t n_streams, stream_len, max_stream_len;
     uint32_t pieces;            // 8 KiB pieces per stream slot, at most 8
-    uint32_t slot;              // elements per stream in sorted / inv / rec_high / rec_low (see BucketBatch::slot)
+    uint32_t slot;              // elements per stream in sorted / inv / the record planes pos[] (see BucketBatch::slot)
     uint32_t pos_stride;        // elements per stream in pos[]
     uint32_t sf_stride;         // u32 elements per stream in sf
     const uint8_t* blob;        // configuration tables (LIT_BLOB_LUT1CLASS, LIT_BLOB_CTXF of the one block type)
