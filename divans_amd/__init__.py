@@ -132,6 +132,9 @@ def load_library():
     L.divans_gpu_lit_encode_batch_chunks.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp, vp, vp, u32]
     L.divans_gpu_lit_encode_batch_chunks.restype = ctypes.c_int
     L.divans_gpu_selftest_division.argtypes = [vp, ctypes.POINTER(u64)]
+    L.divans_gpu_lit_stream_begin.argtypes = [vp]
+    L.divans_gpu_lit_stream_encode.argtypes = [vp, vp, u32, u64, vp, ctypes.c_size_t, vp, u32, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_size_t)]
+    L.divans_gpu_lit_stream_finish.argtypes = [vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.divans_gpu_speed_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
     L.divans_gpu_speed_supported.restype = ctypes.c_int
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
@@ -174,6 +177,7 @@ def exported_symbols():
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
         "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
+        "divans_gpu_lit_stream_begin", "divans_gpu_lit_stream_encode", "divans_gpu_lit_stream_finish",
     ]
 
 
@@ -416,6 +420,29 @@ class LiteralCodec:
         _check(self._lib.divans_gpu_lit_decode_segments_batch(
             self._h, d_coded.data_ptr(), d_offsets.data_ptr(), d_sizes.data_ptr(), int(n_streams), seg_begin.data_ptr(), segs.data_ptr(),
             d_out.data_ptr(), out_offsets.data_ptr(), out_sizes.data_ptr(), int(stream_len)), "divans_gpu_lit_decode_segments_batch")
+
+    def stream_encode_pieces(self, pieces):
+        """One stream handed over piece by piece (divans_gpu_lit_stream_*): returns (coded bytes, chunk sizes)."""
+        import numpy as np
+        _check(self._lib.divans_gpu_lit_stream_begin(self._h), "divans_gpu_lit_stream_begin")
+        out = bytearray(); sizes = []
+        last8 = 0
+        for piece in pieces:
+            piece = np.ascontiguousarray(piece, dtype=np.uint8)
+            buf = np.empty(encode_bound(piece.size) + 65536, dtype=np.uint8)
+            max_chunks = piece.size // 32768 + 2
+            cs = np.zeros(max_chunks, dtype=np.uint32); n = ctypes.c_uint32(0); got = ctypes.c_size_t(0)
+            _check(self._lib.divans_gpu_lit_stream_encode(self._h, piece.ctypes.data, piece.size, last8, buf.ctypes.data, buf.size,
+                                                          cs.ctypes.data, max_chunks, ctypes.byref(n), ctypes.byref(got)), "divans_gpu_lit_stream_encode")
+            out += buf[:got.value].tobytes(); sizes += [int(x) for x in cs[:n.value]]
+            for b in piece[-8:]:
+                last8 = (last8 >> 8) | (int(b) << 56)
+        buf = np.empty(encode_bound(32768) + 64, dtype=np.uint8); got = ctypes.c_size_t(0)
+        _check(self._lib.divans_gpu_lit_stream_finish(self._h, buf.ctypes.data, buf.size, ctypes.byref(got)), "divans_gpu_lit_stream_finish")
+        out += buf[:got.value].tobytes()
+        if got.value:
+            sizes.append(got.value)
+        return np.frombuffer(bytes(out), dtype=np.uint8), sizes
 
     def model_batch(self, d_in, n_streams, stream_len, in_offsets=None, in_sizes=None):
         """Model pass only: int32 device tensor [n_streams, 2 * M] of start | freq << 16 per nibble (M = max_stream_len, even)."""

@@ -128,6 +128,8 @@ struct divans_gpu_codec {
     uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;
     float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
     std::vector<hipEvent_t> ev_rans; size_t rans_pairs = 0;   // around the rANS launches of the last encode call
+    // one stream coded piece by piece (divans_gpu_lit_stream_*): (start | freq << 16) pairs not yet in a complete chunk, the Weights
+    uint32_t* d_sp = nullptr; size_t sp_cap = 0; uint32_t sp_pending = 0; int32_t* d_wstate = nullptr; bool sp_started = false;
     bool timing_pending_enc = false, timing_pending_dec = false;
 };
 
@@ -354,6 +356,8 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_rs) (void)hipFree(c->d_rs);
+    if (c->d_sp) (void)hipFree(c->d_sp);
+    if (c->d_wstate) (void)hipFree(c->d_wstate);
     for (void* q : c->host_scratch) if (q) (void)hipFree(q);
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -938,6 +942,114 @@ static int host_scratch(divans_gpu_codec* c, int which, size_t bytes, T** out) {
     *out = (T*)c->host_scratch[which];
     return 0;
 }
+
+// ---- one stream, piece by piece -------------------------------------------------------------------------------------------
+// The per-stream ABI's encoder (include/divans_ffi.h) emits container bytes while input is still arriving, as the reference does
+// (src/divans_compressor.rs:276-337): each Literal command of a ring lap is coded when it is emitted.  The model pass of a piece
+// continues the previous one -- the stream's CDF tables stay in the codec's table slab, the Weights in d_wstate, the history
+// comes with the call (last8) -- its pairs join the ones still waiting for their 65 536-symbol chunk to complete, and every
+// complete chunk goes through the rANS pass (one lane per chunk) and back to the host.  Memory: the piece, 8 bytes per byte
+// of it, one open chunk.
+static int stream_rans(divans_gpu_codec* c, uint32_t n_chunks, uint32_t syms_last, uint8_t* out, size_t out_cap, uint32_t* sizes, size_t* out_len) {
+    // chunks 0 .. n_chunks-1 of d_sp, 65 536 pairs each except the last (syms_last), as independent one-chunk streams
+    const uint64_t slot = divans_gpu_lit_encode_bound(32768);
+    uint8_t* d_out = nullptr; uint64_t* d_off = nullptr; uint32_t* d_sz = nullptr; uint32_t* d_len = nullptr;
+    int rc;
+    if ((rc = host_scratch(c, 4, (size_t)n_chunks * slot + 64, &d_out))) return rc;
+    if ((rc = host_scratch(c, 5, (size_t)n_chunks * 8u + 64, &d_off))) return rc;
+    if ((rc = host_scratch(c, 6, (size_t)n_chunks * 8u + 64, &d_sz))) return rc;
+    d_len = d_sz + n_chunks;
+    std::vector<uint32_t> lens(n_chunks, 32768u); lens[n_chunks - 1] = syms_last / 2u;
+    HIP_TRY(hipMemcpyAsync(d_len, lens.data(), (size_t)n_chunks * 4u, hipMemcpyHostToDevice, c->stream));
+    RansBatch r;
+    std::memset(&r, 0, sizeof(r));
+    r.sf = c->d_sp; r.n_streams = n_chunks; r.stream_len = 32768u; r.max_stream_len = 32768u; r.sf_stride = 65536u; r.in_sizes = d_len;
+    r.out = d_out; r.out_slot = slot; r.out_offsets = d_off; r.out_sizes = d_sz; r.status = c->d_status;
+    HIP_TRY(launch_rans_encode(r, c->stream));
+    std::vector<uint64_t> offs(n_chunks); std::vector<uint32_t> szs(n_chunks);
+    HIP_TRY(hipMemcpyAsync(offs.data(), d_off, (size_t)n_chunks * 8u, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(szs.data(), d_sz, (size_t)n_chunks * 4u, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    size_t total = 0;
+    for (uint32_t k = 0; k < n_chunks; ++k) total += szs[k];
+    if (total > out_cap) return fail(DIVANS_GPU_ECAP, "output buffer too small");
+    size_t pos = 0;
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        HIP_TRY(hipMemcpyAsync(out + pos, d_out + offs[k], szs[k], hipMemcpyDeviceToHost, c->stream));
+        pos += szs[k]; if (sizes) sizes[k] = szs[k];
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out_len = total;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_stream_begin(divans_gpu_codec* c) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_wstate && hipMalloc(&c->d_wstate, 64) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(stream state) failed");
+    c->sp_pending = 0; c->sp_started = false;
+    // the tables of the stream live in the first slab of the table area from call to call: one workgroup, no row cache (a cached
+    // row would have to be written back at the end of every piece)
+    c->blocks = 1; c->cache_high = c->cache_low = 0; c->cache_unified = false; c->user_geometry = true;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_stream_encode(divans_gpu_codec* c, const uint8_t* in, uint32_t len, uint64_t last8, uint8_t* out, size_t out_cap,
+                                            uint32_t* chunk_sizes, uint32_t max_chunks, uint32_t* n_chunks, size_t* out_len) {
+    if (!c || !in || !out || !n_chunks || !out_len || !c->d_wstate) return fail(DIVANS_GPU_EINVAL, "bad argument (divans_gpu_lit_stream_begin first)");
+    if (len == 0 || len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "a piece is 1 .. max_stream_len bytes");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_tables(c); if (rc) return rc;
+    const size_t need = (size_t)65536u + 2u * (size_t)c->max_stream_len + 64u;
+    if (need > c->sp_cap) {
+        uint32_t* p = nullptr;
+        if (hipMalloc(&p, need * 4u) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(stream pairs) failed");
+        if (c->d_sp) { HIP_TRY(hipMemcpy(p, c->d_sp, (size_t)c->sp_pending * 4u, hipMemcpyDeviceToDevice)); (void)hipFree(c->d_sp); }
+        c->d_sp = p; c->sp_cap = need;
+    }
+    uint8_t* d_in = nullptr; uint32_t* d_seg = nullptr;
+    if ((rc = host_scratch(c, 0, (size_t)len + 64, &d_in))) return rc;
+    if ((rc = host_scratch(c, 7, 64, &d_seg))) return rc;
+    const uint32_t seg_host[8] = {0u, 1u, 0u, 0u, len, (uint32_t)c->cfg.btype, (uint32_t)last8, (uint32_t)(last8 >> 32)};   // seg_begin[2], pad, divans_lit_segment
+    HIP_TRY(hipMemcpyAsync(d_in, in, len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_seg, seg_host, sizeof(seg_host), hipMemcpyHostToDevice, c->stream));
+    LitBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
+    b.n_streams = 1; b.stream_len = len; b.max_stream_len = c->max_stream_len;
+    b.in = d_in; b.sf = c->d_sp + c->sp_pending; b.status = c->d_status;
+    b.seg_begin = d_seg; b.segs = (const LitSegment*)(d_seg + 4);
+    b.resume = c->sp_started ? 1u : 0u; b.wstate = c->d_wstate;
+    set_cache_fields(c, b);
+    HIP_TRY(launch_model_encode(b, c->mix, 1u, c->stream));
+    c->sp_started = true;
+    c->sp_pending += 2u * len;
+    const uint32_t full = c->sp_pending / 65536u;
+    *n_chunks = full; *out_len = 0;
+    if (full == 0) { HIP_TRY(hipStreamSynchronize(c->stream)); return 0; }
+    if (full > max_chunks || !chunk_sizes) return fail(DIVANS_GPU_ECAP, "chunk_sizes too small");
+    rc = stream_rans(c, full, 65536u, out, out_cap, chunk_sizes, out_len); if (rc) return rc;
+    const uint32_t rest = c->sp_pending - full * 65536u;     // < 65536 pairs, behind at least one coded chunk: the ranges do not overlap
+    if (rest) HIP_TRY(hipMemcpyAsync(c->d_sp, c->d_sp + (size_t)full * 65536u, (size_t)rest * 4u, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sp_pending = rest;
+    return 0;
+}
+
+// the open chunk, as ANSEncoder::close flushes it (ans.rs:331-378); 0 bytes when the stream ended on a chunk boundary
+extern "C" int divans_gpu_lit_stream_finish(divans_gpu_codec* c, uint8_t* out, size_t out_cap, size_t* out_len) {
+    if (!c || !out || !out_len) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    *out_len = 0;
+    if (c->sp_pending == 0) return 0;
+    int rc = stream_rans(c, 1u, c->sp_pending, out, out_cap, nullptr, out_len); if (rc) return rc;
+    c->sp_pending = 0;
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpy(&status, c->d_status, 4, hipMemcpyDeviceToHost));
+    if (status & LIT_STATUS_BAD_MODEL) { (void)hipMemsetAsync(c->d_status, 0, 4, c->stream); return fail(DIVANS_GPU_EINVAL, "invalid (start,freq) pair"); }
+    return 0;
+}
+
 
 extern "C" int divans_gpu_lit_encode_host_chunks(divans_gpu_codec* c, const uint8_t* in, uint32_t stream_len, uint32_t n_streams,
                                                  uint8_t* out_packed, size_t out_cap, uint64_t* out_offsets, uint32_t* out_sizes,

@@ -61,6 +61,10 @@ struct LitBatch {
     // (set = (row ^ (row >> shift)) & (rows - 1)).  cache_bytes_per_wg then covers the word rings too.
     uint32_t dm_log2, dm_shift;
     uint8_t* stream_bad;        // optional [n_streams]: set to 1 for every stream whose decode failed its integrity check
+    // lit_model_encode_kernel, one stream coded piece by piece (divans_gpu_lit_stream_*): `resume` = this launch continues the
+    // stream of the previous one -- its CDF tables are kept (no row cache: cache_mode 0), the two Weights objects come back from
+    // `wstate` ([2][3] ints: model_weights[1], [0]) -- and every launch leaves them there; the history arrives as a segment's last8
+    uint32_t resume; int32_t* wstate;
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
 constexpr uint32_t LIT_STATUS_BAD_SEGMENT = 4u;   // a segment names a literal block type outside the codec's context tables

@@ -242,9 +242,10 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
         const uint8_t* in = b.in + (b.in_offsets ? b.in_offsets[s] : (uint64_t)s * b.stream_len);
         const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
         uint32_t* sf = b.sf + (size_t)s * 2u * b.max_stream_len;
-        init_table(tb, g.total_rows, li);
+        if (!b.resume) init_table(tb, g.total_rows, li);
         WeightsPair wp; wp.init();
-        int nh = 1 << 14, nl = 1 << 14;     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
+        if (MIX && b.resume) { const int32_t* p = b.wstate + (li < 8 ? 0 : 3); wp.w.w0 = p[0]; wp.w.w1 = p[1]; wp.w.norm = p[2]; }
+        int nh = wp.norm_high(), nl = wp.norm_low();     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
         uint64_t last8 = 0;
         uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
         SegCursor sc;
@@ -309,6 +310,10 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
             }
             mine = nxt;
             nxt = (base + 32u + li < len) ? in[base + 32u + li] : 0u;
+        }
+        if (MIX && b.wstate && (li & 7) == 0) {   // lanes 0 and 8 of the row hold the two Weights objects
+            int32_t* p = b.wstate + (li ? 3 : 0);
+            p[0] = wp.w.w0; p[1] = wp.w.w1; p[2] = wp.w.norm;
         }
     }
 }

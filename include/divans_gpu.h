@@ -121,6 +121,20 @@ int divans_gpu_lit_decode_segments_batch(divans_gpu_codec *c, const uint8_t *d_i
                                          const uint32_t *d_seg_begin, const divans_lit_segment *d_segs, uint8_t *d_out,
                                          const uint64_t *d_out_offsets, const uint32_t *d_out_sizes, uint32_t stream_len);
 
+/* One stream coded piece by piece from host memory, with bounded memory: what the per-stream encoder of include/divans_ffi.h runs
+ * for every Literal command the moment the reference would code it (src/divans_compressor.rs:276-337; the LIT coder of
+ * src/codec/literal.rs:261-394 with its 65 536-symbol chunks, src/ans.rs:287-378).
+ *   _begin   starts a stream on the codec (one workgroup, no row cache; the codec serves this stream until _finish).
+ *   _encode  codes `len` more bytes (1 .. max_stream_len) whose predecessors end in `last8` (the ring buffer's last 8 bytes, byte 7 the
+ *            most recent, as divans_lit_segment::last8).  `out` receives the bytes of every chunk these bytes COMPLETE, back to back,
+ *            their sizes in chunk_sizes[0 .. *n_chunks); the symbols of the open chunk stay on the device.
+ *   _finish  codes the open chunk (ANSEncoder::close); 0 bytes when the stream ended on a chunk boundary.
+ * The concatenation of everything returned is the stream divans_gpu_lit_encode_host produces for the same bytes. */
+int divans_gpu_lit_stream_begin(divans_gpu_codec *c);
+int divans_gpu_lit_stream_encode(divans_gpu_codec *c, const uint8_t *in, uint32_t len, uint64_t last8, uint8_t *out, size_t out_cap,
+                                 uint32_t *chunk_sizes, uint32_t max_chunks, uint32_t *n_chunks, size_t *out_len);
+int divans_gpu_lit_stream_finish(divans_gpu_codec *c, uint8_t *out, size_t out_cap, size_t *out_len);
+
 /* Status of the device-pointer batch calls (they are asynchronous and return before the kernels ran).  Waits for the
  * codec's stream, stores the bits set since the previous call in *status and clears them:
  *   DIVANS_GPU_STATUS_BAD_MODEL  (1): an encode pass met a (start,freq) outside 15 bits / freq == 0 -- a CDF state the

@@ -501,6 +501,25 @@ def test_encoder_sub_batches_of_two_chunk_streams(cfg_name, corpus):
     codec.close()
 
 
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_stream_coded_piece_by_piece(cfg_name, corpus, random_then_unicode):
+    # divans_gpu_lit_stream_*: the model pass of a piece resumes the previous one (tables, Weights, history), chunks are coded as
+    # they complete.  Pieces of 1 byte, around the 32 768-byte chunk, several chunks at once; the bytes must be the oracle's
+    # stream of the concatenation, the chunk sizes must add up.
+    data = np.concatenate([corpus[:70000], random_then_unicode[200000:260000]])
+    cuts = [0, 1, 2, 17, 4096, 32767, 32768, 32769, 65536, 65537, 100000, data.size]
+    da, codec = _codec(cfg_name, 65536)
+    coded, sizes = codec.stream_encode_pieces([data[a:b] for a, b in zip(cuts[:-1], cuts[1:])])
+    ref = po.lit_encode(_oracle_cfg(cfg_name), data)
+    assert coded.size == ref.size and (coded == ref).all()
+    assert sum(sizes) == coded.size and len(sizes) == (2 * data.size + 65535) // 65536
+    # and again on the same codec: a new stream starts from fresh tables
+    coded2, _ = codec.stream_encode_pieces([data[:5000], data[5000:5001], data[5001:40000]])
+    ref2 = po.lit_encode(_oracle_cfg(cfg_name), data[:40000])
+    assert coded2.size == ref2.size and (coded2 == ref2).all()
+    codec.close()
+
+
 def test_bucketed_encoder_only_where_it_applies():
     import ctypes
     import divans_amd as da
