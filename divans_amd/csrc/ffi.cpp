@@ -27,12 +27,9 @@ struct DivansCompressorState {
     StreamOptions opt;
     bool started = false;        // CompressorState::OptionStage -> constructed compressor (ffi/compressor.rs:212-236)
     bool failed = false;
-    int header_sent = 0;         // bytes of the 16-byte header already handed out (write_header, divans_compressor.rs:150-174)
-    std::vector<uint8_t> input;  // everything the caller has handed over (RawToCmdState buffers it in its ring, raw_to_cmd/mod.rs:55-104)
-    std::vector<size_t> call_inputs;   // bytes per divans_encode call: decides when the ring fills and commands are emitted
-    bool built = false;
-    std::vector<uint8_t> stream; // complete container, produced at the first flush
-    size_t cursor = 0;
+    divans_host::StreamEncoder* enc = nullptr;   // DivansCompressor: ring, CMD coder, Mux, GPU literal coder (host_stream.h)
+    bool flushing = false;
+    ~DivansCompressorState() { delete enc; }
 };
 
 struct DivansDecompressorState {
@@ -104,32 +101,22 @@ static bool start(DivansCompressorState* s) {
     // reference decoder accepts -- larger than a brotli-assisted one -- so c/example.c, which sets no
     // options, round-trips through this library unchanged.
     if (s->opt.dynamic_context_mixing >= 15) s->failed = true;   // codec/interface.rs:359 assert
+    if (!s->failed) s->enc = new (std::nothrow) divans_host::StreamEncoder(s->opt, 0);
+    if (!s->enc) s->failed = true;
     return !s->failed;
 }
 
-static size_t emit_header(DivansCompressorState* s, uint8_t* out, size_t cap) {
-    const int w = s->opt.window_size < 10 ? 10 : (s->opt.window_size > 24 ? 24 : s->opt.window_size);
-    const uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)w, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const size_t n = (size_t)(16 - s->header_sent) < cap ? (size_t)(16 - s->header_sent) : cap;
-    std::memcpy(out, hdr + s->header_sent, n);
-    s->header_sent += (int)n;
-    return n;
-}
-
-// src/ffi/mod.rs:70-91 + divans_compressor.rs:276-337
+// src/ffi/mod.rs:70-91 + divans_compressor.rs:276-337: input goes into the 2^window ring; whenever it fills, its commands are coded
+// and container bytes leave in THIS call, as far as the Mux lets them and `out` has room (DIVANS_NEEDS_MORE_OUTPUT: call again
+// with the rest of the input and an empty buffer)
 DivansResult divans_encode(struct DivansCompressorState* s, const uint8_t* in, size_t in_size, size_t* in_off,
                            uint8_t* out, size_t out_size, size_t* out_off) {
     if (!s || !in_off || !out_off || *in_off > in_size || *out_off > out_size) return DIVANS_FAILURE;
     if (!s->started && !start(s)) return DIVANS_FAILURE;
-    if (s->failed || s->built) return DIVANS_FAILURE;          // NotAllowedToEncodeAfterFlush
-    if (s->header_sent < 16) {
-        *out_off += emit_header(s, out + *out_off, out_size - *out_off);
-        if (s->header_sent < 16) return DIVANS_NEEDS_MORE_OUTPUT;
-    }
-    if (in_size > *in_off) s->input.insert(s->input.end(), in + *in_off, in + in_size);
-    s->call_inputs.push_back(in_size - *in_off);
-    *in_off = in_size;
-    return DIVANS_NEEDS_MORE_INPUT;
+    if (s->failed || s->flushing) return DIVANS_FAILURE;       // NotAllowedToEncodeAfterFlush
+    const int rc = s->enc->encode(in, in_size, in_off, out, out_size, out_off);
+    if (rc < 0) { s->failed = true; return DIVANS_FAILURE; }
+    return rc == 1 ? DIVANS_NEEDS_MORE_OUTPUT : DIVANS_NEEDS_MORE_INPUT;
 }
 
 // src/ffi/mod.rs:94-108 + divans_compressor.rs:363-426
@@ -137,29 +124,10 @@ DivansResult divans_encode_flush(struct DivansCompressorState* s, uint8_t* out, 
     if (!s || !out_off || *out_off > out_size) return DIVANS_FAILURE;
     if (!s->started && !start(s)) return DIVANS_FAILURE;
     if (s->failed) return DIVANS_FAILURE;
-    const bool header_in_this_call = s->header_sent < 16;
-    if (header_in_this_call) {
-        *out_off += emit_header(s, out + *out_off, out_size - *out_off);
-        if (s->header_sent < 16) return DIVANS_NEEDS_MORE_OUTPUT;
-    }
-    if (!s->built) {
-        // The Mux slicing depends on the room the caller gives each call (src/mux.rs:445-476); replay it with this
-        // call's buffer size, which callers keep constant (c/example.c: BUF_SIZE).
-        const size_t call_buffer = out_size ? out_size : 65536;
-        if (s->call_inputs.empty()) s->call_inputs.push_back(0);   // flush without any encode call: the header still goes out first
-        if (divans_host::build_container(s->opt, s->input.data(), s->input.size(), call_buffer, 0, s->stream, &s->call_inputs) != 0) {
-            s->failed = true;
-            return DIVANS_FAILURE;
-        }
-        s->built = true;
-        s->cursor = 16;   // the header already went out through emit_header
-        std::vector<uint8_t>().swap(s->input);
-    }
-    const size_t room = out_size - *out_off, left = s->stream.size() - s->cursor;
-    const size_t n = left < room ? left : room;
-    std::memcpy(out + *out_off, s->stream.data() + s->cursor, n);
-    s->cursor += n; *out_off += n;
-    return s->cursor == s->stream.size() ? DIVANS_SUCCESS : DIVANS_NEEDS_MORE_OUTPUT;
+    s->flushing = true;
+    const int rc = s->enc->flush(out, out_size, out_off);
+    if (rc < 0) { s->failed = true; return DIVANS_FAILURE; }
+    return rc == 1 ? DIVANS_NEEDS_MORE_OUTPUT : DIVANS_SUCCESS;
 }
 
 void divans_free_compressor(struct DivansCompressorState* s) {

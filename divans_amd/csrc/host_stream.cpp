@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -752,26 +753,189 @@ int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_si
     return 0;
 }
 
-int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
-                    std::vector<uint8_t>& out, const std::vector<size_t>* call_inputs) {
-    out.clear();
-    StreamPlan plan;
-    int rc = plan_stream(opt, n, call_inputs, plan);
-    if (rc) return rc;
-    // every literal byte on the GPU (all Literal commands share one LIT coder and one set of priors)
-    std::vector<uint8_t> lit; std::vector<uint32_t> chunk_bytes(std::max<uint32_t>(plan.lit_chunks, 1u), 0u);
-    if (n) {
-        GpuCodecHandle h;
-        rc = h.acquire(plan.cfg, device, (uint32_t)n);
-        if (rc) return rc;
-        lit.resize(divans_gpu_lit_encode_bound(n) + 64);
-        uint64_t off = 0; uint32_t size = 0; size_t total = 0;
-        rc = divans_gpu_lit_encode_host_chunks(h.c, input, (uint32_t)n, 1, lit.data(), lit.size(), &off, &size, &total,
-                                               chunk_bytes.data(), (uint32_t)chunk_bytes.size());
-        if (rc) return rc;
-        lit.resize(size);
+// ---------------------------------------------------------------- the same compressor, one call at a time
+// What plan_stream + assemble_container do for a whole stream at once, as a machine that stops wherever the reference returns to its
+// caller.  Commands are coded the moment the ring emits them (CMD nibbles on the host, literal bytes on the GPU); what that leaves for
+// the Mux is a queue of steps, and a step whose drain cannot finish because the caller's buffer is full stays at the head of the
+// queue: the next call starts by running it again, which is exactly the re-entry of divans_compressor.rs:189-207.
+struct StreamEncoder::Impl {
+    StreamOptions opt; int device; int window;
+    std::vector<uint8_t> ring; size_t decode = 0, output = 0, fresh_tail = 0; bool header_done = false;   // RawToCmdState
+    int header_sent = 0;
+    CommandModel model; RansEncoder cmd; NibbleCoder nc; size_t cmd_logged = 0;
+    GpuCodecHandle gpu; bool lit_started = false; divans_lit_config cfg;
+    uint64_t last8 = 0; uint64_t lit_syms = 0;
+    struct Step { StreamPlan::Kind kind; size_t value; bool started; };
+    std::deque<Step> steps;
+    std::deque<std::vector<uint8_t>> chunks;          // LIT chunks coded but not yet handed to the Mux
+    std::vector<uint8_t> lit; size_t lit_avail = 0, lit_drained = 0, cmd_drained = 0;
+    Mux mux;
+    uint32_t crc = 0;
+    int phase = 0;                                    // flush: 0 commands still to come, 1 steps, 2 MuxDrain, 3 trailer, 4 done
+    int trailer_sent = 0; uint8_t trailer[8];
+    int error = 0;
+
+    Impl(const StreamOptions& o, int dev) : opt(o), device(dev), window(std::min(24, std::max(10, o.window_size))), model(o) {
+        ring.resize((size_t)1 << window);
+        nc.enc = &cmd;
+        nc.before = [this]() { if (cmd.out.size() != cmd_logged) { cmd_logged = cmd.out.size(); steps.push_back({StreamPlan::CmdAvail, cmd_logged, false}); } };
     }
-    return assemble_container(plan, lit.data(), lit.size(), chunk_bytes.data(), call_buffer, out);
+    void put(uint8_t* out, size_t* off, const uint8_t* src, size_t n) { std::memcpy(out + *off, src, n); crc = crc32c(crc, src, n); *off += n; }
+
+    // drain_or_fill_static_buffer against the caller's real buffer: false = NeedsMoreOutput (the step runs again in the next call)
+    bool drain(int id, const std::vector<uint8_t>& coder_out, size_t avail_end, size_t& drained, bool retry, uint8_t* out, size_t cap, size_t* off) {
+        while (drained < avail_end) {
+            const size_t room = cap - *off;
+            const size_t k = mux.serialize(out + *off, room);
+            crc = crc32c(crc, out + *off, k); *off += k;
+            mux.prep(0, 16); mux.prep(1, 16);
+            Mux::Stream& b = mux.s[id];
+            const size_t take = std::min(avail_end - drained, b.buf.size() - b.end);
+            std::memcpy(b.buf.data() + b.end, coder_out.data() + drained, take);
+            b.end += take; drained += take;
+            if (drained < avail_end && cap == *off) return !retry;      // status dropped (LitChunkLast) or handed to the caller
+        }
+        return true;
+    }
+    bool run_steps(uint8_t* out, size_t cap, size_t* off) {          // false = NeedsMoreOutput
+        while (!steps.empty()) {
+            Step& st = steps.front();
+            if (st.kind == StreamPlan::CmdAvail) { if (!drain(0, cmd.out, st.value, cmd_drained, true, out, cap, off)) return false; }
+            else {
+                if (st.kind != StreamPlan::LitDrain && !st.started) {
+                    st.started = true;
+                    if (lit_drained == lit.size()) { lit.clear(); lit_drained = 0; lit_avail = 0; }   // everything before this chunk has left
+                    lit.insert(lit.end(), chunks.front().begin(), chunks.front().end());
+                    lit_avail = lit.size();
+                    chunks.pop_front();
+                }
+                if (!drain(1, lit, lit_avail, lit_drained, st.kind != StreamPlan::LitChunkLast, out, cap, off)) return false;
+            }
+            steps.pop_front();
+        }
+        return true;
+    }
+    // one Literal command of the ring: CMD nibbles, then its bytes through the GPU coder, then the steps its chunks mean for the Mux
+    int code_literal(const uint8_t* data, size_t len) {
+        model.command_type(nc, 3);
+        uint32_t len_out;
+        if (!model.literal_length(nc, (uint32_t)len, len_out)) return DIVANS_GPU_EINVAL;
+        nc.before();
+        steps.push_back({StreamPlan::LitDrain, 0, false});
+        if (!lit_started) {
+            int rc = gpu.acquire(cfg, device, (uint32_t)ring.size()); if (rc) return rc;
+            rc = divans_gpu_lit_stream_begin(gpu.c); if (rc) return rc;
+            lit_started = true;
+        }
+        std::vector<uint8_t> buf((size_t)divans_gpu_lit_encode_bound((uint32_t)len) + 65536u);
+        const uint32_t max_chunks = (uint32_t)(len / 32768u + 2u);
+        std::vector<uint32_t> sizes(max_chunks); uint32_t n_chunks = 0; size_t got = 0;
+        int rc = divans_gpu_lit_stream_encode(gpu.c, data, (uint32_t)len, last8, buf.data(), buf.size(), sizes.data(), max_chunks, &n_chunks, &got);
+        if (rc) return rc;
+        for (size_t i = len < 8 ? 0 : len - 8; i < len; ++i) last8 = (last8 >> 8) | ((uint64_t)data[i] << 56);
+        const uint64_t end_syms = lit_syms + 2 * (uint64_t)len;
+        size_t pos = 0; uint32_t k = 0;
+        while ((lit_syms / 65536 + 1) * 65536 <= end_syms) {
+            lit_syms = (lit_syms / 65536 + 1) * 65536;
+            if (k >= n_chunks) return DIVANS_GPU_EINVAL;
+            chunks.emplace_back(buf.begin() + pos, buf.begin() + pos + sizes[k]); pos += sizes[k]; ++k;
+            steps.push_back({lit_syms == end_syms ? StreamPlan::LitChunkLast : StreamPlan::LitChunk, 0, false});
+        }
+        lit_syms = end_syms;
+        return (k == n_chunks && pos == got) ? 0 : DIVANS_GPU_EINVAL;
+    }
+    int code_prediction_mode() {
+        const PredictionModeIn pm = internal_prediction_mode();
+        model.command_type(nc, 7);
+        if (!model.prediction_mode(nc, &pm)) return DIVANS_GPU_EINVAL;
+        model.fill_lit_config(cfg, 0);
+        return 0;
+    }
+    int ring_flush() {                                    // RawToCmdState::flush, raw_to_cmd/mod.rs:105-181 (fresh bytes only, see RingEvents)
+        int rc = 0;
+        if (!header_done) { header_done = true; if ((rc = code_prediction_mode())) return rc; }
+        if (decode < output) {
+            if (fresh_tail && (rc = code_literal(ring.data() + output, fresh_tail))) return rc;
+            fresh_tail = 0;
+            if (decode == ring.size()) decode = 0;
+            output = 0;
+        }
+        if (decode != output) { if ((rc = code_literal(ring.data() + output, decode - output))) return rc; output = decode; }
+        return 0;
+    }
+    bool header(uint8_t* out, size_t cap, size_t* off) {
+        const uint8_t hdr[16] = {0xff, 0xe5, 0x8c, 0x9f, 0, (uint8_t)window, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const size_t n = std::min<size_t>(16 - header_sent, cap - *off);
+        put(out, off, hdr + header_sent, n); header_sent += (int)n;
+        return header_sent == 16;
+    }
+};
+
+StreamEncoder::StreamEncoder(const StreamOptions& opt, int device) : p_(new Impl(opt, device)) {}
+StreamEncoder::~StreamEncoder() { delete p_; }
+
+int StreamEncoder::encode(const uint8_t* in, size_t n, size_t* in_off, uint8_t* out, size_t cap, size_t* out_off) {   // divans_compressor.rs:276-337
+    Impl& s = *p_;
+    if (s.error) return s.error;
+    if (s.phase != 0) return s.error = DIVANS_GPU_EINVAL;                // NotAllowedToEncodeAfterFlush
+    if (!s.header(out, cap, out_off) || !s.run_steps(out, cap, out_off)) return 1;
+    for (;;) {                                                          // RawToCmdState::stream, raw_to_cmd/mod.rs:55-104
+        if (s.decode >= s.output) {
+            const size_t k = std::min(s.ring.size() - s.decode, n - *in_off);
+            std::memcpy(s.ring.data() + s.decode, in + *in_off, k);
+            *in_off += k; s.decode += k;
+            if (s.output != 0) { s.fresh_tail = s.decode - s.output; s.decode = 0; }
+        }
+        if (s.decode < s.output) {
+            const size_t k = std::min(s.output - 1 - s.decode, n - *in_off);
+            std::memcpy(s.ring.data() + s.decode, in + *in_off, k);
+            *in_off += k; s.decode += k;
+        }
+        if (!(s.decode == s.ring.size() || s.decode + 1 == s.output)) return 0;      // ring not full: all input taken
+        if (int rc = s.ring_flush()) return s.error = rc;
+        if (!s.run_steps(out, cap, out_off)) return 1;
+        if (*in_off == n) return 0;
+    }
+}
+
+int StreamEncoder::flush(uint8_t* out, size_t cap, size_t* out_off) {   // divans_compressor.rs:362-426 + codec/mod.rs:424-560
+    Impl& s = *p_;
+    if (s.error) return s.error;
+    if (!s.header(out, cap, out_off) || !s.run_steps(out, cap, out_off)) return 1;
+    if (s.phase == 0) {
+        if (int rc = s.ring_flush()) return s.error = rc;
+        s.model.command_type(s.nc, 0xf);                                // the end marker through the command-type prior
+        s.nc.before();
+        s.steps.push_back({StreamPlan::LitDrain, 0, false});            // EncodedShutdownNode
+        s.cmd.flush();                                                  // ShutdownCoder(0)
+        s.nc.before();
+        if (s.cmd.failed) return s.error = DIVANS_GPU_EINVAL;
+        if (s.lit_started) {                                            // ShutdownCoder(1), CoderBufferDrain
+            std::vector<uint8_t> buf((size_t)divans_gpu_lit_encode_bound(32768u) + 64u); size_t got = 0;
+            if (int rc = divans_gpu_lit_stream_finish(s.gpu.c, buf.data(), buf.size(), &got)) return s.error = rc;
+            if (got) { s.chunks.emplace_back(buf.begin(), buf.begin() + got); s.steps.push_back({StreamPlan::LitChunk, 0, false}); }
+        }
+        s.phase = 1;
+    }
+    if (s.phase == 1) { if (!s.run_steps(out, cap, out_off)) return 1; s.phase = 2; }
+    while (s.phase == 2) {                                              // MuxDrain
+        if (cap == *out_off) return 1;
+        const size_t k = s.mux.close(out + *out_off, cap - *out_off);
+        s.crc = crc32c(s.crc, out + *out_off, k); *out_off += k;
+        if (s.mux.eof == 3 && s.mux.s[0].avail() == 0 && s.mux.s[1].avail() == 0 && s.mux.leftover == 0) {
+            const uint32_t c = s.crc;
+            const uint8_t tr[8] = {(uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24), 'a', 'n', 's', '~'};
+            std::memcpy(s.trailer, tr, 8);
+            s.phase = 3;
+        }
+    }
+    if (s.phase == 3) {                                                 // WriteChecksum
+        const size_t k = std::min<size_t>(8 - s.trailer_sent, cap - *out_off);
+        std::memcpy(out + *out_off, s.trailer + s.trailer_sent, k); *out_off += k; s.trailer_sent += (int)k;
+        if (s.trailer_sent < 8) return 1;
+        s.phase = 4;
+    }
+    return 0;
 }
 
 // Host half of decoding: framing, CRC, CMD coder.  Leaves the LIT coder's bytes, the decoded size and its configuration.

@@ -32,16 +32,6 @@ struct PredictionModeIn {                 // the PredictionMode command as the e
 int lit_config_from_prediction_mode(const StreamOptions& opt, const PredictionModeIn* pm, divans_lit_config& cfg);
 uint8_t speed_to_f8(int16_t v);           // probability/interface.rs:566-575
 
-// Builds the complete container for `input` exactly as the reference's literal-only internal compressor would
-// (src/divans_compressor.rs:276-426 + src/raw_to_cmd/mod.rs:105-181), `call_buffer` = size of the output buffer
-// the caller hands to each flush call (the Mux slicing depends on it, src/mux.rs:445-476).
-// Literal bytes are coded on GPU `device`.  Returns 0 or a DIVANS_GPU_E* code.
-// `call_inputs`: bytes the caller handed to each divans_encode call (null: all in one call) -- the internal compressor emits
-// commands when its 2^window ring fills (raw_to_cmd/mod.rs:83), i.e. inside those calls, and what the Mux has sliced by then
-// depends on it.
-int build_container(const StreamOptions& opt, const uint8_t* input, size_t n, size_t call_buffer, int device,
-                    std::vector<uint8_t>& out, const std::vector<size_t>* call_inputs = nullptr);
-
 // A stream split into the half that needs no literal data (CMD coder bytes, the order in which coder bytes reach the Mux)
 // and the half that does (assemble_container): the first runs on host threads while the GPU codes the literals.
 struct StreamPlan {
@@ -60,6 +50,23 @@ struct StreamPlan {
 int plan_stream(const StreamOptions& opt, size_t n, const std::vector<size_t>* call_inputs, StreamPlan& plan);
 int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_size, const uint32_t* chunk_bytes, size_t call_buffer,
                        std::vector<uint8_t>& out);
+
+// DivansCompressor with the internal command selection, call by call and with bounded memory (src/divans_compressor.rs:276-426):
+// the ring of 2^window bytes, every Literal command coded on the GPU the moment the reference would code it
+// (divans_gpu_lit_stream_*), container bytes handed out inside the encode() calls as the reference hands them out.
+// encode() / flush() return 0 (NeedsMoreInput resp. Success), 1 (NeedsMoreOutput) or a negative DIVANS_GPU_E* code.
+class StreamEncoder {
+  public:
+    StreamEncoder(const StreamOptions& opt, int device);
+    ~StreamEncoder();
+    StreamEncoder(const StreamEncoder&) = delete;
+    StreamEncoder& operator=(const StreamEncoder&) = delete;
+    int encode(const uint8_t* in, size_t n, size_t* in_off, uint8_t* out, size_t cap, size_t* out_off);
+    int flush(uint8_t* out, size_t cap, size_t* out_off);
+  private:
+    struct Impl;
+    Impl* p_;
+};
 
 enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
 // Decodes a complete container (header .. "ans~").  PARSE_NEED_MORE when `n` bytes do not yet hold the whole stream.

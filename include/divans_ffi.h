@@ -10,8 +10,11 @@
  * internal command selection: a valid .divans stream, larger than a brotli-assisted one (brotli command
  * generation is out of scope).  There is no CPU fallback for the literal coder: without a HIP device the first
  * divans_encode() / divans_decode() that needs it returns DIVANS_FAILURE.
- * The state buffers the input and produces the stream in the divans_encode_flush() calls; the
- * decompressor accepts literal-only streams (one PredictionMode before the first Literal).
+ * The compressor works call by call as the reference's does (src/divans_compressor.rs:276-426): input goes into a ring of 2^window
+ * bytes, a lap is coded inside the divans_encode() call that completes it (its literals on the GPU, resuming the stream's model),
+ * container bytes leave in that call as far as the Mux releases them, and divans_encode() returns DIVANS_NEEDS_MORE_OUTPUT with part
+ * of the input untaken exactly where the reference does.  The decompressor still collects the container before it decodes; it
+ * accepts literal-only streams (one PredictionMode before the first Literal).
  * include/divans_io.hpp wraps this ABI in the reference's writer / reader adaptors (src/writer.rs, src/reader.rs).
  */
 #ifndef DIVANS_FFI_H_
