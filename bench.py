@@ -259,6 +259,8 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
         codec.set_geometry(cache_rows=args.cache_rows)
     if args.encode_path:
         codec.set_encode_path(args.encode_path)
+    if args.bucket_batch:
+        codec.set_bucket_batch(args.bucket_batch)
     if args.decoder_generation:
         codec.set_decoder(args.decoder_generation)
     if args.split_cache:
@@ -368,6 +370,7 @@ def main():
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
     ap.add_argument("--decoder-generation", type=int, default=0, help="decode kernel: 1 = lit_kernels.hip, 2 / 3 = lit_decode2.hip direct-mapped / 2-way caches (tuning; 0 = the codec's default)")
     ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
+    ap.add_argument("--bucket-batch", type=int, default=0, help="streams per launch sequence of the two-model bucketed pass (tuning; default 32768)")
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
     ap.add_argument("--host-data", action="store_true", help="build the input with tests/workload.py on the host instead of on the GPU (same bytes; "
                     "keeps the tens of thousands of small torch kernels of the GPU generator out of profiler runs)")
