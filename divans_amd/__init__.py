@@ -135,6 +135,8 @@ def load_library():
     L.divans_gpu_lit_stream_begin.argtypes = [vp]
     L.divans_gpu_lit_stream_encode.argtypes = [vp, vp, u32, u64, vp, ctypes.c_size_t, vp, u32, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_size_t)]
     L.divans_gpu_lit_stream_finish.argtypes = [vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.divans_gpu_lit_stream_decode_begin.argtypes = [vp]
+    L.divans_gpu_lit_stream_decode.argtypes = [vp, vp, ctypes.c_size_t, u32, u64, vp, ctypes.POINTER(ctypes.c_size_t)]
     L.divans_gpu_speed_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
     L.divans_gpu_speed_supported.restype = ctypes.c_int
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
@@ -178,6 +180,7 @@ def exported_symbols():
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
         "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
         "divans_gpu_lit_stream_begin", "divans_gpu_lit_stream_encode", "divans_gpu_lit_stream_finish",
+        "divans_gpu_lit_stream_decode_begin", "divans_gpu_lit_stream_decode",
     ]
 
 
@@ -443,6 +446,26 @@ class LiteralCodec:
         if got.value:
             sizes.append(got.value)
         return np.frombuffer(bytes(out), dtype=np.uint8), sizes
+
+    def stream_decode_chunks(self, coded, n, chunks_per_call=1, slack=None):
+        """One stream decoded chunk by chunk (divans_gpu_lit_stream_decode): every call sees at most `slack` coded bytes past the
+        current position (default: the bound of the chunks it asks for) -- a chunk must not need more."""
+        import numpy as np
+        coded = np.ascontiguousarray(coded, dtype=np.uint8)
+        _check(self._lib.divans_gpu_lit_stream_decode_begin(self._h), "divans_gpu_lit_stream_decode_begin")
+        out = np.empty(n, dtype=np.uint8)
+        pos = 0; done = 0; last8 = 0
+        while done < n:
+            want = min(32768 * chunks_per_call, n - done)
+            window = min(coded.size - pos, slack if slack is not None else encode_bound(32768) * chunks_per_call)
+            got = ctypes.c_size_t(0)
+            piece = np.ascontiguousarray(coded[pos:pos + window])
+            _check(self._lib.divans_gpu_lit_stream_decode(self._h, piece.ctypes.data, piece.size, want, last8,
+                                                          out[done:].ctypes.data, ctypes.byref(got)), "divans_gpu_lit_stream_decode")
+            for b in out[max(done, done + want - 8):done + want]:
+                last8 = (last8 >> 8) | (int(b) << 56)
+            pos += got.value; done += want
+        return out, pos
 
     def model_batch(self, d_in, n_streams, stream_len, in_offsets=None, in_sizes=None):
         """Model pass only: int32 device tensor [n_streams, 2 * M] of start | freq << 16 per nibble (M = max_stream_len, even)."""

@@ -129,7 +129,7 @@ struct divans_gpu_codec {
     float last_model_ms = 0, last_rans_ms = 0, last_decode_ms = 0;
     std::vector<hipEvent_t> ev_rans; size_t rans_pairs = 0;   // around the rANS launches of the last encode call
     // one stream coded piece by piece (divans_gpu_lit_stream_*): (start | freq << 16) pairs not yet in a complete chunk, the Weights
-    uint32_t* d_sp = nullptr; size_t sp_cap = 0; uint32_t sp_pending = 0; int32_t* d_wstate = nullptr; bool sp_started = false;
+    uint32_t* d_sp = nullptr; size_t sp_cap = 0; uint32_t sp_pending = 0; int32_t* d_wstate = nullptr; bool sp_started = false, sd_started = false;
     bool timing_pending_enc = false, timing_pending_dec = false;
 };
 
@@ -1033,6 +1033,55 @@ extern "C" int divans_gpu_lit_stream_encode(divans_gpu_codec* c, const uint8_t* 
     if (rest) HIP_TRY(hipMemcpyAsync(c->d_sp, c->d_sp + (size_t)full * 65536u, (size_t)rest * 4u, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->sp_pending = rest;
+    return 0;
+}
+
+// The decode direction: whole 65 536-symbol chunks per call (a chunk starts from fresh rANS states, so besides the tables, the
+// Weights and the history nothing carries over).  `coded` = the LIT-coder bytes from the current chunk boundary on, as many as have
+// arrived (a multiple of 4 is used); `out_len` = 32768 * k bytes of output, or less for the last chunk of the stream; the bytes the
+// chunks occupied come back in *consumed_bytes.  The caller makes sure the chunks are complete: divans_gpu_lit_encode_bound(32768)
+// bytes per chunk always are enough.
+extern "C" int divans_gpu_lit_stream_decode_begin(divans_gpu_codec* c) {
+    const int rc = divans_gpu_lit_stream_begin(c);
+    if (rc) return rc;
+    c->sd_started = false;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_stream_decode(divans_gpu_codec* c, const uint8_t* coded, size_t coded_bytes, uint32_t out_len, uint64_t last8,
+                                            uint8_t* out, size_t* consumed_bytes) {
+    if (!c || !coded || !out || !consumed_bytes || !c->d_wstate) return fail(DIVANS_GPU_EINVAL, "bad argument (divans_gpu_lit_stream_decode_begin first)");
+    if (out_len == 0 || out_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "a call decodes 1 .. max_stream_len bytes");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_tables(c); if (rc) return rc;
+    const size_t use = std::min<size_t>(coded_bytes & ~(size_t)3, (size_t)0xfffffff0u);
+    uint8_t* d_in = nullptr; uint8_t* d_out = nullptr; uint32_t* d_meta = nullptr;
+    if ((rc = host_scratch(c, 0, use + 64, &d_in))) return rc;
+    if ((rc = host_scratch(c, 1, (size_t)out_len + 64, &d_out))) return rc;
+    if ((rc = host_scratch(c, 7, 128, &d_meta))) return rc;
+    // d_meta: [0..1] in_offset (u64 0), [2] in_size, [3] consumed, [4..5] seg_begin, [8..11] divans_lit_segment
+    const uint32_t meta[12] = {0u, 0u, (uint32_t)use, 0u, 0u, 1u, 0u, 0u, out_len, (uint32_t)c->cfg.btype, (uint32_t)last8, (uint32_t)(last8 >> 32)};
+    HIP_TRY(hipMemcpyAsync(d_in, coded, use, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, c->stream));
+    LitBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
+    b.n_streams = 1; b.stream_len = out_len; b.max_stream_len = c->max_stream_len;
+    b.in = d_in; b.in_offsets = (const uint64_t*)d_meta; b.in_sizes = d_meta + 2; b.consumed = d_meta + 3;
+    b.out = d_out; b.status = c->d_status;
+    b.seg_begin = d_meta + 4; b.segs = (const LitSegment*)(d_meta + 8);
+    b.resume = c->sd_started ? 1u : 0u; b.wstate = c->d_wstate;
+    set_cache_fields(c, b);
+    HIP_TRY(launch_decode(b, c->mix, 1u, c->stream));
+    c->sd_started = true;
+    uint32_t words = 0, status = 0;
+    HIP_TRY(hipMemcpyAsync(&words, d_meta + 3, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&status, c->d_status, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out, out_len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (status & LIT_STATUS_BAD_STREAM) { (void)hipMemsetAsync(c->d_status, 0, 4, c->stream); return fail(DIVANS_GPU_ECORRUPT, "the literal stream fails its integrity check"); }
+    *consumed_bytes = (size_t)words * 4u;
     return 0;
 }
 

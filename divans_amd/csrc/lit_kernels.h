@@ -65,6 +65,10 @@ struct LitBatch {
     // stream of the previous one -- its CDF tables are kept (no row cache: cache_mode 0), the two Weights objects come back from
     // `wstate` ([2][3] ints: model_weights[1], [0]) -- and every launch leaves them there; the history arrives as a segment's last8
     uint32_t resume; int32_t* wstate;
+    // lit_decode_kernel under `resume` / `wstate` likewise (whole chunks per launch: a chunk starts from fresh rANS states, so nothing
+    // else carries over); `consumed` (optional, [n_streams]) receives the coded words a stream read, and with it set the words
+    // offered may outnumber the words read (the caller passes what has arrived so far)
+    uint32_t* consumed;
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
 constexpr uint32_t LIT_STATUS_BAD_SEGMENT = 4u;   // a segment names a literal block type outside the codec's context tables

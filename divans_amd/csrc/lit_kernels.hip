@@ -576,9 +576,10 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
         ww.in = (const uint32_t*)(b.in + b.in_offsets[s]);
         ww.nwords = b.in_sizes[s] >> 2;
         ww.start(li);
-        init_table(tb, g.total_rows, li);
+        if (!b.resume) init_table(tb, g.total_rows, li);
         WeightsPair wp; wp.init();
-        int nh = 1 << 14, nl = 1 << 14;     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
+        if (MIX && b.resume) { const int32_t* p = b.wstate + (li < 8 ? 0 : 3); wp.w.w0 = p[0]; wp.w.w1 = p[1]; wp.w.norm = p[2]; }
+        int nh = wp.norm_high(), nl = wp.norm_low();     // normalized_weight of model_weights[1] (high nibble) / [0] (low nibble)
         uint64_t last8 = 0;
         uint32_t ctab = LIT_BLOB_CTXF;      // context table of the current literal block type
         SegCursor sc;
@@ -649,7 +650,12 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
             // NeedsMoreInput or fail its checksum)
             corrupt |= (SA != (1ull << 31)) | (SB != (1ull << 31));
         }
-        corrupt |= ww.pos != ww.nwords;     // every coded word consumed, none read past the end
+        if (b.consumed) { corrupt |= ww.pos > ww.nwords; if (li == 0) b.consumed[s] = ww.pos; }
+        else corrupt |= ww.pos != ww.nwords;     // every coded word consumed, none read past the end
+        if (MIX && b.wstate && (li & 7) == 0) {   // lanes 0 and 8 of the row hold the two Weights objects
+            int32_t* p = b.wstate + (li ? 3 : 0);
+            p[0] = wp.w.w0; p[1] = wp.w.w1; p[2] = wp.w.norm;
+        }
         if (corrupt && li == 0) {
             if (b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
             if (b.stream_bad) b.stream_bad[s] = 1;

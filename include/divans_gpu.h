@@ -134,6 +134,14 @@ int divans_gpu_lit_stream_begin(divans_gpu_codec *c);
 int divans_gpu_lit_stream_encode(divans_gpu_codec *c, const uint8_t *in, uint32_t len, uint64_t last8, uint8_t *out, size_t out_cap,
                                  uint32_t *chunk_sizes, uint32_t max_chunks, uint32_t *n_chunks, size_t *out_len);
 int divans_gpu_lit_stream_finish(divans_gpu_codec *c, uint8_t *out, size_t out_cap, size_t *out_len);
+/* The other direction, whole 65 536-symbol chunks per call (a chunk starts from fresh rANS states: besides the CDF tables, the Weights
+ * and the history nothing carries over).  `coded` = the LIT-coder bytes from the current chunk boundary on, as many as have arrived
+ * (multiples of 4 are used); out_len = 32768 * k bytes of output, or fewer for the last chunk of the stream; *consumed_bytes = what those
+ * chunks occupied.  The caller makes sure the chunks it asks for are complete -- divans_gpu_lit_encode_bound(32768) bytes per chunk
+ * always are enough; DIVANS_GPU_ECORRUPT if a chunk does not end in the start states or reads past `coded_bytes`. */
+int divans_gpu_lit_stream_decode_begin(divans_gpu_codec *c);
+int divans_gpu_lit_stream_decode(divans_gpu_codec *c, const uint8_t *coded, size_t coded_bytes, uint32_t out_len, uint64_t last8,
+                                 uint8_t *out, size_t *consumed_bytes);
 
 /* Status of the device-pointer batch calls (they are asynchronous and return before the kernels ran).  Waits for the
  * codec's stream, stores the bits set since the previous call in *status and clears them:

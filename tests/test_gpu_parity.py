@@ -520,6 +520,24 @@ def test_stream_coded_piece_by_piece(cfg_name, corpus, random_then_unicode):
     codec.close()
 
 
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_stream_decoded_chunk_by_chunk(cfg_name, corpus, random_then_unicode):
+    # divans_gpu_lit_stream_decode: whole chunks per call, the model resumed (tables, Weights, history); each call is shown only
+    # the bound of the chunks it asks for, never the whole stream
+    data = np.concatenate([corpus[:70000], random_then_unicode[200000:260001]])
+    ref = po.lit_encode(_oracle_cfg(cfg_name), data)
+    da, codec = _codec(cfg_name, 65536)
+    for per_call in (1, 2):
+        back, used = codec.stream_decode_chunks(ref, data.size, chunks_per_call=per_call)
+        assert used == ref.size and (back == data).all(), per_call
+    with pytest.raises(da.DivansGpuError):                     # a call that is shown too little of its chunk says so
+        codec.stream_decode_chunks(ref, data.size, slack=1000)
+    bad = ref.copy(); bad[40000] ^= 4
+    with pytest.raises(da.DivansGpuError):
+        codec.stream_decode_chunks(bad, data.size)
+    codec.close()
+
+
 def test_bucketed_encoder_only_where_it_applies():
     import ctypes
     import divans_amd as da
