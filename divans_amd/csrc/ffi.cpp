@@ -35,10 +35,10 @@ struct DivansCompressorState {
 struct DivansDecompressorState {
     CAllocator alloc;
     bool skip_crc = false;
-    bool failed = false, decoded = false;
+    bool failed = false;
     size_t max_output = (size_t)1 << 30;   // bound on the decoded size a stream may claim (divans_decompressor_set_max_output_size)
-    std::vector<uint8_t> input, output;
-    size_t cursor = 0;
+    divans_host::StreamDecoder* dec = nullptr;   // DivansDecompressor: Mux, CMD coder, GPU literal decoder (host_stream.h); built by the first decode
+    ~DivansDecompressorState() { delete dec; }
 };
 
 extern "C" {
@@ -160,29 +160,13 @@ DivansResult divans_decode(struct DivansDecompressorState* s, const uint8_t* in,
                            uint8_t* out, size_t out_size, size_t* out_off) {
     if (!s || !in_off || !out_off || *in_off > in_size || *out_off > out_size) return DIVANS_FAILURE;
     if (s->failed) return DIVANS_FAILURE;
-    if (!s->decoded) {
-        if (in_size > *in_off) s->input.insert(s->input.end(), in + *in_off, in + in_size);
-        *in_off = in_size;
-        // magic / window are checkable as soon as the 16-byte header is in (divans_decompressor.rs:38-52)
-        if (s->input.size() >= 6) {
-            const uint8_t* h = s->input.data();
-            if (h[0] != 0xff || h[1] != 0xe5 || h[2] != 0x8c || h[3] != 0x9f || h[5] < 10 || h[5] >= 25) { s->failed = true; return DIVANS_FAILURE; }
-        }
-        // a complete stream ends with the trailer crc32c || "ans~" (codec/mod.rs:518-554)
-        const size_t n = s->input.size();
-        if (n < 16 + 3 + 8 || std::memcmp(s->input.data() + n - 4, "ans~", 4) != 0) return DIVANS_NEEDS_MORE_INPUT;
-        size_t consumed = 0;
-        const divans_host::ParseStatus st = divans_host::parse_container(s->input.data(), n, s->skip_crc, 0, s->output, &consumed, s->max_output);
-        if (st == divans_host::PARSE_NEED_MORE) return DIVANS_NEEDS_MORE_INPUT;   // "ans~" occurred inside the payload
-        if (st != divans_host::PARSE_OK) { s->failed = true; return DIVANS_FAILURE; }
-        s->decoded = true;
-        std::vector<uint8_t>().swap(s->input);
+    if (!s->dec) {
+        s->dec = new (std::nothrow) divans_host::StreamDecoder(s->skip_crc, s->max_output, 0);
+        if (!s->dec) { s->failed = true; return DIVANS_FAILURE; }
     }
-    const size_t room = out_size - *out_off, left = s->output.size() - s->cursor;
-    const size_t n = left < room ? left : room;
-    if (n) std::memcpy(out + *out_off, s->output.data() + s->cursor, n);
-    s->cursor += n; *out_off += n;
-    return s->cursor == s->output.size() ? DIVANS_SUCCESS : DIVANS_NEEDS_MORE_OUTPUT;
+    const int rc = s->dec->decode(in, in_size, in_off, out, out_size, out_off);
+    if (rc < 0) { s->failed = true; return DIVANS_FAILURE; }
+    return rc == 0 ? DIVANS_SUCCESS : (rc == 1 ? DIVANS_NEEDS_MORE_INPUT : DIVANS_NEEDS_MORE_OUTPUT);
 }
 
 // extension (not in c/divans/ffi.h): the literal lengths of a stream are its own claim; refuse streams that claim more

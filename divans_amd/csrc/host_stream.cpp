@@ -1000,22 +1000,148 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
     return PARSE_OK;
 }
 
-ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,
-                            size_t max_output) {
-    out.clear();
-    ParsedStream ps;
-    const ParseStatus st = parse_container_host(in, n, skip_crc, max_output, ps, consumed);
-    if (st != PARSE_OK || ps.total == 0) return st;
-    GpuCodecHandle h;
-    if (h.acquire(ps.cfg, device, (uint32_t)ps.total)) return PARSE_GPU_ERROR;
-    const uint64_t off = 0; const uint32_t size = (uint32_t)ps.lit.size();
-    ps.lit.resize(ps.lit.size() + 64, 0);
-    out.resize(ps.total);
-    const int drc = divans_gpu_lit_decode_host(h.c, ps.lit.data(), &off, &size, 1, out.data(), (uint32_t)ps.total);
-    if (drc == DIVANS_GPU_ECORRUPT) { out.clear(); return PARSE_CORRUPT; }   // short / corrupt / mismatched LIT stream
-    if (drc) return PARSE_GPU_ERROR;
-    return PARSE_OK;
+// ---------------------------------------------------------------- the decompressor, one call at a time
+struct StreamDecoder::Impl {
+    bool skip_crc; size_t max_output; int device;
+    uint8_t hdr[16]; int hdr_have = 0;
+    Mux mux; uint32_t crc = 0;
+    uint8_t trailer[8]; int trailer_have = 0; bool trailer_ok = false;
+    // what the CMD coder has told so far (re-read from its first byte whenever more of it has arrived: it is a few hundred bytes)
+    size_t cmd_seen = 0; bool cmd_done = false, have_cfg = false; uint64_t known = 0; divans_lit_config cfg;
+    GpuCodecHandle gpu; bool lit_started = false;
+    uint64_t done = 0; uint64_t last8 = 0;
+    std::vector<uint8_t> ready; size_t ready_pos = 0;      // decoded, not yet handed out
+    int error = 0;
+
+    int read_commands() {       // codec/mod.rs:652-792 on the CMD bytes that are in; a command whose bytes are not all there is not counted
+        Mux::Stream& c = mux.s[0];
+        if (cmd_done || c.avail() == cmd_seen) return 0;
+        cmd_seen = c.avail();
+        StreamOptions o;
+        CommandModel model(o);
+        RansDecoder cd(c.buf.data() + c.start, c.avail());
+        NibbleCoder nc; nc.dec = &cd;
+        uint8_t btype = 0; bool have_pm = false, seen_literal = false;
+        uint64_t total = 0;
+        for (;;) {
+            const int code = model.command_type(nc, 0);
+            if (cd.starved) break;
+            if (code == 0xf) { cmd_done = true; break; }
+            if (code == 7) {
+                if (seen_literal) return -101;
+                if (!model.prediction_mode(nc, nullptr)) { if (cd.starved) break; return -100; }
+                if (cd.starved) break;
+                have_pm = true;
+            } else if (code == 4) {
+                if (seen_literal) return -101;
+                model.block_switch_literal(nc, 0, 0, btype);
+                if (cd.starved) break;
+            } else if (code == 3) {
+                uint32_t len;
+                if (!model.literal_length(nc, 15, len)) { if (cd.starved) break; return -100; }
+                if (cd.starved) break;
+                if (!have_cfg) {         // the first Literal fixes the configuration the LIT coder runs under
+                    if (have_pm) model.fill_lit_config(cfg, btype);
+                    else { std::memset(&cfg, 0, sizeof(cfg)); cfg.btype = btype; for (auto& sp : cfg.literal_adaptation) sp = divans_speed{0x10, 0x2000}; }
+                    have_cfg = true;
+                }
+                total += len; seen_literal = true;
+                if (total > 0x7fffffffu) return -101;
+                if (total > max_output) return -100;
+            } else return -101;   // Copy / Dict / command- and distance- block switches
+        }
+        known = total;
+        return 0;
+    }
+    // decodes what can be decoded now: whole chunks the commands cover and whose coded bytes are certainly complete, everything once
+    // the container has ended
+    int decode_chunks() {
+        Mux::Stream& l = mux.s[1];
+        const size_t chunk_bound = (size_t)divans_gpu_lit_encode_bound(32768);
+        for (;;) {
+            if (ready.size() - ready_pos > (1u << 20)) return 0;          // the caller first takes what is there
+            uint32_t want = 0;
+            if (mux.eof == 3 && cmd_done) want = (uint32_t)std::min<uint64_t>(known - done, 65536u);
+            else if (known >= done + 32768u && l.avail() >= chunk_bound) want = (known >= done + 65536u && l.avail() >= 2 * chunk_bound) ? 65536u : 32768u;
+            if (want == 0) return 0;
+            if (!lit_started) {
+                int rc = gpu.acquire(cfg, device, 65536u); if (rc) return rc;
+                rc = divans_gpu_lit_stream_decode_begin(gpu.c); if (rc) return rc;
+                lit_started = true;
+            }
+            if (ready_pos == ready.size()) { ready.clear(); ready_pos = 0; }
+            const size_t at = ready.size();
+            ready.resize(at + want);
+            size_t used = 0;
+            const int rc = divans_gpu_lit_stream_decode(gpu.c, l.buf.data() + l.start, l.avail(), want, last8, ready.data() + at, &used);
+            if (rc) return rc == DIVANS_GPU_ECORRUPT ? -100 : rc;
+            if (used > l.avail()) return -100;
+            l.start += used;
+            for (size_t i = want < 8 ? 0 : want - 8; i < want; ++i) last8 = (last8 >> 8) | ((uint64_t)ready[at + i] << 56);
+            done += want;
+        }
+    }
+};
+
+StreamDecoder::StreamDecoder(bool skip_crc, size_t max_output, int device) : p_(new Impl()) { p_->skip_crc = skip_crc; p_->max_output = max_output; p_->device = device; }
+StreamDecoder::~StreamDecoder() { delete p_; }
+
+int StreamDecoder::decode(const uint8_t* in, size_t n, size_t* in_off, uint8_t* out, size_t cap, size_t* out_off) {
+    Impl& s = *p_;
+    if (s.error) return s.error;
+    auto fail_with = [&](int e) { s.error = e; return e; };
+    for (;;) {
+        // hand out what is decoded
+        if (s.ready_pos < s.ready.size()) {
+            const size_t k = std::min(s.ready.size() - s.ready_pos, cap - *out_off);
+            std::memcpy(out + *out_off, s.ready.data() + s.ready_pos, k);
+            s.ready_pos += k; *out_off += k;
+            if (s.ready_pos < s.ready.size()) return 2;
+        }
+        if (s.trailer_ok && s.cmd_done && s.done == s.known) {
+            if (s.mux.s[1].avail() != 0) return fail_with(-100);          // LIT bytes nobody asked for
+            return 0;
+        }
+        // take input: header, Mux slices, trailer
+        bool progressed = false;
+        if (s.hdr_have < 16 && *in_off < n) {
+            const size_t k = std::min<size_t>(16 - s.hdr_have, n - *in_off);
+            std::memcpy(s.hdr + s.hdr_have, in + *in_off, k); s.crc = crc32c(s.crc, in + *in_off, k);
+            s.hdr_have += (int)k; *in_off += k; progressed = true;
+            const int h = s.hdr_have;     // magic / window are checkable as soon as they are in (divans_decompressor.rs:38-52)
+            if ((h > 0 && s.hdr[0] != 0xff) || (h > 1 && s.hdr[1] != 0xe5) || (h > 2 && s.hdr[2] != 0x8c) || (h > 3 && s.hdr[3] != 0x9f) ||
+                (h > 5 && (s.hdr[5] < 10 || s.hdr[5] >= 25))) return fail_with(-100);
+        }
+        if (s.hdr_have == 16 && s.mux.eof != 3 && *in_off < n) {
+            const size_t k = s.mux.deserialize(in + *in_off, n - *in_off);
+            s.crc = crc32c(s.crc, in + *in_off, k);
+            *in_off += k; progressed = progressed || k != 0;
+            if (k == 0 && s.mux.eof != 3) return fail_with(-100);          // bytes that are neither a slice nor the end marker
+        }
+        if (s.mux.eof == 3 && !s.trailer_ok && *in_off < n) {
+            const size_t k = std::min<size_t>(8 - s.trailer_have, n - *in_off);
+            std::memcpy(s.trailer + s.trailer_have, in + *in_off, k);
+            s.trailer_have += (int)k; *in_off += k; progressed = true;
+            if (s.trailer_have == 8) {                                     // codec/mod.rs:949-1017
+                const uint8_t want[8] = {(uint8_t)s.crc, (uint8_t)(s.crc >> 8), (uint8_t)(s.crc >> 16), (uint8_t)(s.crc >> 24), 'a', 'n', 's', '~'};
+                if (std::memcmp(s.trailer + 4, want + 4, 4) != 0 || (!s.skip_crc && std::memcmp(s.trailer, want, 4) != 0)) return fail_with(-100);
+                s.trailer_ok = true;
+                if (s.mux.s[1].avail() % 4) return fail_with(-100);
+            }
+        }
+        if (int rc = s.read_commands()) return fail_with(rc);
+        if (s.mux.eof == 3 && !s.cmd_done) return fail_with(-100);          // the container ended before its command stream did
+        if (s.have_cfg || s.known == 0) {
+            const uint64_t before = s.done;
+            if (s.known) { if (int rc = s.decode_chunks()) return fail_with(rc); }
+            progressed = progressed || s.done != before;
+        }
+        if (s.ready_pos < s.ready.size()) continue;
+        if (s.trailer_ok && s.cmd_done && s.done == s.known) continue;
+        if (!progressed) return 1;                                          // nothing more can be done with what has arrived
+    }
 }
+
 
 }  // namespace divans_host
 

@@ -68,12 +68,25 @@ class StreamEncoder {
     Impl* p_;
 };
 
-enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
-// Decodes a complete container (header .. "ans~").  PARSE_NEED_MORE when `n` bytes do not yet hold the whole stream.
-// `max_output` bounds the decoded size the stream may claim (literal lengths come from the stream itself).
-ParseStatus parse_container(const uint8_t* in, size_t n, bool skip_crc, int device, std::vector<uint8_t>& out, size_t* consumed,
-                            size_t max_output = (size_t)1 << 30);
+// DivansDecompressor for literal-only containers, call by call (src/divans_decompressor.rs:356-397): the container is demultiplexed
+// as it arrives, the CMD coder is read as far as its bytes reach (command types, the PredictionMode, literal lengths), and the
+// literals are decoded on the GPU one or two 65 536-symbol chunks at a time as soon as the commands read so far cover them and their
+// coded bytes are certainly in (divans_gpu_lit_stream_decode); decoded bytes are handed out in the same call.  Neither the container
+// nor the output is held as a whole.  decode() returns 0 (done), 1 (NeedsMoreInput), 2 (NeedsMoreOutput) or a negative code:
+// a DIVANS_GPU_E* value, -100 corrupt, -101 a stream this decoder does not take (Copy / Dict commands, a second PredictionMode).
+class StreamDecoder {
+  public:
+    StreamDecoder(bool skip_crc, size_t max_output, int device);
+    ~StreamDecoder();
+    StreamDecoder(const StreamDecoder&) = delete;
+    StreamDecoder& operator=(const StreamDecoder&) = delete;
+    int decode(const uint8_t* in, size_t n, size_t* in_off, uint8_t* out, size_t cap, size_t* out_off);
+  private:
+    struct Impl;
+    Impl* p_;
+};
 
+enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
 struct ParsedStream { divans_lit_config cfg; size_t total = 0; std::vector<uint8_t> lit; };
 // The host half of parse_container: framing + CRC + CMD coder; `ps` gets the LIT-coder bytes, the decoded size and the LIT configuration.
 ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed);

@@ -13,8 +13,10 @@
  * The compressor works call by call as the reference's does (src/divans_compressor.rs:276-426): input goes into a ring of 2^window
  * bytes, a lap is coded inside the divans_encode() call that completes it (its literals on the GPU, resuming the stream's model),
  * container bytes leave in that call as far as the Mux releases them, and divans_encode() returns DIVANS_NEEDS_MORE_OUTPUT with part
- * of the input untaken exactly where the reference does.  The decompressor still collects the container before it decodes; it
- * accepts literal-only streams (one PredictionMode before the first Literal).
+ * of the input untaken exactly where the reference does.  The decompressor works the same way (src/divans_decompressor.rs:356-397):
+ * it demultiplexes the container as it arrives, reads the CMD coder as far as its bytes reach and decodes the literals one or two
+ * 65 536-symbol chunks at a time on the GPU as soon as the commands read so far cover them, handing the bytes out in the same call;
+ * it accepts literal-only streams (one PredictionMode before the first Literal).
  * include/divans_io.hpp wraps this ABI in the reference's writer / reader adaptors (src/writer.rs, src/reader.rs).
  */
 #ifndef DIVANS_FFI_H_
