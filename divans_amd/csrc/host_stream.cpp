@@ -1073,7 +1073,8 @@ struct StreamDecoder::Impl {
             const size_t at = ready.size();
             ready.resize(at + want);
             size_t used = 0;
-            const int rc = divans_gpu_lit_stream_decode(gpu.c, l.buf.data() + l.start, l.avail(), want, last8, ready.data() + at, &used);
+            const size_t show = std::min<size_t>(l.avail(), (size_t)((want + 32767u) / 32768u) * chunk_bound);   // no chunk needs more than its bound
+            const int rc = divans_gpu_lit_stream_decode(gpu.c, l.buf.data() + l.start, show, want, last8, ready.data() + at, &used);
             if (rc) return rc == DIVANS_GPU_ECORRUPT ? -100 : rc;
             if (used > l.avail()) return -100;
             l.start += used;
