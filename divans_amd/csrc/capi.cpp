@@ -104,6 +104,7 @@ struct divans_gpu_codec {
     bool cache_unified = false;
     // decoder generation: 2 = lit_decode2.hip (direct-mapped row caches, LDS word ring), 1 = lit_decode_kernel of lit_kernels.hip
     uint32_t decode_gen = 2;
+    bool dm_auto = true;          // nobody chose between direct-mapped and 2-way caches (divans_gpu_codec_set_decoder): pick per batch
     uint32_t dm_log2 = 0, dm_shift = 0;   // LitBatch::dm_log2 / dm_shift
     uint32_t blocks2 = 0;                 // persistent grid of lit_decode2_kernel
     bool user_geometry = false;           // set_geometry / set_split_cache / set_decoder were called: set_block_types keeps their choices
@@ -500,6 +501,7 @@ extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t genera
     if (generation < 1u || generation > 3u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches) or 3 (second generation, 2-way caches)");
     HIP_TRY(hipSetDevice(c->device));
     const bool two_way = generation == 3u;
+    c->dm_auto = false;
     if (generation == 3u) generation = 2u;
     c->dm_shift = (c->dm_shift & 0x7fffffffu) | (two_way ? 0x80000000u : 0u);
     if (generation == 2u && rows && shifts) {
@@ -785,6 +787,10 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     if (d_segs && !use_decode2(c) && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
     if (use_decode2(c)) {
         b.dm_log2 = lit_decode2_effective_caches(c->dm_log2, c->mix, d_segs != nullptr); b.dm_shift = c->dm_shift;
+        // A batch that is resident all at once runs at the latency of a stream's dependency chain, and the direct-mapped lookup is
+        // the shorter chain (16 384 streams: 60.3 vs 63.5 ms, mixing 138 vs 142); only a batch that keeps the grid busy for several
+        // rounds gains from the 2-way sets' fewer misses (profiles/r03c_small_batch_geometry.txt)
+        if (c->dm_auto && n_streams <= c->blocks2 * groups_per_block(c)) b.dm_shift &= 0x7fffffffu;
         b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
