@@ -320,7 +320,11 @@ __device__ __forceinline__ uint32_t mix_nibble(Weights& w, uint32_t st_x, uint32
 // together -- every 16-byte load instruction covers 128-byte runs of eight streams -- into LDS, 16 positions at a time,
 // double-buffered; each lane then reads its own stream's records from LDS, and the (start, freq) pairs go back out the
 // same way (a lane-per-stream walk straight over global memory costs one 16-byte request per lane and load).
-constexpr uint32_t MW_CHUNK = 16;                       // positions per LDS buffer
+constexpr uint32_t MW_CHUNK = 16;                       // positions per LDS buffer (8 or 4 -- more, smaller workgroups per CU -- cost 13 % / 25 % of the model pass)
+constexpr uint32_t MW_PIECES = MW_CHUNK / 2u;           // 16-byte pieces (two records) of a stream's chunk in one plane
+constexpr uint32_t MW_SPL = 64u / MW_PIECES;            // streams one load instruction of the wave covers
+constexpr uint32_t MW_GROUPS = 32u / MW_SPL;            // such loads per plane
+constexpr uint32_t MW_NLOAD = 4u * MW_GROUPS;
 constexpr uint32_t MW_IN_STRIDE = 4u * MW_CHUNK * 8u + 16u;   // bytes per stream: 4 planes x 16 records, padded against bank conflicts
 constexpr uint32_t MW_OUT_STRIDE = 2u * MW_CHUNK * 4u + 16u;
 constexpr uint32_t MW_IN_BYTES = 32u * MW_IN_STRIDE;
@@ -334,21 +338,21 @@ __global__ __launch_bounds__(64) void mix_weights_kernel(const MixBucketBatch b)
     const uint32_t cs = s0 + (lane >> 1), half = lane & 1u;
     const uint32_t len = cs < b.n_streams ? (b.in_sizes ? b.in_sizes[cs] : b.stream_len) : 0u;
     // mover role: stream s0 + 8 i + lane / 8 of load i, records 2 (lane & 7), 2 (lane & 7) + 1 of the chunk
-    const uint32_t mq = lane & 7u, mj = lane >> 3;
+    const uint32_t mq = lane % MW_PIECES, mj = lane / MW_PIECES;
     const uint32_t chunks = (b.stream_len + MW_CHUNK - 1u) / MW_CHUNK;     // stream_len = the longest stream of the batch
     Weights w; w.w0 = 1; w.w1 = 1; w.norm = 1 << 14;               // weights.rs:15-21
-    u32x4 r[16];
+    u32x4 r[MW_NLOAD];
 #define MW_FETCH(C)                                                                                     \
-    _Pragma("unroll") for (uint32_t i = 0; i < 16u; ++i) {                                              \
-        const uint32_t plane = i >> 2, j = (i & 3u) * 8u + mj;                                          \
+    _Pragma("unroll") for (uint32_t i = 0; i < MW_NLOAD; ++i) {                                         \
+        const uint32_t plane = i / MW_GROUPS, j = (i % MW_GROUPS) * MW_SPL + mj;                        \
         const uint32_t p = (C) * MW_CHUNK + 2u * mq;                                                    \
         const bool ok = s0 + j < b.n_streams && p < b.max_stream_len;                                   \
         const u32x2* src = b.pos[plane] + (ok ? (size_t)(s0 + j) * b.pos_stride + p : 0u);          \
         r[i] = __builtin_nontemporal_load((const u32x4*)src);                                           \
     }
 #define MW_STAGE(BUF)                                                                                   \
-    _Pragma("unroll") for (uint32_t i = 0; i < 16u; ++i) {                                              \
-        const uint32_t plane = i >> 2, j = (i & 3u) * 8u + mj;                                          \
+    _Pragma("unroll") for (uint32_t i = 0; i < MW_NLOAD; ++i) {                                         \
+        const uint32_t plane = i / MW_GROUPS, j = (i % MW_GROUPS) * MW_SPL + mj;                        \
         *(u32x4*)(lds_in + (BUF) * MW_IN_BYTES + j * MW_IN_STRIDE + plane * (MW_CHUNK * 8u) + mq * 16u) = r[i]; \
     }
     if (chunks == 0u) return;
@@ -371,8 +375,8 @@ __global__ __launch_bounds__(64) void mix_weights_kernel(const MixBucketBatch b)
         __syncthreads();
         // pairs out: load-shaped again, 16 bytes = both nibbles of two positions per lane
 #pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i) {
-            const uint32_t j = i * 8u + mj, p = p0 + 2u * mq;
+        for (uint32_t i = 0; i < MW_GROUPS; ++i) {
+            const uint32_t j = i * MW_SPL + mj, p = p0 + 2u * mq;
             const uint32_t slen = s0 + j < b.n_streams ? (b.in_sizes ? b.in_sizes[s0 + j] : b.stream_len) : 0u;
             if (p < slen)   // an odd stream's last quad carries one stale pair: it stays inside the (even) slot and is never read
                 *(u32x4*)(b.sf + (size_t)(s0 + j) * b.sf_stride + 2u * p) = *(const u32x4*)(lds_out + j * MW_OUT_STRIDE + mq * 16u);
