@@ -178,9 +178,9 @@ static uint8_t speed_to_u8(int16_t d) {
 uint8_t speed_to_f8(int16_t v) { return speed_to_u8(v); }
 static int16_t u8_to_speed(uint8_t d) {
     if (d < 8) return 0;
-    const int lg = (d >> 3) - 1;
-    const int16_t rem = (int16_t)(((int16_t)d & 7) << lg);
-    return (int16_t)((int16_t)(1 << lg) | (rem >> 3));
+    const int lg = ((d >> 3) - 1) & 15;       // exponents past 15 only come from damaged streams; an i16 shift in a release build of the reference takes the amount mod 16
+    const int16_t rem = (int16_t)(uint16_t)(((uint32_t)d & 7u) << lg);
+    return (int16_t)((int16_t)(uint16_t)(1u << lg) | (rem >> 3));
 }
 
 // ---------------------------------------------------------------- command-stream model
@@ -377,7 +377,7 @@ class Mux {
         if (have) std::memcpy(nb.data() + 3, b.buf.data() + b.start, have);
         b.buf.swap(nb); b.end = 3 + have; b.start = 3;
     }
-    void push(int id, const uint8_t* p, size_t n) { prep(id, n); std::memcpy(s[id].buf.data() + s[id].end, p, n); s[id].end += n; }
+    void push(int id, const uint8_t* p, size_t n) { if (!n) return; prep(id, n); std::memcpy(s[id].buf.data() + s[id].end, p, n); s[id].end += n; }
 
     size_t serialize(uint8_t* out, size_t cap) {   // :445-476
         size_t off = 0;

@@ -117,9 +117,9 @@ uint8_t orc_speed_to_u8(int16_t data) {
 /* probability/interface.rs:577-585 */
 int16_t orc_u8_to_speed(uint8_t data) {
     if (data < 8) return 0;
-    uint8_t log_val = (uint8_t)((data >> 3) - 1);
-    int16_t rem = (int16_t)(((int16_t)data & 0x7) << log_val);
-    return (int16_t)((int16_t)(1 << log_val) | (rem >> 3));
+    unsigned log_val = ((unsigned)(data >> 3) - 1u) & 15u; /* > 15 only in damaged streams: release-build i16 shifts take the amount mod 16 */
+    int16_t rem = (int16_t)(uint16_t)(((unsigned)data & 0x7u) << log_val);
+    return (int16_t)((int16_t)(uint16_t)(1u << log_val) | (rem >> 3));
 }
 
 /* probability/interface.rs:303-320 */

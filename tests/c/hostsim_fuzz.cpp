@@ -1,0 +1,150 @@
+// TEST HARNESS (see hostsim_device_stub.cpp): the per-stream C ABI's host logic under AddressSanitizer / UBSan.
+//
+//   hostsim_fuzz <file> <seed> <iterations> [selector=value ...]
+//
+// 1. compresses <file> through divans_encode / divans_encode_flush with seeded random input pieces and output buffer sizes (1 byte ..
+//    64 KiB), decompresses it the same way and compares;
+// 2. `iterations` times: damages the container (bit flips, overwritten runs, truncation, deleted / duplicated / inserted spans, a splice
+//    of two containers) and decodes it with random piece and buffer sizes, with and without the CRC check.  The decoder may answer
+//    DIVANS_FAILURE, may ask for input that does not exist, or -- when the damage was harmless -- succeed; what it may not do is touch
+//    memory it does not own (the sanitizers abort), spin without progress, hand out more than max_output, or report success with wrong
+//    bytes while the CRC is checked.
+// exit 0 = all held; prints one summary line.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/divans_ffi.h"
+
+static uint64_t rng_state;
+static uint64_t rnd() {                       // xorshift64*
+    rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
+    return rng_state * 2685821237909765ull;
+}
+static size_t rnd_below(size_t n) { return n ? (size_t)(rnd() % n) : 0; }
+static size_t rnd_size() {                   // skewed: tiny, small and buffer-sized values all occur
+    switch (rnd() % 4) {
+        case 0: return 1 + rnd_below(16);
+        case 1: return 1 + rnd_below(700);
+        case 2: return 1 + rnd_below(8192);
+        default: return 1 + rnd_below(65536);
+    }
+}
+
+typedef std::vector<uint8_t> Bytes;
+
+static bool compress(const Bytes& in, const std::vector<std::pair<unsigned, unsigned>>& opts, bool fixed_sizes, Bytes& out) {
+    DivansCompressorState* st = divans_new_compressor();
+    for (auto& o : opts) if (divans_set_option(st, (DivansOptionSelect)o.first, o.second) != DIVANS_SUCCESS) { std::fprintf(stderr, "option %u=%u refused\n", o.first, o.second); return false; }
+    Bytes buf(65536);
+    size_t off = 0;
+    while (off < in.size()) {
+        const size_t piece = fixed_sizes ? in.size() - off : std::min(in.size() - off, rnd_size());
+        size_t done = 0; int idle = 0;
+        while (done < piece) {
+            const size_t cap = fixed_sizes ? buf.size() : rnd_size();
+            size_t ro = 0, wo = 0;
+            const DivansResult r = divans_encode(st, in.data() + off + done, piece - done, &ro, buf.data(), cap, &wo);
+            if (r == DIVANS_FAILURE || ro > piece - done || wo > cap) { std::fprintf(stderr, "encode failed (%d)\n", (int)r); return false; }
+            done += ro; out.insert(out.end(), buf.begin(), buf.begin() + wo);
+            idle = (ro | wo) ? 0 : idle + 1;
+            if (idle > 4) { std::fprintf(stderr, "encode makes no progress\n"); return false; }
+        }
+        off += piece;
+    }
+    for (int idle = 0;;) {
+        const size_t cap = fixed_sizes ? buf.size() : rnd_size();
+        size_t wo = 0;
+        const DivansResult r = divans_encode_flush(st, buf.data(), cap, &wo);
+        if (r == DIVANS_FAILURE || wo > cap) { std::fprintf(stderr, "flush failed\n"); return false; }
+        out.insert(out.end(), buf.begin(), buf.begin() + wo);
+        if (r == DIVANS_SUCCESS) break;
+        idle = wo ? 0 : idle + 1;
+        if (idle > 4) { std::fprintf(stderr, "flush makes no progress\n"); return false; }
+    }
+    divans_free_compressor(st);
+    return true;
+}
+
+enum Outcome { OK = 0, FAILED = 1, WANTS_INPUT = 2, STUCK = 3, OVERRUN = 4 };
+
+static Outcome decompress(const Bytes& coded, bool skip_crc, bool fixed_sizes, size_t limit, Bytes& out) {
+    struct CAllocator none = {nullptr, nullptr, nullptr};
+    DivansDecompressorState* st = divans_new_decompressor_with_custom_alloc(none, skip_crc ? 1 : 0, 0);
+    Bytes buf(65536);
+    size_t off = 0; int idle = 0; Outcome res = STUCK;
+    for (;;) {
+        const size_t feed = std::min(coded.size() - off, fixed_sizes ? (size_t)100000 : rnd_size());
+        const size_t cap = fixed_sizes ? buf.size() : rnd_size();
+        size_t ro = 0, wo = 0;
+        const DivansResult r = divans_decode(st, coded.data() + off, feed, &ro, buf.data(), cap, &wo);
+        if (ro > feed || wo > cap) { res = OVERRUN; break; }
+        off += ro; out.insert(out.end(), buf.begin(), buf.begin() + wo);
+        if (out.size() > limit) { res = OVERRUN; break; }
+        if (r == DIVANS_SUCCESS) { res = OK; break; }
+        if (r == DIVANS_FAILURE) { res = FAILED; break; }
+        if (r == DIVANS_NEEDS_MORE_INPUT && off == coded.size() && feed == 0) { res = WANTS_INPUT; break; }
+        idle = (ro | wo) ? 0 : idle + 1;
+        if (idle > 8) { res = STUCK; break; }
+    }
+    divans_free_decompressor(st);
+    return res;
+}
+
+static void damage(Bytes& c, const Bytes& other) {
+    const int kinds = 1 + (int)(rnd() % 3);
+    for (int k = 0; k < kinds && !c.empty(); ++k) {
+        const size_t at = (rnd() % 4 == 0) ? rnd_below(std::min<size_t>(c.size(), 64)) : rnd_below(c.size());   // the header and the first slices get their share
+        switch (rnd() % 8) {
+            case 0: c[at] ^= (uint8_t)(1u << (rnd() % 8)); break;
+            case 1: { const size_t n = std::min(c.size() - at, 1 + rnd_below(32)); for (size_t i = 0; i < n; ++i) c[at + i] = (uint8_t)rnd(); break; }
+            case 2: c.resize(at); break;
+            case 3: { const size_t n = std::min(c.size() - at, 1 + rnd_below(300)); c.erase(c.begin() + at, c.begin() + at + n); break; }
+            case 4: { const size_t n = std::min(c.size() - at, 1 + rnd_below(300)); Bytes d(c.begin() + at, c.begin() + at + n); c.insert(c.begin() + at, d.begin(), d.end()); break; }
+            case 5: { Bytes d(1 + rnd_below(64)); for (auto& b : d) b = (uint8_t)rnd(); c.insert(c.begin() + at, d.begin(), d.end()); break; }
+            case 6: { const size_t n = std::min(c.size() - at, 1 + rnd_below(8)); for (size_t i = 0; i < n; ++i) c[at + i] = (rnd() & 1) ? 0xff : 0x00; break; }
+            default: if (!other.empty()) { const size_t from = rnd_below(other.size()); c.resize(at); c.insert(c.end(), other.begin() + from, other.end()); } break;
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) { std::fprintf(stderr, "usage: hostsim_fuzz <file> <seed> <iterations> [selector=value ...]\n"); return 2; }
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    Bytes data; { uint8_t tmp[65536]; size_t n; while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) data.insert(data.end(), tmp, tmp + n); }
+    std::fclose(f);
+    rng_state = std::strtoull(argv[2], nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
+    const long iterations = std::strtol(argv[3], nullptr, 0);
+    std::vector<std::pair<unsigned, unsigned>> opts;
+    for (int i = 4; i < argc; ++i) { unsigned s, v; if (std::sscanf(argv[i], "%u=%u", &s, &v) == 2) opts.push_back({s, v}); }
+
+    // 1. the same bytes whatever the caller's buffer sizes are NOT expected (the Mux's slices depend on them); the same CONTENT is
+    Bytes plain, ragged, back;
+    if (!compress(data, opts, true, plain) || !compress(data, opts, false, ragged)) return 3;
+    for (const Bytes* c : {&plain, &ragged})
+        for (int fixed = 0; fixed < 2; ++fixed) {
+            back.clear();
+            const Outcome o = decompress(*c, false, fixed != 0, data.size(), back);
+            if (o != OK || back != data) { std::fprintf(stderr, "round trip failed: outcome %d, %zu of %zu bytes\n", (int)o, back.size(), data.size()); return 4; }
+        }
+    // trailing bytes behind a complete container are not consumed and do not turn success into failure
+    { Bytes t = plain; t.insert(t.end(), 100, 0x5a); back.clear(); if (decompress(t, false, true, data.size(), back) != OK || back != data) { std::fprintf(stderr, "trailing bytes changed the result\n"); return 5; } }
+
+    long n_ok = 0, n_failed = 0, n_wants = 0;
+    for (long it = 0; it < iterations; ++it) {
+        Bytes c = (rnd() & 1) ? plain : ragged;
+        damage(c, (rnd() & 1) ? plain : ragged);
+        const bool skip_crc = (rnd() % 3) == 0;
+        back.clear();
+        const Outcome o = decompress(c, skip_crc, (rnd() % 4) == 0, data.size() + (1u << 20), back);
+        if (o == STUCK || o == OVERRUN) { std::fprintf(stderr, "iteration %ld: decoder %s\n", it, o == STUCK ? "makes no progress" : "overran a bound"); return 6; }
+        if (o == OK && !skip_crc && back != data) { std::fprintf(stderr, "iteration %ld: success with wrong bytes under the CRC\n", it); return 7; }
+        n_ok += o == OK; n_failed += o == FAILED; n_wants += o == WANTS_INPUT;
+    }
+    std::printf("containers %zu / %zu bytes for %zu; %ld damaged: %ld refused, %ld starved, %ld decoded\n", plain.size(), ragged.size(), data.size(), iterations, n_failed, n_wants, n_ok);
+    return 0;
+}

@@ -1,0 +1,54 @@
+"""Builds the host-logic test harness of tests/c: the product's per-stream host code (divans_amd/csrc/host_stream.cpp, ffi.cpp)
+linked against tests/c/hostsim_device_stub.cpp, which answers the nine GPU entry points that code uses with the CPU oracle.
+TEST INFRASTRUCTURE: nothing in divans_amd/ knows of it; it exists so that the call-by-call container logic and the parser of
+untrusted input run in the "not gpu" tier, and under AddressSanitizer / UBSan."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "c", "_build")
+
+CXX_SOURCES = ["divans_amd/csrc/host_stream.cpp", "divans_amd/csrc/ffi.cpp", "tests/c/hostsim_device_stub.cpp"]
+C_SOURCES = ["oracle/cdf.c", "oracle/ans.c", "oracle/literal.c", "oracle/crc32c.c", "oracle/stream.c"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    deps = list(sources) + [os.path.join(ROOT, "divans_amd", "csrc", "host_stream.h"), os.path.join(ROOT, "oracle", "divans_oracle.h"),
+                            os.path.join(ROOT, "include", "divans_gpu.h"), os.path.join(ROOT, "include", "divans_ffi.h"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _objects(tag, flags):
+    os.makedirs(OUT, exist_ok=True)
+    objs = []
+    for src in CXX_SOURCES + C_SOURCES:
+        path = os.path.join(ROOT, src)
+        obj = os.path.join(OUT, tag + "_" + os.path.basename(src) + ".o")
+        if _newer(obj, [path]):
+            cc = ["g++", "-std=c++17"] if src.endswith(".cpp") else ["gcc", "-std=c11"]
+            subprocess.run(cc + flags + ["-fPIC", "-c", path, "-o", obj, "-I" + os.path.join(ROOT, "include")], check=True)
+        objs.append(obj)
+    return objs
+
+
+def build_library():
+    """tests/c/_build/libdivans_hostsim.so: the per-stream C ABI over the oracle-backed device stub, for ctypes."""
+    lib = os.path.join(OUT, "libdivans_hostsim.so")
+    objs = _objects("so", ["-O2", "-g", "-msse4.2"])
+    if _newer(lib, objs):
+        subprocess.run(["g++", "-shared", "-Wl,-Bsymbolic", "-o", lib] + objs + ["-lpthread"], check=True)   # its own divans_* symbols, whatever else the process has loaded
+    return lib
+
+
+def build_fuzzer():
+    """tests/c/_build/hostsim_fuzz: tests/c/hostsim_fuzz.cpp with the same objects, everything under -fsanitize=address,undefined."""
+    exe = os.path.join(OUT, "hostsim_fuzz")
+    san = ["-O1", "-g", "-msse4.2", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    objs = _objects("san", san)
+    driver = os.path.join(ROOT, "tests", "c", "hostsim_fuzz.cpp")
+    if _newer(exe, objs + [driver]):
+        subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
+    return exe

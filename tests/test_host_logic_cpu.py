@@ -1,0 +1,115 @@
+"""The per-stream container logic of the product on the CPU tier.
+
+divans_amd/csrc/host_stream.cpp + ffi.cpp (ring-buffer command emission, CMD coder, Mux, CRC, the call-by-call semantics of
+divans_encode / divans_encode_flush / divans_decode, the parser of untrusted containers) are built here against
+tests/c/hostsim_device_stub.cpp, which answers the nine GPU entry points they use with the CPU oracle -- test infrastructure, see
+tests/hostsim.py.  What these tests pin is the HOST code: the same source files the product library is built from, compared with
+the oracle's container (itself checked against the independent restatement of tests/ref_container.py), and run under
+AddressSanitizer / UBSan against damaged input.  The kernels are not involved; their parity tests are the "-m gpu" tier."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ffi_harness as fh
+import hostsim
+import pyoracle as po
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return fh.bind(ctypes.CDLL(hostsim.build_library()))
+
+
+@pytest.fixture(scope="module")
+def fuzzer():
+    return hostsim.build_fuzzer()
+
+
+@pytest.mark.parametrize("which", range(len(fh.OPTION_SETS)))
+@pytest.mark.parametrize("buf", [65536, 4096, 17])
+def test_container_is_the_oracles_for_every_option_set_and_buffer(lib, which, buf, corpus):
+    ffi_opts, orc_opts = fh.OPTION_SETS[which]
+    data = corpus[:152089] if which == 0 and buf == 65536 else corpus[5000:5000 + 70001]
+    coded = fh.ffi_compress(lib, data, ffi_opts, buf_size=buf)
+    ref = po.stream_compress_raw(data, po.stream_options(call_buffer_size=buf, **orc_opts))
+    assert coded.size == ref.size and (coded == ref).all()
+    assert (fh.ffi_decompress(lib, coded, data.size, buf_size=buf, feed=max(buf // 3, 1)) == data).all()
+
+
+def test_call_patterns_past_the_window(lib, corpus):
+    """the ring laps inside the encode calls (raw_to_cmd/mod.rs:55-104): whole-input, 4 KiB and odd pieces at window 16 and 10"""
+    import workload
+    data = workload.make_blocks(corpus, 7, 24).reshape(-1)                 # 1.5 MiB
+    for feed in (None, 4096, 70001):
+        coded = fh.ffi_compress(lib, data, [(5, 0), (2, 16)], buf_size=4096, feed=feed)
+        calls = [data.size] if feed is None else [feed] * (data.size // feed) + ([data.size % feed] if data.size % feed else [])
+        ref = po.stream_compress_raw(data, po.stream_options(window_size=16, call_buffer_size=4096), call_inputs=calls)
+        assert coded.size == ref.size and (coded == ref).all(), feed
+    assert (fh.ffi_decompress(lib, coded, data.size, buf_size=4096, feed=4096) == data).all()
+    for n in (0, 1, 1023, 1024, 1025, 2047, 2048, 3070, 3071, 3072, 5000):
+        d = corpus[:n]
+        coded = fh.ffi_compress(lib, d, [(5, 0), (2, 10)], buf_size=777)
+        assert (coded == po.stream_compress_raw(d, po.stream_options(window_size=10, call_buffer_size=777), call_inputs=[n] if n else None)).all(), n
+        assert (fh.ffi_decompress(lib, coded, n, buf_size=100, feed=13) == d).all()
+
+
+def test_decoder_hands_out_bytes_while_the_input_arrives(lib, corpus):
+    """the decoder is incremental: fed 4 KiB at a time, output appears long before the last input byte (a literal-only stream's CMD
+    bytes only come with the flush, so nothing can appear before the container's tail has been seen -- but no later than that)"""
+    import workload
+    data = workload.make_blocks(corpus, 3, 16).reshape(-1)                 # 1 MiB, window 16: 16 laps
+    coded = fh.ffi_compress(lib, data, [(5, 0), (2, 16)])
+    st = lib.divans_new_decompressor()
+    buf = np.empty(65536, np.uint8); out = bytearray(); off = 0
+    calls_after_last_input = 0
+    while True:
+        ro = ctypes.c_size_t(0); wo = ctypes.c_size_t(0)
+        n = min(4096, coded.size - off)
+        r = lib.divans_decode(st, coded.ctypes.data + off, n, ctypes.byref(ro), buf.ctypes.data, buf.size, ctypes.byref(wo))
+        assert r != 3
+        off += ro.value; out += buf[:wo.value].tobytes()
+        if off == coded.size:
+            calls_after_last_input += 1
+        if r == 0:
+            break
+    lib.divans_free_decompressor(st)
+    assert bytes(out) == data.tobytes()
+    assert calls_after_last_input <= data.size // buf.size + 2           # what is left once the input is in: one buffer per call
+
+
+def test_damaged_containers_are_refused(lib, corpus):
+    data = corpus[:40000]
+    coded = fh.ffi_compress(lib, data, [(5, 0)]).copy()
+
+    def decode_result(buf, skip_crc):
+        lib.divans_new_decompressor_with_custom_alloc.restype = ctypes.c_void_p
+        lib.divans_new_decompressor_with_custom_alloc.argtypes = [fh.CAllocator, ctypes.c_uint8, ctypes.c_uint8]
+        st = lib.divans_new_decompressor_with_custom_alloc(fh.CAllocator(None, None, None), skip_crc, 0)
+        out = np.empty(1 << 20, np.uint8); ro = ctypes.c_size_t(0); wo = ctypes.c_size_t(0)
+        r = lib.divans_decode(st, buf.ctypes.data, buf.size, ctypes.byref(ro), out.ctypes.data, out.size, ctypes.byref(wo))
+        lib.divans_free_decompressor(st)
+        return r, out[:wo.value]
+
+    r, out = decode_result(coded, 0)
+    assert r == 0 and (out == data).all()
+    bad = coded.copy(); bad[coded.size // 2] ^= 0x40
+    assert decode_result(bad, 0)[0] == 3 and decode_result(bad, 1)[0] == 3
+    assert decode_result(coded[:coded.size - 500].copy(), 0)[0] in (1, 3)
+    for magic_byte in range(4):                                             # header magic, divans_compressor.rs:126-131
+        bad = coded.copy(); bad[magic_byte] ^= 1
+        assert decode_result(bad, 0)[0] == 3
+
+
+@pytest.mark.parametrize("opts,n,iters", [(["5=0"], 3000, 1500), (["5=0", "4=2", "2=10"], 9000, 1500), (["5=0", "7=0", "9=1", "4=0"], 70001, 150)])
+def test_fuzzed_containers_under_sanitizers(fuzzer, opts, n, iters, tmp_path, corpus):
+    """tests/c/hostsim_fuzz.cpp: random piece / buffer sizes both ways, then damaged containers through divans_decode -- no sanitizer
+    report, no spinning, no success with wrong bytes while the CRC is checked"""
+    src = tmp_path / "in.bin"
+    corpus[1234:1234 + n].tofile(src)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([fuzzer, str(src), str(n), str(iters)] + opts, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "damaged" in r.stdout
