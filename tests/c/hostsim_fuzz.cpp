@@ -1,6 +1,7 @@
 // TEST HARNESS (see hostsim_device_stub.cpp): the per-stream C ABI's host logic under AddressSanitizer / UBSan.
 //
 //   hostsim_fuzz <file> <seed> <iterations> [selector=value ...]
+//   hostsim_fuzz ir <file.ir> <seed> <iterations>
 //
 // 1. compresses <file> through divans_encode / divans_encode_flush with seeded random input pieces and output buffer sizes (1 byte ..
 //    64 KiB), decompresses it the same way and compares;
@@ -9,6 +10,10 @@
 //    DIVANS_FAILURE, may ask for input that does not exist, or -- when the damage was harmless -- succeed; what it may not do is touch
 //    memory it does not own (the sanitizers abort), spin without progress, hand out more than max_output, or report success with wrong
 //    bytes while the CRC is checked.
+// 3. every damaged container also goes through divans_host::parse_container_host, the whole-container parser of the batch interface
+//    (divans_amd/csrc/batch.cpp), which must agree with the streaming decoder on what is acceptable.
+// `ir` mode: the textual command IR (include/divans_ir.h) -- the file must parse and expand; damaged copies (bytes flipped, tokens
+// deleted / duplicated, numbers replaced by huge ones) may be refused or accepted, within bounds.
 // exit 0 = all held; prints one summary line.
 #include <cstdint>
 #include <cstdio>
@@ -18,6 +23,8 @@
 #include <vector>
 
 #include "../../include/divans_ffi.h"
+#include "../../include/divans_ir.h"
+#include "../../divans_amd/csrc/host_stream.h"
 
 static uint64_t rng_state;
 static uint64_t rnd() {                       // xorshift64*
@@ -74,6 +81,7 @@ enum Outcome { OK = 0, FAILED = 1, WANTS_INPUT = 2, STUCK = 3, OVERRUN = 4 };
 static Outcome decompress(const Bytes& coded, bool skip_crc, bool fixed_sizes, size_t limit, Bytes& out) {
     struct CAllocator none = {nullptr, nullptr, nullptr};
     DivansDecompressorState* st = divans_new_decompressor_with_custom_alloc(none, skip_crc ? 1 : 0, 0);
+    divans_decompressor_set_max_output_size(st, limit);       // a stream that claims more is refused, not followed
     Bytes buf(65536);
     size_t off = 0; int idle = 0; Outcome res = STUCK;
     for (;;) {
@@ -111,7 +119,63 @@ static void damage(Bytes& c, const Bytes& other) {
     }
 }
 
+static int fuzz_ir(const char* path, long iterations) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return 2;
+    std::string text; { char tmp[65536]; size_t n; while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) text.append(tmp, n); }
+    std::fclose(f);
+    const size_t cap = (size_t)64 << 20;
+    Bytes raw(cap), lit(cap); std::vector<divans_lit_segment> segs(1 << 20);
+    auto run = [&](const std::string& t, bool must) -> int {
+        divans_ir* ir = nullptr;
+        const int rc = divans_ir_parse(t.data(), t.size(), &ir);
+        if (rc) { if (ir) return 10; return must ? 11 : 0; }
+        if (!ir) return 12;
+        const size_t n = divans_ir_raw_size(ir);
+        const int e = divans_ir_expand(ir, raw.data(), cap);
+        if ((n <= cap) != (e == 0) && must) { divans_ir_free(ir); return 13; }
+        const size_t nl = divans_ir_literal_size(ir), ns = divans_ir_num_segments(ir);
+        const int l = divans_ir_literal_segments(ir, lit.data(), cap, segs.data(), segs.size());
+        if (must && (l != 0 || nl > n || ns > divans_ir_num_commands(ir))) { divans_ir_free(ir); return 14; }
+        divans_ir_options o; divans_ir_options_default(&o);
+        divans_lit_config cfg;
+        (void)divans_ir_lit_config(ir, &o, &cfg);
+        (void)divans_ir_num_block_types(ir); (void)divans_ir_count(ir, DIVANS_IR_COPY);
+        divans_ir_free(ir);
+        return 1;
+    };
+    int r = run(text, true);
+    if (r != 1) { std::fprintf(stderr, "the IR file itself: %d (%s)\n", r, divans_gpu_last_error()); return 3; }
+    long accepted = 0;
+    for (long it = 0; it < iterations; ++it) {
+        std::string t = text;
+        if (rnd() % 4 == 0 && t.size() > 4096) { const size_t from = rnd_below(t.size() - 4096); t = t.substr(from, 4096 + rnd_below(60000)); }   // a window of it: most damage then lands near live commands
+        const int kinds = 1 + (int)(rnd() % 4);
+        for (int k = 0; k < kinds && !t.empty(); ++k) {
+            const size_t at = rnd_below(t.size());
+            switch (rnd() % 7) {
+                case 0: t[at] = (char)rnd(); break;
+                case 1: t.erase(at, 1 + rnd_below(40)); break;
+                case 2: t.insert(at, t.substr(rnd_below(t.size()), 1 + rnd_below(80))); break;
+                case 3: t.insert(at, " 99999999999999999999 "); break;
+                case 4: t.insert(at, " 4294967295 "); break;
+                case 5: t.insert(at, (rnd() & 1) ? "\n" : " "); break;
+                default: t.resize(at); break;
+            }
+        }
+        r = run(t, false);
+        if (r != 0 && r != 1) { std::fprintf(stderr, "iteration %ld: %d\n", it, r); return 6; }
+        accepted += r;
+    }
+    std::printf("IR of %zu characters; %ld damaged: %ld still parse\n", text.size(), iterations, accepted);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 5 && std::strcmp(argv[1], "ir") == 0) {
+        rng_state = std::strtoull(argv[3], nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
+        return fuzz_ir(argv[2], std::strtol(argv[4], nullptr, 0));
+    }
     if (argc < 4) { std::fprintf(stderr, "usage: hostsim_fuzz <file> <seed> <iterations> [selector=value ...]\n"); return 2; }
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;
@@ -144,6 +208,15 @@ int main(int argc, char** argv) {
         if (o == STUCK || o == OVERRUN) { std::fprintf(stderr, "iteration %ld: decoder %s\n", it, o == STUCK ? "makes no progress" : "overran a bound"); return 6; }
         if (o == OK && !skip_crc && back != data) { std::fprintf(stderr, "iteration %ld: success with wrong bytes under the CRC\n", it); return 7; }
         n_ok += o == OK; n_failed += o == FAILED; n_wants += o == WANTS_INPUT;
+        // the whole-container parser of the batch interface on the same bytes
+        divans_host::ParsedStream ps; size_t used = 0;
+        const divans_host::ParseStatus st = divans_host::parse_container_host(c.data(), c.size(), skip_crc, data.size() + (1u << 20), ps, &used);
+        if (st == divans_host::PARSE_OK && (used > c.size() || ps.total > data.size() + (1u << 20))) { std::fprintf(stderr, "iteration %ld: parser out of bounds\n", it); return 8; }
+        if (st == divans_host::PARSE_OK && o != OK) {
+            // framing, CMD stream and CRC held, so only the literal decoder can have refused it (its final-state check) -- impossible while the CRC is checked
+            if (!skip_crc) { std::fprintf(stderr, "iteration %ld: the parser accepts what the decoder (%d) refused under the CRC\n", it, (int)o); return 9; }
+        }
+        if (o == OK && st != divans_host::PARSE_OK) { std::fprintf(stderr, "iteration %ld: the decoder accepts what the parser (%d) refused\n", it, (int)st); return 9; }
     }
     std::printf("containers %zu / %zu bytes for %zu; %ld damaged: %ld refused, %ld starved, %ld decoded\n", plain.size(), ragged.size(), data.size(), iterations, n_failed, n_wants, n_ok);
     return 0;

@@ -8,7 +8,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "c", "_build")
 
-CXX_SOURCES = ["divans_amd/csrc/host_stream.cpp", "divans_amd/csrc/ffi.cpp", "tests/c/hostsim_device_stub.cpp"]
+CXX_SOURCES = ["divans_amd/csrc/host_stream.cpp", "divans_amd/csrc/ffi.cpp", "divans_amd/csrc/ir.cpp", "tests/c/hostsim_device_stub.cpp"]
 C_SOURCES = ["oracle/cdf.c", "oracle/ans.c", "oracle/literal.c", "oracle/crc32c.c", "oracle/stream.c"]
 
 
@@ -17,7 +17,7 @@ def _newer(target, sources):
         return True
     t = os.path.getmtime(target)
     deps = list(sources) + [os.path.join(ROOT, "divans_amd", "csrc", "host_stream.h"), os.path.join(ROOT, "oracle", "divans_oracle.h"),
-                            os.path.join(ROOT, "include", "divans_gpu.h"), os.path.join(ROOT, "include", "divans_ffi.h"), os.path.abspath(__file__)]
+                            os.path.join(ROOT, "include", "divans_gpu.h"), os.path.join(ROOT, "include", "divans_ffi.h"), os.path.join(ROOT, "include", "divans_ir.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -101,6 +101,14 @@ def test_damaged_containers_are_refused(lib, corpus):
     for magic_byte in range(4):                                             # header magic, divans_compressor.rs:126-131
         bad = coded.copy(); bad[magic_byte] ^= 1
         assert decode_result(bad, 0)[0] == 3
+    # a stream that decodes to more than the caller's bound is refused, not followed (divans_decompressor_set_max_output_size)
+    lib.divans_decompressor_set_max_output_size.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    for bound, expect in ((data.size, 0), (data.size - 1, 3)):
+        st = lib.divans_new_decompressor()
+        lib.divans_decompressor_set_max_output_size(st, bound)
+        out = np.empty(1 << 20, np.uint8); ro = ctypes.c_size_t(0); wo = ctypes.c_size_t(0)
+        assert lib.divans_decode(st, coded.ctypes.data, coded.size, ctypes.byref(ro), out.ctypes.data, out.size, ctypes.byref(wo)) == expect
+        lib.divans_free_decompressor(st)
 
 
 @pytest.mark.parametrize("opts,n,iters", [(["5=0"], 3000, 1500), (["5=0", "4=2", "2=10"], 9000, 1500), (["5=0", "7=0", "9=1", "4=0"], 70001, 150)])
@@ -113,3 +121,16 @@ def test_fuzzed_containers_under_sanitizers(fuzzer, opts, n, iters, tmp_path, co
     r = subprocess.run([fuzzer, str(src), str(n), str(iters)] + opts, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     assert "damaged" in r.stdout
+
+
+@pytest.mark.parametrize("name,iters", [("alice29", 150), ("alice29-priors", 150), ("ends_with_truncated_dictionary", 1500)])
+def test_fuzzed_ir_text_under_sanitizers(fuzzer, name, iters, tmp_path):
+    """the textual command IR (divans_amd/csrc/ir.cpp, grammar of the reference's bin/divans.rs:191-483) with damaged text: refused or
+    accepted, within bounds, no sanitizer report"""
+    import lzma
+    src = tmp_path / (name + ".ir")
+    with lzma.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ir_" + name + ".ir.xz")) as f:
+        src.write_bytes(f.read())
+    r = subprocess.run([fuzzer, "ir", str(src), "7", str(iters)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "still parse" in r.stdout
