@@ -76,5 +76,6 @@ int main(int argc, char **argv) {
         divans_free_decompressor(ds);
     }
     printf("File length %zu reduced to %zu\n", len, coded_len);
+    free(back); free(coded); free(data);
     return 0;
 }

@@ -52,3 +52,17 @@ def build_fuzzer():
     if _newer(exe, objs + [driver]):
         subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
     return exe
+
+
+def build_program(name, source, lang="c++", sanitize_main=True):
+    """tests/c/_build/<name>: `source` (a caller of the per-stream C ABI) linked with the sanitized harness objects;
+    sanitize_main=False leaves the caller itself uninstrumented (the reference's c/example.c trips UBSan in its own vec_u8.h)."""
+    exe = os.path.join(OUT, name)
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    objs = _objects("san", san + ["-msse4.2"])
+    if _newer(exe, objs + [source]):
+        obj = os.path.join(OUT, name + ".main.o")
+        cc = ["g++", "-std=c++14"] if lang == "c++" else ["gcc", "-Wno-unused-result"]
+        subprocess.run(cc + (san if sanitize_main else ["-O1", "-g"]) + ["-c", source, "-o", obj, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(source)], check=True)
+        subprocess.run(["g++"] + san + ["-o", exe, obj] + objs + ["-lpthread"], check=True)
+    return exe

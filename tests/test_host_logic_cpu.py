@@ -134,3 +134,48 @@ def test_fuzzed_ir_text_under_sanitizers(fuzzer, name, iters, tmp_path):
     r = subprocess.run([fuzzer, "ir", str(src), "7", str(iters)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     assert "still parse" in r.stdout
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN_ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+
+
+def test_c_harness_and_cpp_adaptors_under_sanitizers(tmp_path, corpus):
+    """tests/c/ffi_roundtrip.c (c/example.c's calling pattern with a counting allocator) and tests/c/io_adaptors.cpp
+    (include/divans_io.hpp: the reference's writer.rs / reader.rs adaptors), the programs the GPU tier links against the product
+    library, here against the harness objects: same exit codes, container == the oracle's, nothing for ASan / UBSan / LSan to report"""
+    src = tmp_path / "in.bin"
+    data = corpus[:200000]
+    data.tofile(src)
+    exe = hostsim.build_program("ffi_roundtrip", os.path.join(ROOT, "tests", "c", "ffi_roundtrip.c"), lang="c")
+    dv = tmp_path / "a.divans"
+    r = subprocess.run([exe, str(src), str(dv), "5=0", "4=2", "9=0"], capture_output=True, text=True, env=SAN_ENV, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-3000:])
+    assert (po.stream_decompress(np.fromfile(dv, dtype=np.uint8), data.size) == data).all()
+    exe = hostsim.build_program("io_adaptors", os.path.join(ROOT, "tests", "c", "io_adaptors.cpp"))
+    dv = tmp_path / "b.divans"
+    r = subprocess.run([exe, str(src), str(dv)], capture_output=True, text=True, env=SAN_ENV, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-3000:])
+    coded = np.fromfile(dv, dtype=np.uint8)
+    calls = [65536] * (data.size // 65536) + [data.size % 65536]
+    ref = po.stream_compress_raw(data, po.stream_options(window_size=16, dynamic_context_mixing=2, use_context_map=1, call_buffer_size=4096),
+                                 call_inputs=calls)
+    assert coded.size == ref.size and (coded == ref).all()
+
+
+REF_C = "/root/reference/c"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_C, "example.c")), reason="the reference tree is not mounted here")
+@pytest.mark.parametrize("args,env", [([], {}), (["-l"], {}), (["-l", "-cm", "-m2", "-s1"], {}), (["-l", "-w12"], {"NO_MALLOC": "1"}), ([], {"RUST_MALLOC": "1"})])
+def test_reference_example_c_on_the_host_logic(args, env, tmp_path, corpus):
+    """the reference's own C harness (c/example.c, compiled verbatim from where it lies) over the harness objects: compress ->
+    decompress -> memcmp with its three allocators, under the sanitizers.  The GPU tier runs the same program against the product."""
+    exe = hostsim.build_program("ref_example", os.path.join(REF_C, "example.c"), lang="c", sanitize_main=False)
+    e = dict(SAN_ENV, ASAN_OPTIONS="detect_leaks=0"); e.update(env)       # the harness does not free its own buffers
+    r = subprocess.run([exe] + args, capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0 and "reduced to" in r.stdout, (r.returncode, r.stdout, r.stderr[-3000:])
+    src = tmp_path / "in.bin"
+    corpus[:100000].tofile(src)
+    r = subprocess.run([exe] + args + [str(src)], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0 and "File length 100000 reduced to" in r.stdout, (r.returncode, r.stdout, r.stderr[-3000:])
