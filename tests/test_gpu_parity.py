@@ -648,3 +648,75 @@ def test_both_decoder_generations_agree(cfg_name, corpus):
         with pytest.raises(da.DivansGpuError):
             codec.decode_host(bad, offs, sizes, 3000)
     codec.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_decoder_survives_thousands_of_damaged_streams(cfg_name, corpus):
+    """The coded bytes are untrusted input to the decode kernels.  2048 streams in one launch, three in four damaged in a seeded way
+    (bit flips, overwritten runs, random bytes, sizes cut to 0 / 4 / 12 / 16 / odd lengths, a neighbour's stream, sizes grown into the
+    neighbour's slot), every fourth left intact: each generation of the decoder must return, flag EXACTLY the streams whose bytes no
+    longer decode to a valid stream -- an intact stream next to a damaged one decodes exactly -- and never flag an intact one.  (A
+    damaged stream that still passes the integrity rule would be caught by the container's CRC; here it only has to be harmless.)"""
+    import ctypes
+    import torch
+    n, L = 2048, 2500
+    blocks = workload.make_blocks(corpus, 11, n, block_len=L)
+    da, codec = _codec(cfg_name, L)
+    d_in = torch.from_numpy(blocks).cuda()
+    outs = codec.alloc_encode_outputs(n, L)
+    codec.encode_batch(d_in, n, L, outs)
+    assert codec.status() == 0
+    coded = outs["out"].cpu().numpy().copy()
+    offs = outs["offsets"].cpu().numpy().copy(); sizes = outs["sizes"].cpu().numpy().copy()
+    rng = np.random.default_rng(5)
+    changed = np.zeros(n, bool); kinds = np.full(n, -1)
+    for i in range(n):
+        if i % 4 == 0:
+            continue
+        o, sz = int(offs[i]), int(sizes[i])
+        kind = int(rng.integers(0, 8)); kinds[i] = kind
+        before = coded[o:o + sz].copy(); before_sz = sz
+        if kind == 0:
+            coded[o + int(rng.integers(0, sz))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        elif kind == 1:
+            a = int(rng.integers(0, sz)); m = min(sz - a, int(rng.integers(1, 64)))
+            coded[o + a:o + a + m] = rng.integers(0, 256, m, dtype=np.uint8)
+        elif kind == 2:
+            coded[o:o + sz] = rng.integers(0, 256, sz, dtype=np.uint8)
+        elif kind == 3:
+            sizes[i] = [0, 4, 12, 16, 20, sz - 4, sz - 3, sz // 2][int(rng.integers(0, 8))]
+        elif kind == 4:
+            j = (i + 1) % n
+            m = min(sz, int(sizes[j])); coded[o:o + m] = coded[int(offs[j]):int(offs[j]) + m]
+        elif kind == 5:
+            sizes[i] = min(sz + 4 * int(rng.integers(1, 40)), coded.size - o)   # reads on into the next stream's slot
+        elif kind == 6:
+            coded[o:o + 16] = 0xff                                           # both rANS states at their maximum
+        else:
+            coded[o:o + 16] = 0                                              # and at zero
+        changed[i] = int(sizes[i]) != before_sz or not np.array_equal(coded[o:o + before_sz], before)
+    d_coded = torch.from_numpy(coded).cuda(); d_offs = torch.from_numpy(offs).cuda(); d_sizes = torch.from_numpy(sizes).cuda()
+    flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert codec._lib.divans_gpu_codec_set_stream_flags(codec._h, ctypes.c_void_p(flags.data_ptr())) == 0
+    results = []
+    for gen in (1, 2, 3):
+        codec.set_decoder(gen)
+        flags.zero_()
+        d_back = torch.full((n, L), 0xEE, dtype=torch.uint8, device="cuda")
+        codec.decode_batch(d_coded, d_offs, d_sizes, n, L, d_back)
+        st = codec.status()
+        f = flags.cpu().numpy().astype(bool); back = d_back.cpu().numpy()
+        good = (back == blocks).all(axis=1)
+        assert not f[~changed].any(), gen                      # nothing intact is flagged ...
+        assert good[~changed].all(), gen                       # ... and everything intact decodes exactly, whatever its neighbours hold
+        assert (st & 2) == 2 and f[changed].mean() > 0.9, (gen, f[changed].mean())
+        # a damaged stream either is flagged or decoded to valid bytes after all
+        # (kind 4 with a neighbour of the same coded size IS a valid stream: the neighbour's)
+        good = good | ((kinds == 4) & (back == np.roll(blocks, -1, axis=0)).all(axis=1))
+        bad = np.flatnonzero(~(f | good) & changed)
+        assert bad.size == 0, (gen, bad[:10], kinds[bad[:10]], sizes[bad[:10]], outs['sizes'].cpu().numpy()[bad[:10]])
+        results.append((f.copy(), back.copy()))
+    for f, back in results[1:]:
+        assert (f == results[0][0]).all()                          # the generations agree on what is acceptable
+    assert codec._lib.divans_gpu_codec_set_stream_flags(codec._h, None) == 0
+    codec.close()
