@@ -78,3 +78,54 @@ def test_batch_decompress_names_the_damaged_stream(corpus):
     with pytest.raises(da.DivansGpuError) as ei:
         da.batch_decompress(bad, sum(x.size for x in inputs), da.batch_options(skip_crc=1))
     assert "23" in str(ei.value)
+
+
+def test_batch_decompress_with_damaged_containers_in_bulk(corpus):
+    """containers are untrusted input: 240 batches of 6 containers with one or two of them damaged (bit flips, overwritten / deleted /
+    inserted spans, truncation, a splice with another container), with and without the CRC check.  Every call either refuses the
+    batch -- naming a container that really was damaged -- or, when the damage was harmless, returns exactly the original bytes."""
+    import re
+    import divans_amd as da
+    rng = np.random.default_rng(23)
+    inputs = [corpus[k * 7000:k * 7000 + 3000 + 211 * k] for k in range(6)]
+    total = sum(x.size for x in inputs)
+    sets = [da.batch_compress(inputs, da.batch_options())[0],
+            da.batch_compress(inputs, da.batch_options(dynamic_context_mixing=2, force_stride=0))[0]]
+    refused = accepted = 0
+    for it in range(240):
+        cs = [c.copy() for c in sets[it & 1]]
+        victims = sorted(set(int(v) for v in rng.integers(0, 6, size=1 + (it % 3 == 0))))
+        for v in victims:
+            c = cs[v]
+            at = int(rng.integers(0, min(c.size, 64))) if rng.integers(0, 4) == 0 else int(rng.integers(0, c.size))
+            kind = int(rng.integers(0, 6))
+            if kind == 0:
+                c[at] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            elif kind == 1:
+                m = min(c.size - at, int(rng.integers(1, 32))); c[at:at + m] = rng.integers(0, 256, m, dtype=np.uint8)
+            elif kind == 2:
+                c = c[:at].copy()
+            elif kind == 3:
+                m = min(c.size - at, int(rng.integers(1, 300))); c = np.concatenate([c[:at], c[at + m:]])
+            elif kind == 4:
+                c = np.concatenate([c[:at], rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8), c[at:]])
+            else:
+                other = sets[it & 1][(v + 1) % 6]
+                c = np.concatenate([c[:at], other[int(rng.integers(0, other.size)):]])
+            cs[v] = np.ascontiguousarray(c) if c.size else np.zeros(1, np.uint8)[:0]
+        try:
+            back, _ = da.batch_decompress(cs, total + (1 << 16), da.batch_options(skip_crc=int(rng.integers(0, 2))))
+        except da.DivansGpuError as e:
+            refused += 1
+            m = re.search(r"container (\d+)", str(e))
+            if m:
+                assert int(m.group(1)) in victims, (it, str(e), victims)
+            continue
+        accepted += 1
+        for i, x in enumerate(inputs):
+            if i not in victims:
+                assert back[i].size == x.size and (back[i] == x).all(), (it, i)
+    assert refused > 200 and refused + accepted == 240
+    # and the library is still in working order
+    back, _ = da.batch_decompress(sets[0], total, da.batch_options())
+    assert all((back[i] == inputs[i]).all() for i in range(6))
