@@ -403,8 +403,8 @@ static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b
 static int ensure_bucket_mix(divans_gpu_codec* c, uint32_t n_streams, MixBucketBatch& b) {
     const size_t pl = bucket_slot(c);
     const size_t n = n_streams;
-    const size_t sz_rec = n * pl * 8u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 6u * 4u, sz_inv = n * pl * 2u, sz_sorted = n * pl * 2u;
-    const size_t need = 256u + 4u * sz_rec + sz_desc + sz_tasks + sz_inv + sz_sorted;
+    const size_t sz_xs = n * pl * 8u, sz_max = n * pl * 4u, sz_desc = n * 256u * 8u * 4u, sz_tasks = n * 256u * 6u * 4u, sz_inv = n * pl * 2u, sz_sorted = n * pl * 2u;
+    const size_t need = 256u + 2u * (sz_xs + sz_max) + sz_desc + sz_tasks + sz_inv + sz_sorted;
     if (need > c->bk_bytes) {
         if (c->d_bk) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_bk)); c->d_bk = nullptr; c->bk_bytes = 0; }
         if (hipMalloc(&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed two-model encoder work arrays) failed");
@@ -412,7 +412,8 @@ static int ensure_bucket_mix(divans_gpu_codec* c, uint32_t n_streams, MixBucketB
     }
     uint8_t* p = c->d_bk;
     b.counters = (uint32_t*)p; p += 256;
-    for (int i = 0; i < 4; ++i) { b.pos[i] = (bk_u32x2*)p; p += sz_rec; }
+    for (int i = 0; i < 2; ++i) { b.xs[i] = (bk_u32x2*)p; p += sz_xs; }      // 12 bytes per position and model: the entries, then the row totals
+    for (int i = 0; i < 2; ++i) { b.maxes[i] = (uint32_t*)p; p += sz_max; }
     b.desc = (uint32_t*)p; p += sz_desc;
     b.tasks = (uint32_t*)p; p += sz_tasks;
     b.inv = (uint16_t*)p; p += sz_inv;       // inv and sorted stay adjacent: together they are the rANS pass's scratch (SfView::spare)
@@ -610,7 +611,7 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
         if (rc) return rc;
         k.blob = c->d_blob; k.stream_len = stream_len; k.max_stream_len = c->max_stream_len; k.pieces = bucket_pieces(c);
         k.slot = bucket_slot(c); k.pos_stride = k.slot;
-        k.sf = (uint32_t*)k.pos[0]; k.sf_stride = 2u * k.slot;  // mix_weights_kernel writes the pairs over the stride model's high records
+        k.sf = (uint32_t*)k.xs[0]; k.sf_stride = 2u * k.slot;  // mix_weights_kernel writes the pairs over the stride model's entries
         k.inc0 = c->geom.inc0; k.lim0 = c->geom.lim0; k.inc2 = c->geom.inc2; k.lim2 = c->geom.lim2; k.inc3 = c->geom.inc3; k.lim3 = c->geom.lim3;
         view.sf = k.sf; view.stride = k.sf_stride;
         view.spare = (uint8_t*)k.inv;

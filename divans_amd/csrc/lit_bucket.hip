@@ -310,6 +310,28 @@ __global__ __launch_bounds__(1024) void bucket_unsort_kernel(const BucketBatch b
     for (uint32_t i = threadIdx.x; i < n; i += 1024u) dst[i] = buf[inv[i]];
 }
 
+// the same for a plane of 4-byte elements (the two-model pass's maxes): sfs / sf are read as uint32_t arrays, `slot` / sf_stride apart
+__global__ __launch_bounds__(1024) void bucket_unsort32_kernel(const BucketBatch b) {
+    __shared__ uint32_t buf[BK_PIECE];
+    const uint32_t s = blockIdx.x / b.pieces, piece = blockIdx.x % b.pieces;
+    const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
+    const uint32_t base = piece * BK_PIECE;
+    if (base >= len) return;
+    const uint32_t n = len - base < BK_PIECE ? len - base : BK_PIECE;
+    const size_t pl = b.slot;
+    const uint32_t* src = (const uint32_t*)b.sfs + (size_t)s * pl + base;
+    const uint32_t n2 = (n + 1u) & ~1u;                    // pieces start on even elements and the slot is even: whole pairs
+    for (uint32_t i = 2u * threadIdx.x; i < n2; i += 2048u) *(u32x2*)(buf + i) = __builtin_nontemporal_load((const u32x2*)(src + i));
+    __syncthreads();
+    const uint16_t* inv = b.inv + (size_t)s * pl + base;
+    uint32_t* dst = b.sf + (size_t)s * b.sf_stride + base;
+    for (uint32_t i = 2u * threadIdx.x; i < n2; i += 2048u) {
+        const uint32_t iv = *(const uint32_t*)(inv + i);
+        const u32x2 v = {buf[iv & 0xffffu], i + 1u < n ? buf[iv >> 16] : 0u};
+        *(u32x2*)(dst + i) = v;
+    }
+}
+
 uint32_t bucket_chain_lds_bytes() { return (64u * BK_LANE_DWORDS + 128u) * 4u; }
 
 // steps 2 and 4 on their own, for the two-model pass (lit_bucket_mix.hip) that brings its own sort and chain kernels
@@ -318,6 +340,10 @@ void launch_bucket_tasks(const BucketBatch& b, hipStream_t st) {
 }
 void launch_bucket_unsort(const BucketBatch& b, hipStream_t st) {
     hipLaunchKernelGGL(bucket_unsort_kernel, dim3(b.n_streams * b.pieces), dim3(1024), 0, st, b);
+}
+
+void launch_bucket_unsort32(const BucketBatch& b, hipStream_t st) {
+    hipLaunchKernelGGL(bucket_unsort32_kernel, dim3(b.n_streams * b.pieces), dim3(1024), 0, st, b);
 }
 
 hipError_t launch_bucket_model(const BucketBatch& b, uint32_t chain_blocks, hipStream_t st) {

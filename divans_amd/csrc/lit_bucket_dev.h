@@ -74,6 +74,9 @@ __device__ __forceinline__ void bk_store_quad(u32x4* p, u32x4 v) {     // 8-byte
 __device__ __forceinline__ void bk_store_pair(u32x2* p, u32x2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void bk_store_word(uint32_t* p, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
 
 }  // namespace divans_hip
 #endif

@@ -9,7 +9,8 @@
 // can be walked bucket by bucket exactly as in lit_bucket.hip, once per model:
 //   stride model:  buckets keyed by prev  (up to 8 high rows, one per class of prev_prev that reaches a different ctx, + 16 low rows)
 //   context model: buckets keyed by ctx   (1 high row + 16 low rows)
-// Instead of (start, freq) a chain lane leaves the three raw counts mixing needs: {cdf[sym] | cdf[sym-1] << 16, cdf[15]}.
+// Instead of (start, freq) a chain lane leaves the three raw counts mixing needs per nibble -- cdf[sym], cdf[sym-1], cdf[15] --
+// as 12 bytes per position: {high: cdf[sym] | cdf[sym-1] << 16, low: the same} in one plane, the two cdf[15] in another.
 // After both models' records are back in position order, mix_weights_kernel runs the only serial part that is left --
 // the per-stream Weights recursion, one lane per (stream, nibble half): average (probability/frequentist_cdf.rs:58-72)
 // of the three entries, the six divisions of sym_to_start_and_freq (probability/interface.rs:97-108), Weights::update.
@@ -164,33 +165,34 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
     // eight sorted payloads per iteration requested an iteration ahead, the records of a group stored at the top of the next one.
     bool has_task = false, exhausted = false;
     uint32_t run_i = 0, nruns = 0, left = 0, idx = 0;
-    u32x2* const rec_h = b.pos[2 * MODEL]; u32x2* const rec_l = b.pos[2 * MODEL + 1];
-    u32x2* cur_h = rec_h; u32x2* cur_l = rec_l; const uint16_t* cur_sorted = b.sorted;
+    u32x2* const rec_x = b.xs[MODEL]; uint32_t* const rec_m = b.maxes[MODEL];
+    u32x2* cur_x = rec_x; uint32_t* cur_m = rec_m; const uint16_t* cur_sorted = b.sorted;
     uint32_t nt_stage = 0, nt_tid = 0;
     u32x4 nd0 = {0u, 0u, 0u, 0u}, nd1 = {0u, 0u, 0u, 0u};
     uint32_t win_cur = 0, win_end = 0, nxt_val = 0, nxt_w = 0;
     const uint32_t long_end = lists.ends[3];     // tasks of at least 2048 positions come first
     bool nxt_pending = false, drained = false;
     u32x4 e_next = {0u, 0u, 0u, 0u}; uint32_t m_next = 0;   // meta: base | first << 16 | cnt << 20 | BK_VALID
-    u32x2 h0 = {0u, 0u}, h1 = h0, h2 = h0, h3 = h0, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
-    u32x2 l0 = h0, l1 = h0, l2 = h0, l3 = h0, l4 = h0, l5 = h0, l6 = h0, l7 = h0;
-    uint32_t m_prev = 0; u32x2* h_prev = rec_h; u32x2* l_prev = rec_l;
+    u32x2 x0 = {0u, 0u}, x1 = x0, x2 = x0, x3 = x0, x4 = x0, x5 = x0, x6 = x0, x7 = x0;     // {high, low} entries of the group's positions
+    uint32_t t0 = 0u, t1 = 0u, t2 = 0u, t3 = 0u, t4 = 0u, t5 = 0u, t6 = 0u, t7 = 0u;       // their row totals, high | low << 16
+    uint32_t m_prev = 0; u32x2* x_prev = rec_x; uint32_t* t_prev = rec_m;
 
 #define MX_OPAQUE(X) asm volatile("" : "+v"(X))
-#define MX_POS(K, WORD, RH, RL)                                                                         \
+#define MX_POS(K, WORD, RX, RT)                                                                         \
     if (((K - first) & 15u) < cnt) {                                                                    \
         const uint32_t pay = (WORD >> (16u * (K & 1u))) & 0xffffu;                                      \
         const uint32_t hi = (pay >> 4) & 15u, lo = pay & 15u;                                           \
         uint32_t* rowh = MODEL == 0 ? my + ((pay >> 5) & 0x38u) : my;   /* 8 dwords x slot (bits 8..10) */ \
         uint32_t* rowl = my + 8u * (G::NH + hi);                                                        \
         BkRow H = bk_read(rowh, tabh, hi), L = bk_read(rowl, tabl, lo);                                 \
-        const u32x2 vh = {(uint32_t)H.chi | (hi ? (uint32_t)H.cprev << 16 : 0u), H.w1.w >> 16};         \
-        const u32x2 vl = {(uint32_t)L.chi | (lo ? (uint32_t)L.cprev << 16 : 0u), L.w1.w >> 16};         \
+        const u32x2 vx = {(uint32_t)H.chi | (hi ? (uint32_t)H.cprev << 16 : 0u),                        \
+                          (uint32_t)L.chi | (lo ? (uint32_t)L.cprev << 16 : 0u)};                       \
+        const uint32_t vt = (H.w1.w >> 16) | (L.w1.w & 0xffff0000u);                                    \
         H.w0 += H.a0; H.w1 += H.a1; L.w0 += L.a0; L.w1 += L.a1;   /* frequentist_cdf.rs:75-78 */        \
         if ((int)(H.w1.w >> 16) >= limh) bk_renorm(H);                                                  \
         if ((int)(L.w1.w >> 16) >= liml) bk_renorm(L);                                                  \
         *(u32x4*)rowh = H.w0; *(u32x4*)(rowh + 4) = H.w1; *(u32x4*)rowl = L.w0; *(u32x4*)(rowl + 4) = L.w1; \
-        RH = vh; RL = vl;                                                                               \
+        RX = vx; RT = vt;                                                                               \
     }
 #define MX_STORE8(DST, R0, R1, R2, R3, R4, R5, R6, R7)                                                  \
     {                                                                                                   \
@@ -211,13 +213,30 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
             if (((7u - pf) & 15u) < pc) bk_store_pair(dst + 7, R7);                                     \
         }                                                                                               \
     }
+#define MX_STORE8W(DST, R0, R1, R2, R3, R4, R5, R6, R7)                                                 \
+    {                                                                                                   \
+        uint32_t* dst = DST + (m_prev & 0xffffu);                                                       \
+        if (pc == 8u) {                                                                                 \
+            const u32x4 q0 = {R0, R1, R2, R3}, q1 = {R4, R5, R6, R7};                                   \
+            bk_store_quad((u32x4*)dst, q0); bk_store_quad((u32x4*)(dst + 4), q1);                       \
+        } else {                                                                                        \
+            if (((0u - pf) & 15u) < pc) bk_store_word(dst + 0, R0);                                     \
+            if (((1u - pf) & 15u) < pc) bk_store_word(dst + 1, R1);                                     \
+            if (((2u - pf) & 15u) < pc) bk_store_word(dst + 2, R2);                                     \
+            if (((3u - pf) & 15u) < pc) bk_store_word(dst + 3, R3);                                     \
+            if (((4u - pf) & 15u) < pc) bk_store_word(dst + 4, R4);                                     \
+            if (((5u - pf) & 15u) < pc) bk_store_word(dst + 5, R5);                                     \
+            if (((6u - pf) & 15u) < pc) bk_store_word(dst + 6, R6);                                     \
+            if (((7u - pf) & 15u) < pc) bk_store_word(dst + 7, R7);                                     \
+        }                                                                                               \
+    }
 
     for (;;) {
         u32x4 e = e_next; const uint32_t m = m_next;
         if (m_prev & BK_VALID) {                        // 1. the previous group's records leave
             const uint32_t pf = (m_prev >> 16) & 15u, pc = (m_prev >> 20) & 15u;
-            MX_STORE8(h_prev, h0, h1, h2, h3, h4, h5, h6, h7)
-            MX_STORE8(l_prev, l0, l1, l2, l3, l4, l5, l6, l7)
+            MX_STORE8(x_prev, x0, x1, x2, x3, x4, x5, x6, x7)
+            MX_STORE8W(t_prev, t0, t1, t2, t3, t4, t5, t6, t7)
         }
         {                                               // 2. the next group of the run is requested, the next run taken
             const bool adv = has_task && left == 0u, more = run_i < nruns;
@@ -235,11 +254,11 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
             idx += fetch_ ? cnt_ : 0u; left -= fetch_ ? cnt_ : 0u;
         }
         MX_OPAQUE(e);                                   // 3. this iteration's group
-        m_prev = m; h_prev = cur_h; l_prev = cur_l;
+        m_prev = m; x_prev = cur_x; t_prev = cur_m;
         if (m & BK_VALID) {
             const uint32_t first = (m >> 16) & 15u, cnt = (m >> 20) & 15u;
-            MX_POS(0u, e.x, h0, l0) MX_POS(1u, e.x, h1, l1) MX_POS(2u, e.y, h2, l2) MX_POS(3u, e.y, h3, l3)
-            MX_POS(4u, e.z, h4, l4) MX_POS(5u, e.z, h5, l5) MX_POS(6u, e.w, h6, l6) MX_POS(7u, e.w, h7, l7)
+            MX_POS(0u, e.x, x0, t0) MX_POS(1u, e.x, x1, t1) MX_POS(2u, e.y, x2, t2) MX_POS(3u, e.y, x3, t3)
+            MX_POS(4u, e.z, x4, t4) MX_POS(5u, e.z, x5, t5) MX_POS(6u, e.w, x6, t6) MX_POS(7u, e.w, x7, t7)
         }
         if (!has_task && !(m_next & BK_VALID) && nt_stage == 3u) {   // 4. a finished lane takes its prefetched task
             MX_OPAQUE(nd0); MX_OPAQUE(nd1);
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
             nruns = n; run_i = 0u;
             for (uint32_t r = 0; r < G::NR; ++r) { *(u32x4*)(my + 8u * r) = def0; *(u32x4*)(my + 8u * r + 4u) = def1; }
             const size_t slot = (size_t)(nt_tid >> 8) * pl;
-            cur_h = rec_h + slot; cur_l = rec_l + slot; cur_sorted = b.sorted + slot;
+            cur_x = rec_x + slot; cur_m = rec_m + slot; cur_sorted = b.sorted + slot;
             left = 0u; has_task = true; nt_stage = 0u;
         }
         const bool want = nt_stage == 0u && !exhausted;
@@ -293,6 +312,7 @@ __global__ __launch_bounds__(64) void mix_chain_kernel(const MixBucketBatch b) {
     }
 #undef MX_POS
 #undef MX_STORE8
+#undef MX_STORE8W
 #undef MX_OPAQUE
 }
 
@@ -317,19 +337,26 @@ __device__ __forceinline__ uint32_t mix_nibble(Weights& w, uint32_t st_x, uint32
 }
 
 // One wave = 32 streams x 2 halves.  The records of a stream are contiguous in memory, so the wave fetches them
-// together -- every 16-byte load instruction covers 128-byte runs of eight streams -- into LDS, 16 positions at a time,
-// double-buffered; each lane then reads its own stream's records from LDS, and the (start, freq) pairs go back out the
+// together -- every 16-byte load instruction covers 128-byte (xs) / 64-byte (maxes) runs of 8 / 16 streams -- into LDS, 16 positions
+// at a time, double-buffered; each lane then reads its own stream's records from LDS, and the (start, freq) pairs go back out the
 // same way (a lane-per-stream walk straight over global memory costs one 16-byte request per lane and load).
-constexpr uint32_t MW_CHUNK = 16;                       // positions per LDS buffer (8 or 4 -- more, smaller workgroups per CU -- cost 13 % / 25 % of the model pass)
-constexpr uint32_t MW_PIECES = MW_CHUNK / 2u;           // 16-byte pieces (two records) of a stream's chunk in one plane
-constexpr uint32_t MW_SPL = 64u / MW_PIECES;            // streams one load instruction of the wave covers
-constexpr uint32_t MW_GROUPS = 32u / MW_SPL;            // such loads per plane
-constexpr uint32_t MW_NLOAD = 4u * MW_GROUPS;
-constexpr uint32_t MW_IN_STRIDE = 4u * MW_CHUNK * 8u + 16u;   // bytes per stream: 4 planes x 16 records, padded against bank conflicts
+constexpr uint32_t MW_CHUNK = 16;                       // positions per LDS buffer (8 and 4 measured 13 % / 25 % worse on the model pass -- before the
+                                                        // one-wave-per-SIMD attribute below, so possibly for its reason; not re-measured)
+constexpr uint32_t MW_XP = MW_CHUNK / 2u, MW_TP = MW_CHUNK / 4u;     // 16-byte pieces of a stream's chunk: two xs records, four maxes
+constexpr uint32_t MW_XS = 64u / MW_XP, MW_TS = 64u / MW_TP;         // streams one load instruction of the wave covers
+constexpr uint32_t MW_XG = 32u / MW_XS, MW_TG = 32u / MW_TS;         // such loads per plane
+constexpr uint32_t MW_PER_MODEL = MW_XG + MW_TG;
+constexpr uint32_t MW_NLOAD = 2u * MW_PER_MODEL;
+constexpr uint32_t MW_MODEL_BYTES = MW_CHUNK * 12u;                  // a stream's chunk of one model in LDS: xs (8 B / position), then maxes (4 B)
+constexpr uint32_t MW_IN_STRIDE = 2u * MW_MODEL_BYTES + 16u;         // bytes per stream, padded against bank conflicts
 constexpr uint32_t MW_OUT_STRIDE = 2u * MW_CHUNK * 4u + 16u;
 constexpr uint32_t MW_IN_BYTES = 32u * MW_IN_STRIDE;
 
-__global__ __launch_bounds__(64) void mix_weights_kernel(const MixBucketBatch b) {
+// One wave per SIMD, enforced (amdgpu_waves_per_eu): a wave walks its 32 streams' recursions at the SIMD's issue rate and a second
+// wave on the same SIMD only halves both, while a 32 768-stream sequence is exactly one wave for each of the chip's 1024 SIMDs.  Left
+// to the dispatcher, a CU's four workgroups do not always land on four different SIMDs: round 2's version happened to be safe because
+// its 257 registers allowed one wave per SIMD anyway; with 169 the kernel took 39.6 instead of 24.5 ms until this attribute came.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void mix_weights_kernel(const MixBucketBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_in[2u * MW_IN_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t lds_out[32u * MW_OUT_STRIDE];
     const uint32_t lane = threadIdx.x;
@@ -337,49 +364,61 @@ __global__ __launch_bounds__(64) void mix_weights_kernel(const MixBucketBatch b)
     // consumer role: stream s0 + lane / 2, nibble half lane & 1
     const uint32_t cs = s0 + (lane >> 1), half = lane & 1u;
     const uint32_t len = cs < b.n_streams ? (b.in_sizes ? b.in_sizes[cs] : b.stream_len) : 0u;
-    // mover role: stream s0 + 8 i + lane / 8 of load i, records 2 (lane & 7), 2 (lane & 7) + 1 of the chunk
-    const uint32_t mq = lane % MW_PIECES, mj = lane / MW_PIECES;
+    // mover role, xs: stream s0 + 8 g + lane / 8 of load g, records 2 (lane & 7), + 1 of the chunk; maxes: stream s0 + 16 g + lane / 4,
+    // totals 4 (lane & 3) .. + 3; pairs out: as xs
+    const uint32_t xq = lane % MW_XP, xj = lane / MW_XP, tq = lane % MW_TP, tj = lane / MW_TP;
     const uint32_t chunks = (b.stream_len + MW_CHUNK - 1u) / MW_CHUNK;     // stream_len = the longest stream of the batch
     Weights w; w.w0 = 1; w.w1 = 1; w.norm = 1 << 14;               // weights.rs:15-21
     u32x4 r[MW_NLOAD];
 #define MW_FETCH(C)                                                                                     \
     _Pragma("unroll") for (uint32_t i = 0; i < MW_NLOAD; ++i) {                                         \
-        const uint32_t plane = i / MW_GROUPS, j = (i % MW_GROUPS) * MW_SPL + mj;                        \
-        const uint32_t p = (C) * MW_CHUNK + 2u * mq;                                                    \
-        const bool ok = s0 + j < b.n_streams && p < b.max_stream_len;                                   \
-        const u32x2* src = b.pos[plane] + (ok ? (size_t)(s0 + j) * b.pos_stride + p : 0u);          \
-        r[i] = __builtin_nontemporal_load((const u32x4*)src);                                           \
+        const uint32_t model = i / MW_PER_MODEL, g = i % MW_PER_MODEL;                                  \
+        if (g < MW_XG) {                                                                                \
+            const uint32_t j = g * MW_XS + xj, p = (C) * MW_CHUNK + 2u * xq;                            \
+            const bool ok = s0 + j < b.n_streams && p < b.max_stream_len;                               \
+            const u32x2* src = b.xs[model] + (ok ? (size_t)(s0 + j) * b.pos_stride + p : 0u);           \
+            r[i] = __builtin_nontemporal_load((const u32x4*)src);                                       \
+        } else {                                                                                        \
+            const uint32_t j = (g - MW_XG) * MW_TS + tj, p = (C) * MW_CHUNK + 4u * tq;                  \
+            const bool ok = s0 + j < b.n_streams && p < b.max_stream_len;                               \
+            const uint32_t* src = b.maxes[model] + (ok ? (size_t)(s0 + j) * b.pos_stride + p : 0u);     \
+            r[i] = __builtin_nontemporal_load((const u32x4*)src);                                       \
+        }                                                                                               \
     }
 #define MW_STAGE(BUF)                                                                                   \
     _Pragma("unroll") for (uint32_t i = 0; i < MW_NLOAD; ++i) {                                         \
-        const uint32_t plane = i / MW_GROUPS, j = (i % MW_GROUPS) * MW_SPL + mj;                        \
-        *(u32x4*)(lds_in + (BUF) * MW_IN_BYTES + j * MW_IN_STRIDE + plane * (MW_CHUNK * 8u) + mq * 16u) = r[i]; \
+        const uint32_t model = i / MW_PER_MODEL, g = i % MW_PER_MODEL;                                  \
+        uint8_t* dst = lds_in + (BUF) * MW_IN_BYTES + model * MW_MODEL_BYTES;                           \
+        if (g < MW_XG) *(u32x4*)(dst + (g * MW_XS + xj) * MW_IN_STRIDE + xq * 16u) = r[i];              \
+        else *(u32x4*)(dst + ((g - MW_XG) * MW_TS + tj) * MW_IN_STRIDE + MW_CHUNK * 8u + tq * 16u) = r[i]; \
     }
     if (chunks == 0u) return;
     MW_FETCH(0u)
     MW_STAGE(0u)
     __syncthreads();
+    const uint32_t hs = 16u * half;
     for (uint32_t c = 0; c < chunks; ++c) {
         const uint32_t buf = c & 1u;
         if (c + 1u < chunks) { MW_FETCH(c + 1u) }
-        const uint8_t* mine = lds_in + buf * MW_IN_BYTES + (lane >> 1) * MW_IN_STRIDE + half * (MW_CHUNK * 8u);
+        const uint8_t* mine = lds_in + buf * MW_IN_BYTES + (lane >> 1) * MW_IN_STRIDE;
         uint32_t* outp = (uint32_t*)(lds_out + (lane >> 1) * MW_OUT_STRIDE) + half;
         const uint32_t p0 = c * MW_CHUNK;
 #pragma unroll
         for (uint32_t k = 0; k < MW_CHUNK / 2u; ++k) {
-            const u32x4 st = *(const u32x4*)(mine + k * 16u), cm = *(const u32x4*)(mine + 2u * (MW_CHUNK * 8u) + k * 16u);
+            const u32x4 st = *(const u32x4*)(mine + k * 16u), cm = *(const u32x4*)(mine + MW_MODEL_BYTES + k * 16u);
+            const u32x2 stt = *(const u32x2*)(mine + MW_CHUNK * 8u + k * 8u), cmt = *(const u32x2*)(mine + MW_MODEL_BYTES + MW_CHUNK * 8u + k * 8u);
             const uint32_t p = p0 + 2u * k;
-            if (p < len) outp[4u * k] = mix_nibble(w, st.x, st.y, cm.x, cm.y);
-            if (p + 1u < len) outp[4u * k + 2u] = mix_nibble(w, st.z, st.w, cm.z, cm.w);
+            if (p < len) outp[4u * k] = mix_nibble(w, half ? st.y : st.x, (stt.x >> hs) & 0xffffu, half ? cm.y : cm.x, (cmt.x >> hs) & 0xffffu);
+            if (p + 1u < len) outp[4u * k + 2u] = mix_nibble(w, half ? st.w : st.z, (stt.y >> hs) & 0xffffu, half ? cm.w : cm.z, (cmt.y >> hs) & 0xffffu);
         }
         __syncthreads();
         // pairs out: load-shaped again, 16 bytes = both nibbles of two positions per lane
 #pragma unroll
-        for (uint32_t i = 0; i < MW_GROUPS; ++i) {
-            const uint32_t j = i * MW_SPL + mj, p = p0 + 2u * mq;
+        for (uint32_t i = 0; i < MW_XG; ++i) {
+            const uint32_t j = i * MW_XS + xj, p = p0 + 2u * xq;
             const uint32_t slen = s0 + j < b.n_streams ? (b.in_sizes ? b.in_sizes[s0 + j] : b.stream_len) : 0u;
             if (p < slen)   // an odd stream's last quad carries one stale pair: it stays inside the (even) slot and is never read
-                *(u32x4*)(b.sf + (size_t)(s0 + j) * b.sf_stride + 2u * p) = *(const u32x4*)(lds_out + j * MW_OUT_STRIDE + mq * 16u);
+                *(u32x4*)(b.sf + (size_t)(s0 + j) * b.sf_stride + 2u * p) = *(const u32x4*)(lds_out + j * MW_OUT_STRIDE + xq * 16u);
         }
         if (c + 1u < chunks) { MW_STAGE(buf ^ 1u) }
         __syncthreads();
@@ -411,10 +450,10 @@ hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hi
             launch_bucket_tasks(v, st);
             hipLaunchKernelGGL(mix_chain_kernel<1>, dim3(num_cus * MX_CHAIN_WAVES), dim3(64), MxGeom<1>::LDS_BYTES, st, b);
         }
-        v.sfs = b.pos[2 * model]; v.sf = (uint32_t*)b.pos[2 * model];
+        v.sfs = b.xs[model]; v.sf = (uint32_t*)b.xs[model]; v.sf_stride = 2u * b.pos_stride;
         launch_bucket_unsort(v, st);
-        v.sfs = b.pos[2 * model + 1]; v.sf = (uint32_t*)b.pos[2 * model + 1];
-        launch_bucket_unsort(v, st);
+        v.sfs = (bk_u32x2*)b.maxes[model]; v.sf = b.maxes[model]; v.sf_stride = b.pos_stride;
+        launch_bucket_unsort32(v, st);
     }
     hipLaunchKernelGGL(mix_weights_kernel, dim3((b.n_streams + 31u) / 32u), dim3(64), 0, st, b);
     return hipGetLastError();

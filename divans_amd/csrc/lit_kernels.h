@@ -106,6 +106,7 @@ struct BucketBatch {
 hipError_t launch_bucket_model(const BucketBatch& b, uint32_t chain_blocks, hipStream_t st);
 void launch_bucket_tasks(const BucketBatch& b, hipStream_t st);
 void launch_bucket_unsort(const BucketBatch& b, hipStream_t st);
+void launch_bucket_unsort32(const BucketBatch& b, hipStream_t st);   // the same for a plane of 4-byte elements
 
 // Bucketed encoder model pass for the two-model configuration (lit_bucket_mix.hip): context map on, every mixing value 4
 // (stride 1), dynamic mixing (context_mixing >= 2), one literal block type, no segment lists, streams <= 64 KiB.
@@ -113,8 +114,8 @@ struct MixBucketBatch {
     const uint8_t* in; const uint64_t* in_offsets; const uint32_t* in_sizes;
     uint32_t n_streams, stream_len, max_stream_len;
     uint32_t pieces;            // 8 KiB pieces per stream slot, at most 8
-    uint32_t slot;              // elements per stream in sorted / inv / the record planes pos[] (see BucketBatch::slot)
-    uint32_t pos_stride;        // elements per stream in pos[]
+    uint32_t slot;              // elements per stream in sorted / inv / the record planes (see BucketBatch::slot)
+    uint32_t pos_stride;        // elements per stream in xs[] / maxes[]
     uint32_t sf_stride;         // u32 elements per stream in sf
     const uint8_t* blob;        // configuration tables (LIT_BLOB_LUT1CLASS, LIT_BLOB_CTXF of the one block type)
     uint16_t* sorted;           // [n_streams][pieces * 8192] byte | high-row slot << 8, every piece ordered by (key, position)
@@ -122,11 +123,14 @@ struct MixBucketBatch {
     uint32_t* desc;             // [n_streams][256 keys][8 pieces] first slot | count << 16
     uint32_t* tasks;            // [6 size classes][n_streams * 256]
     uint32_t* counters;
-    // [n_streams][slot] records {cdf[sym] | cdf[sym-1] << 16, cdf[15]} of a nibble's row BEFORE the row is blended with the
-    // symbol: stride high, stride low, cm high, cm low.  The chains write them in sorted order; bucket_unsort_kernel puts every
-    // piece back into position order in place (it holds a whole piece in LDS before it writes)
-    bk_u32x2* pos[4];
-    uint32_t* sf;               // [n_streams][sf_stride] what rans_encode_kernel reads; may be pos[0] (mix_weights_kernel reads a
+    // What the chains leave per position and model (0 stride, 1 context map), taken from the two rows BEFORE they are blended with the
+    // position's nibbles: xs[m][n_streams][slot] = {high: cdf[sym] | cdf[sym-1] << 16, low: the same}, maxes[m][n_streams][slot] =
+    // cdf[15] of the high row | of the low row << 16 -- 12 bytes, split so that each plane keeps power-of-two elements.  The chains
+    // write them in sorted order; the unsort kernels put every piece back into position order in place (a whole piece sits in LDS
+    // before it is written).
+    bk_u32x2* xs[2];
+    uint32_t* maxes[2];
+    uint32_t* sf;               // [n_streams][sf_stride] what rans_encode_kernel reads; may be xs[0] (mix_weights_kernel reads a
                                 // chunk of all four planes before it writes that chunk's pairs)
     int32_t inc0, lim0, inc2, lim2, inc3, lim3;   // literal_adaptation[0] (stride rows), [2] (cm low), [3] (cm high)
 };
