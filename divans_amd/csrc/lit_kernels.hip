@@ -434,7 +434,11 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
 // Streams of one or two chunks (at most 65 536 bytes): the chunks are independent rANS runs (states restart at 2^31,
 // ans.rs:331-378), so each gets its own lane.  Lane pair (2k, 2k+1) = chunks (0, 1) of stream k; chunk 1 lands
 // right-aligned in the stream's slot as before, chunk 0 in a scratch area, and rans_stitch_kernel puts it in front.
-__global__ __launch_bounds__(RANS_THREADS) void rans_encode2_kernel(const RansBatch b) {
+// At most two waves per SIMD (amdgpu_waves_per_eu): the pass is bound by its own instruction stream -- two waves on a SIMD take twice
+// as long as one -- so all that matters is that the one-wave workgroups are spread evenly, and left to itself the dispatcher stacks
+// three on some SIMDs of a CU while others hold one: 65 536 streams = 2048 waves = two per SIMD took 19.0 ms, pinned 14.7
+// (profiles/r03g_rans_wave_placement.txt).  Larger batches simply run in rounds of 2048 waves.
+__global__ __launch_bounds__(RANS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void rans_encode2_kernel(const RansBatch b) {
     const uint32_t g = blockIdx.x * RANS_THREADS + threadIdx.x;
     const uint32_t s = g >> 1, ck = g & 1u;
     const bool live = s < b.n_streams;
