@@ -179,3 +179,20 @@ def test_reference_example_c_on_the_host_logic(args, env, tmp_path, corpus):
     corpus[:100000].tofile(src)
     r = subprocess.run([exe] + args + [str(src)], capture_output=True, text=True, env=e, timeout=300)
     assert r.returncode == 0 and "File length 100000 reduced to" in r.stdout, (r.returncode, r.stdout, r.stderr[-3000:])
+
+
+def test_stub_restates_the_librarys_host_rules(lib):
+    """the stub carries copies of two host-only rules of capi.cpp (which cannot be linked without HIP): the speed rule and the output
+    bound; they must not drift from the library's"""
+    import divans_amd as da
+    real = da.load_library()
+    for L in (lib, real):
+        L.divans_gpu_speed_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]; L.divans_gpu_speed_supported.restype = ctypes.c_int
+        L.divans_gpu_lit_encode_bound.argtypes = [ctypes.c_size_t]; L.divans_gpu_lit_encode_bound.restype = ctypes.c_size_t
+    rng = np.random.default_rng(2)
+    cases = [(int(a) >> int(s), max(0, int(b) >> int(t))) for a, b, s, t in zip(rng.integers(-2, 0x4003, 4000), rng.integers(-2, 0x4003, 4000),
+                                                                              rng.integers(0, 8, 4000), rng.integers(0, 8, 4000))]
+    for inc, lim in cases:
+        assert lib.divans_gpu_speed_supported(inc, lim) == real.divans_gpu_speed_supported(inc, lim), (inc, lim)
+    for n in list(range(0, 70)) + [32767, 32768, 32769, 65535, 65536, 65537, 1 << 20, (1 << 24) + 5]:
+        assert lib.divans_gpu_lit_encode_bound(n) == real.divans_gpu_lit_encode_bound(n), n
