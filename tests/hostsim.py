@@ -66,3 +66,14 @@ def build_program(name, source, lang="c++", sanitize_main=True):
         subprocess.run(cc + (san if sanitize_main else ["-O1", "-g"]) + ["-c", source, "-o", obj, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(source)], check=True)
         subprocess.run(["g++"] + san + ["-o", exe, obj] + objs + ["-lpthread"], check=True)
     return exe
+
+
+def build_thread_test():
+    """tests/c/_build/hostsim_threads: tests/c/hostsim_threads.cpp and the harness objects under -fsanitize=thread."""
+    exe = os.path.join(OUT, "hostsim_threads")
+    san = ["-O1", "-g", "-msse4.2", "-fsanitize=thread", "-fno-omit-frame-pointer"]
+    objs = _objects("tsan", san)
+    driver = os.path.join(ROOT, "tests", "c", "hostsim_threads.cpp")
+    if _newer(exe, objs + [driver]):
+        subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
+    return exe

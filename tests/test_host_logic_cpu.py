@@ -196,3 +196,13 @@ def test_stub_restates_the_librarys_host_rules(lib):
         assert lib.divans_gpu_speed_supported(inc, lim) == real.divans_gpu_speed_supported(inc, lim), (inc, lim)
     for n in list(range(0, 70)) + [32767, 32768, 32769, 65535, 65536, 65537, 1 << 20, (1 << 24) + 5]:
         assert lib.divans_gpu_lit_encode_bound(n) == real.divans_gpu_lit_encode_bound(n), n
+
+
+def test_independent_states_on_concurrent_threads_under_tsan(tmp_path, corpus):
+    """distinct compressor / decompressor states are independent (src/ffi/interface.rs:49-50): four threads of round trips and refused
+    damaged streams over the shared codec cache and the per-thread error string, under ThreadSanitizer"""
+    exe = hostsim.build_thread_test()
+    src = tmp_path / "in.bin"
+    corpus[:100000].tofile(src)
+    r = subprocess.run([exe, str(src), "4", "6"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failures" in r.stdout, (r.returncode, r.stdout, r.stderr[-4000:])
