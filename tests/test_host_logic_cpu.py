@@ -206,3 +206,61 @@ def test_independent_states_on_concurrent_threads_under_tsan(tmp_path, corpus):
     corpus[:100000].tofile(src)
     r = subprocess.run([exe, str(src), "4", "6"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 failures" in r.stdout, (r.returncode, r.stdout, r.stderr[-4000:])
+
+
+def test_decoder_on_random_command_streams_from_the_oracle(lib):
+    """containers whose CMD stream is not the internal compressor's: a random PredictionMode (prediction mode, context map for 1-4
+    literal block types coded through the LRU / mnemonic scheme of context_map.rs:264-331, mixing values 0..8, speeds as f8 pairs,
+    mixing parameter, prior depth), a BlockSwitchLiteral, then Literal commands of random lengths -- built by the oracle's encoder
+    from the command list, decoded by the product's host code (CommandModel, lit_config_from_prediction_mode) call by call"""
+    speeds = [(0, 1024), (2, 1024), (1, 128), (1, 16384), (2, 2048), (4, 1024), (8, 8192), (16, 48), (16, 8192), (32, 4096), (64, 16384),
+              (128, 256), (128, 16384), (512, 16384), (1664, 16384)]                           # probability/interface.rs:303-320
+    L = po.lib()
+    L.orc_speed_to_u8.argtypes = [ctypes.c_int16]; L.orc_speed_to_u8.restype = ctypes.c_uint8
+    rng = np.random.default_rng(77)
+    done = 0
+    for case in range(240):
+        n_bt = int(rng.integers(1, 5))
+        style = int(rng.integers(0, 3))
+        if style == 0:
+            cm = (np.arange(64 * n_bt) & 63).astype(np.uint8)
+        elif style == 1:
+            cm = rng.integers(0, int(rng.integers(1, 64)), 64 * n_bt).astype(np.uint8)        # few clusters: long mnemonic runs
+        else:
+            cm = np.repeat(rng.integers(0, 256, 8 * n_bt), 8).astype(np.uint8)                # any byte value, runs of eight
+        dm = rng.integers(0, 4, 4 * int(rng.integers(1, 5))).astype(np.uint8)
+        mix = (rng.integers(0, 9, 8192) if case % 3 else np.full(8192, int(rng.integers(0, 9)))).astype(np.uint8)
+        pm = po.PredictionMode()
+        pm.prediction_mode = int(rng.integers(0, 4))
+        pm.literal_context_map = cm.ctypes.data; pm.n_literal_context_map = cm.size
+        pm.distance_context_map = dm.ctypes.data; pm.n_distance_context_map = dm.size
+        pm.mixing_values = mix.ctypes.data
+        pm.has_context_speeds = int(rng.integers(0, 2))
+        for arr in (pm.context_map_speed_f8, pm.stride_speed_f8, pm.combined_stride_speed_f8):
+            for i in range(2):
+                inc, lim = speeds[int(rng.integers(0, len(speeds)))]
+                arr[i][0] = L.orc_speed_to_u8(inc); arr[i][1] = L.orc_speed_to_u8(lim)
+        cmds = []
+        c = po.StreamCommand(); c.kind = 7; c.pm = pm; cmds.append(c)
+        c = po.StreamCommand(); c.kind = 4; c.btype = int(rng.integers(0, n_bt)); c.stride = int(rng.integers(0, 5)); cmds.append(c)
+        pieces = []
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(rng.integers(1, 1 << int(rng.integers(1, 17))))
+            kind = int(rng.integers(0, 3))
+            d = (rng.integers(0, 256, n) if kind == 0 else np.resize(rng.integers(32, 127, int(rng.integers(1, 40))), n) if kind == 1
+                 else rng.integers(97, 123, n)).astype(np.uint8)
+            pieces.append(d)
+            c = po.StreamCommand(); c.kind = 3; c.data = d.ctypes.data; c.len = d.size; cmds.append(c)
+        data = np.concatenate(pieces)
+        o = po.stream_options(window_size=int(rng.integers(10, 23)), dynamic_context_mixing=int(rng.integers(0, 3)),
+                              prior_depth=int(rng.integers(0, 3)), use_context_map=int(rng.integers(0, 2)), force_stride=int(rng.integers(0, 3)),
+                              call_buffer_size=int(rng.integers(1, 70000)))
+        try:
+            coded = po.stream_compress_commands(cmds, o, keepalive=(pieces, cm, dm, mix))
+        except RuntimeError:
+            continue                                             # a combination the oracle's encoder refuses (e.g. a speed pair it cannot run)
+        assert (po.stream_decompress(coded, data.size) == data).all(), case
+        back = fh.ffi_decompress(lib, coded, data.size, buf_size=int(rng.integers(1, 70000)), feed=int(rng.integers(1, 9000)))
+        assert (back == data).all(), case
+        done += 1
+    assert done >= 180
