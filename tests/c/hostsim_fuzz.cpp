@@ -2,6 +2,7 @@
 //
 //   hostsim_fuzz <file> <seed> <iterations> [selector=value ...]
 //   hostsim_fuzz ir <file.ir> <seed> <iterations>
+//   hostsim_fuzz plan <file> <seed> <iterations>
 //
 // 1. compresses <file> through divans_encode / divans_encode_flush with seeded random input pieces and output buffer sizes (1 byte ..
 //    64 KiB), decompresses it the same way and compares;
@@ -14,6 +15,10 @@
 //    (divans_amd/csrc/batch.cpp), which must agree with the streaming decoder on what is acceptable.
 // `ir` mode: the textual command IR (include/divans_ir.h) -- the file must parse and expand; damaged copies (bytes flipped, tokens
 // deleted / duplicated, numbers replaced by huge ones) may be refused or accepted, within bounds.
+// `plan` mode: the two-phase container builder of the batch interface (divans_host::plan_stream -- everything that needs no literal
+// data -- and assemble_container, divans_amd/csrc/batch.cpp's host half) with random lengths, options, call buffers and call
+// patterns; the literal bytes come from the oracle's literal coder under the plan's configuration, and the container must be the
+// oracle's (orc_stream_compress_raw) byte for byte.
 // exit 0 = all held; prints one summary line.
 #include <cstdint>
 #include <cstdio>
@@ -25,6 +30,9 @@
 #include "../../include/divans_ffi.h"
 #include "../../include/divans_ir.h"
 #include "../../divans_amd/csrc/host_stream.h"
+extern "C" {
+#include "../../oracle/divans_oracle.h"
+}
 
 static uint64_t rng_state;
 static uint64_t rnd() {                       // xorshift64*
@@ -171,7 +179,80 @@ static int fuzz_ir(const char* path, long iterations) {
     return 0;
 }
 
+static int fuzz_plan(const char* path, long iterations) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return 2;
+    Bytes data; { uint8_t tmp[65536]; size_t n; while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) data.insert(data.end(), tmp, tmp + n); }
+    std::fclose(f);
+    static const divans_speed palette[6] = {{0x10, 0x2000}, {2, 1024}, {64, 16384}, {128, 16384}, {1, 16384}, {4, 1024}};
+    size_t total_in = 0, total_out = 0;
+    for (long it = 0; it < iterations; ++it) {
+        const size_t n = (rnd() % 8 == 0) ? rnd_below(8) : std::min(data.size(), (rnd() % 3 == 0) ? rnd_below(data.size() + 1) : rnd_size() * (1 + rnd_below(4)));
+        const size_t from = rnd_below(data.size() - n + 1);
+        const uint8_t* in = data.data() + from;
+        divans_host::StreamOptions opt;
+        opt.window_size = 10 + (int)rnd_below(13);
+        opt.dynamic_context_mixing = (uint8_t)rnd_below(3);
+        opt.use_context_map = (rnd() & 1) != 0;
+        opt.force_stride = (uint8_t)((rnd() & 1) ? rnd_below(9) : 9);
+        opt.has_prior_depth = (rnd() & 3) == 0; opt.prior_depth = (uint8_t)rnd_below(3);
+        opt.has_literal_adaptation = (rnd() & 3) == 0;
+        for (auto& sp : opt.literal_adaptation) sp = palette[rnd_below(6)];
+        opt.use_brotli = 0;
+        const size_t call_buffer = rnd_size();
+        std::vector<size_t> calls;
+        if (rnd() & 1) { size_t left = n; while (left) { const size_t k = std::min(left, rnd_size() * (1 + rnd_below(3))); calls.push_back(k); left -= k; } }
+        // the product's two phases
+        divans_host::StreamPlan plan;
+        if (divans_host::plan_stream(opt, n, calls.empty() ? nullptr : &calls, plan) != 0) { std::fprintf(stderr, "iteration %ld: plan_stream failed\n", it); return 3; }
+        orc_lit_config cfg; std::memcpy(&cfg, &plan.cfg, sizeof(cfg));
+        orc_lit_state* st = orc_lit_state_new(&cfg);
+        orc_ans_encoder enc; orc_ans_encoder_init(&enc);
+        std::vector<uint32_t> chunk_bytes;
+        for (size_t pos = 0; pos < n; ) {                            // 32 768 bytes = one 65 536-symbol chunk
+            const size_t take = std::min<size_t>(n - pos, 32768);
+            const size_t before = enc.out.len;
+            orc_lit_encode_bytes(st, &enc, in + pos, take);
+            pos += take;
+            if (enc.out.len != before) chunk_bytes.push_back((uint32_t)(enc.out.len - before));
+        }
+        if (enc.n_pending) { const size_t before = enc.out.len; orc_ans_flush_chunk(&enc); chunk_bytes.push_back((uint32_t)(enc.out.len - before)); }
+        if (chunk_bytes.size() != plan.lit_chunks) { std::fprintf(stderr, "iteration %ld: %zu chunks, the plan expects %u\n", it, chunk_bytes.size(), plan.lit_chunks); return 4; }
+        Bytes mine;
+        const int rc = divans_host::assemble_container(plan, enc.out.data, enc.out.len, chunk_bytes.data(), call_buffer, mine);
+        orc_ans_encoder_free(&enc); orc_lit_state_free(st);
+        if (rc != 0) { std::fprintf(stderr, "iteration %ld: assemble_container failed (%d)\n", it, rc); return 5; }
+        // the oracle's container for the same caller
+        orc_stream_options o; orc_stream_options_default(&o);
+        o.window_size = opt.window_size; o.dynamic_context_mixing = opt.dynamic_context_mixing;
+        o.prior_depth = opt.has_prior_depth ? opt.prior_depth : 0; o.use_context_map = opt.use_context_map ? 1 : 0; o.force_stride = opt.force_stride;
+        o.has_literal_adaptation = opt.has_literal_adaptation ? 1 : 0;
+        for (int i = 0; i < 4; ++i) { o.literal_adaptation[i].inc = opt.literal_adaptation[i].inc; o.literal_adaptation[i].lim = opt.literal_adaptation[i].lim; }
+        o.call_buffer_size = call_buffer; o.call_inputs = calls.empty() ? nullptr : calls.data(); o.n_call_inputs = calls.size();
+        Bytes ref(2 * n + 70000);
+        const size_t rn = orc_stream_compress_raw(&o, in, n, ref.data(), ref.size());
+        if (rn == (size_t)-1) { std::fprintf(stderr, "iteration %ld: the oracle failed\n", it); return 6; }
+        if (rn != mine.size() || std::memcmp(ref.data(), mine.data(), rn) != 0) {
+            size_t d = 0; while (d < rn && d < mine.size() && ref[d] == mine[d]) ++d;
+            std::fprintf(stderr, "iteration %ld: n %zu window %d mixing %u buffer %zu calls %zu: %zu vs %zu bytes, first difference at %zu\n",
+                         it, n, opt.window_size, opt.dynamic_context_mixing, call_buffer, calls.size(), mine.size(), rn, d);
+            return 7;
+        }
+        // and the whole-container parser takes it apart again
+        divans_host::ParsedStream ps; size_t used = 0;
+        if (divans_host::parse_container_host(mine.data(), mine.size(), false, n + 16, ps, &used) != divans_host::PARSE_OK || ps.total != n || used != mine.size()
+            || std::memcmp(&ps.cfg, &plan.cfg, sizeof(plan.cfg)) != 0) { std::fprintf(stderr, "iteration %ld: the parser disagrees with the plan\n", it); return 8; }
+        total_in += n; total_out += mine.size();
+    }
+    std::printf("%ld planned containers: %zu bytes in, %zu out, all equal to the oracle's\n", iterations, total_in, total_out);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 5 && std::strcmp(argv[1], "plan") == 0) {
+        rng_state = std::strtoull(argv[3], nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
+        return fuzz_plan(argv[2], std::strtol(argv[4], nullptr, 0));
+    }
     if (argc >= 5 && std::strcmp(argv[1], "ir") == 0) {
         rng_state = std::strtoull(argv[3], nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
         return fuzz_ir(argv[2], std::strtol(argv[4], nullptr, 0));

@@ -264,3 +264,15 @@ def test_decoder_on_random_command_streams_from_the_oracle(lib):
         assert (back == data).all(), case
         done += 1
     assert done >= 180
+
+
+def test_planned_containers_of_the_batch_interface_equal_the_oracles(fuzzer, tmp_path, corpus):
+    """divans_batch_compress builds a container in two phases -- plan_stream (CMD coder, order of events; needs no literal data, runs on
+    host threads under the GPU work) and assemble_container (Mux replay once the literal chunks exist).  `hostsim_fuzz plan` runs both
+    with random lengths, options, call buffers and call patterns, takes the literal bytes from the oracle's literal coder under the
+    plan's configuration, and compares the container with the oracle's; parse_container_host then has to recover the plan's
+    configuration and the length."""
+    src = tmp_path / "in.bin"
+    corpus[3000:3000 + 150000].tofile(src)
+    r = subprocess.run([fuzzer, "plan", str(src), "5", "150"], capture_output=True, text=True, timeout=900, env=SAN_ENV)
+    assert r.returncode == 0 and "all equal to the oracle's" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
