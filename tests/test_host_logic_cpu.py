@@ -276,3 +276,51 @@ def test_planned_containers_of_the_batch_interface_equal_the_oracles(fuzzer, tmp
     corpus[3000:3000 + 150000].tofile(src)
     r = subprocess.run([fuzzer, "plan", str(src), "5", "150"], capture_output=True, text=True, timeout=900, env=SAN_ENV)
     assert r.returncode == 0 and "all equal to the oracle's" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_option_stage_and_state_helpers(lib, corpus):
+    """divans_set_option (src/ffi/compressor.rs:63-166): accepted, ignored and refused selectors and values, the OptionStage rule, the
+    brotli knobs changing nothing about the container, the serial decompressor alias and the state allocators (src/ffi/mod.rs:111-145)"""
+    vp = ctypes.c_void_p
+    data = corpus[2000:2000 + 20000]
+    plain = fh.ffi_compress(lib, data, [(5, 0)])
+    # front-end knobs are stored and never read by the literal-only compressor
+    assert (fh.ffi_compress(lib, data, [(5, 0), (1, 11), (3, 18), (10, 2), (15, 340), (16, 1), (17, 1), (18, 1), (19, 2), (20, 1)]) == plain).all()
+    # brotli command selection 1 / 2 and the brotli bitstream setting fall back to the internal selection: same bytes
+    assert (fh.ffi_compress(lib, data, [(5, 1)]) == plain).all() and (fh.ffi_compress(lib, data, [(6, 1)]) == plain).all()
+    st = lib.divans_new_compressor()
+    for sel, val in [(0, 0), (21, 0), (99, 1), (5, 3), (6, 0), (6, 2), (7, 2), (9, 9), (8, 15), (12, 15), (13, 99), (14, 15)]:
+        assert lib.divans_set_option(st, sel, val) == 3, (sel, val)
+    for sel, val in [(2, 9), (2, 30), (4, 0), (4, 2), (7, 0), (7, 1), (9, 0), (9, 8), (11, 0), (11, 2), (8, 0), (12, 14), (13, 7), (14, 3)]:
+        assert lib.divans_set_option(st, sel, val) == 0, (sel, val)
+    q = lib.divans_compressor_uses_internal_command_selection_instead_of_brotli
+    q.argtypes = [vp]; q.restype = ctypes.c_uint8
+    assert q(st) == 1 and lib.divans_set_option(st, 5, 0) == 0 and q(st) == 0 and q(None) == 0
+    for fn, rt in (("divans_compressor_malloc_u8", vp), ("divans_compressor_malloc_usize", vp)):
+        getattr(lib, fn).argtypes = [vp, ctypes.c_size_t]; getattr(lib, fn).restype = rt
+    lib.divans_compressor_free_u8.argtypes = [vp, vp, ctypes.c_size_t]; lib.divans_compressor_free_usize.argtypes = [vp, vp, ctypes.c_size_t]
+    p = lib.divans_compressor_malloc_u8(st, 1000); u = lib.divans_compressor_malloc_usize(st, 100)
+    assert p and u
+    ctypes.memset(p, 0xAB, 1000); ctypes.memset(u, 0xCD, 100 * ctypes.sizeof(ctypes.c_size_t))
+    lib.divans_compressor_free_u8(st, p, 1000); lib.divans_compressor_free_usize(st, u, 100)
+    lib.divans_free_compressor(st)
+    lib.divans_free_compressor(None)
+    # window sizes outside [10, 24] are clamped, not refused (divans_compressor.rs:89)
+    assert (fh.ffi_decompress(lib, fh.ffi_compress(lib, data, [(5, 0), (2, 3)]), data.size) == data).all()
+    assert (fh.ffi_decompress(lib, fh.ffi_compress(lib, data, [(5, 0), (2, 31)]), data.size) == data).all()
+    lib.divans_new_serial_decompressor.restype = vp
+    ds = lib.divans_new_serial_decompressor()
+    for fn in ("divans_decompressor_malloc_u8", "divans_decompressor_malloc_usize"):
+        getattr(lib, fn).argtypes = [vp, ctypes.c_size_t]; getattr(lib, fn).restype = vp
+    lib.divans_decompressor_free_u8.argtypes = [vp, vp, ctypes.c_size_t]; lib.divans_decompressor_free_usize.argtypes = [vp, vp, ctypes.c_size_t]
+    p = lib.divans_decompressor_malloc_u8(ds, 64); u = lib.divans_decompressor_malloc_usize(ds, 8)
+    assert p and u
+    lib.divans_decompressor_free_u8(ds, p, 64); lib.divans_decompressor_free_usize(ds, u, 8)
+    out = np.empty(data.size, np.uint8); ro = ctypes.c_size_t(0); wo = ctypes.c_size_t(0)
+    assert lib.divans_decode(ds, plain.ctypes.data, plain.size, ctypes.byref(ro), out.ctypes.data, out.size, ctypes.byref(wo)) == 0
+    assert wo.value == data.size and (out == data).all()
+    lib.divans_free_decompressor(ds)
+    lib.divans_free_decompressor(None)
+    # null arguments are failures, not crashes (src/ffi/mod.rs:70-108,236-262)
+    assert lib.divans_encode(None, None, 0, None, None, 0, None) == 3 and lib.divans_encode_flush(None, None, 0, None) == 3
+    assert lib.divans_decode(None, None, 0, None, None, 0, None) == 3
