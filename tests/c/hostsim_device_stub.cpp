@@ -2,7 +2,8 @@
 //
 // The per-stream container logic of the product (divans_amd/csrc/host_stream.cpp + ffi.cpp: ring-buffer command emission, CMD coder,
 // Mux, CRC, the call-by-call NEEDS_MORE_INPUT / NEEDS_MORE_OUTPUT semantics, the parser of untrusted containers) reaches the GPU through
-// nine entry points of include/divans_gpu.h.  This file stands in for those nine with the CPU oracle (oracle/*.c), so that the host logic
+// nine entry points of include/divans_gpu.h (and divans_amd/csrc/batch.cpp through six more, at the end of this file).  This file stands
+// in for them with the CPU oracle (oracle/*.c), so that the host logic
 // can be run where there is no GPU -- the "not gpu" test tier -- and under AddressSanitizer / UBSan with mutated input.  What it proves is
 // about the HOST code only; the kernels are compared with the oracle by the "-m gpu" tests through the real library.
 #include <cstdint>
@@ -27,6 +28,7 @@ struct divans_gpu_codec {
     orc_lit_state* st = nullptr;
     orc_ans_encoder enc; bool enc_live = false;
     bool begun = false;
+    uint8_t* flags = nullptr; uint32_t status = 0, blocks = 1024;      // what the batch entry points at the end of the file keep
 };
 
 static int fail(int code, const char* msg) { g_err = msg; return code; }
@@ -50,7 +52,7 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     delete c;
 }
 
-extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t, uint32_t) { return c ? 0 : DIVANS_GPU_EINVAL; }
+extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t) { if (!c) return DIVANS_GPU_EINVAL; if (blocks) c->blocks = blocks; return 0; }
 
 // the rule of divans_amd/csrc/capi.cpp (the one trajectory of cdf[15] from 64 under FrequentistCDF16::blend), so that the stub refuses
 // what the library refuses
@@ -142,5 +144,85 @@ extern "C" int divans_gpu_lit_stream_decode(divans_gpu_codec* c, const uint8_t* 
     // encoder's start states
     if (d.starved || d.state_a != (1ull << 31) || d.state_b != (1ull << 31)) return fail(DIVANS_GPU_ECORRUPT, "the literal stream fails its integrity check");
     *consumed_bytes = d.in_pos;
+    return 0;
+}
+
+// ---- the batch entry points divans_amd/csrc/batch.cpp uses (with tests/c/fakehip "device" pointers are host pointers) -----------
+extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info) {
+    if (!c || !info) return fail(DIVANS_GPU_EINVAL, "null argument");
+    std::memset(info, 0, sizeof(*info));
+    info->blocks = c->blocks; info->threads = 256; info->rows_per_stream = 4352; info->resident_groups = 16 * info->blocks;
+    return 0;
+}
+extern "C" int divans_gpu_codec_status(divans_gpu_codec* c, uint32_t* status) {
+    if (!c || !status) return fail(DIVANS_GPU_EINVAL, "null argument");
+    *status = c->status; c->status = 0;
+    return 0;
+}
+extern "C" int divans_gpu_codec_set_stream_flags(divans_gpu_codec* c, uint8_t* d_flags) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    c->flags = d_flags;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_encode_batch_chunks(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes,
+                                                  uint32_t stream_len, uint32_t n_streams, uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets,
+                                                  uint32_t* d_out_sizes, uint32_t* d_chunk_bytes, uint32_t max_chunks) {
+    if (!c || !d_in || !d_out || !d_out_offsets || !d_out_sizes) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if (stream_len > c->max_len || (out_slot & 15u) || out_slot < divans_gpu_lit_encode_bound(stream_len)) return fail(DIVANS_GPU_EINVAL, "bad geometry");
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        const uint32_t len = d_in_sizes ? d_in_sizes[i] : stream_len;
+        const uint8_t* in = d_in + (d_in_offsets ? d_in_offsets[i] : (uint64_t)i * stream_len);
+        if (len > stream_len) return fail(DIVANS_GPU_EINVAL, "stream longer than stream_len");
+        orc_lit_state* st = orc_lit_state_new(&c->cfg);
+        orc_ans_encoder enc; orc_ans_encoder_init(&enc);
+        uint32_t k = 0;
+        for (uint32_t pos = 0; pos < len; ) {
+            const uint32_t take = len - pos < 32768u ? len - pos : 32768u;
+            const size_t before = enc.out.len;
+            orc_lit_encode_bytes(st, &enc, in + pos, take);
+            pos += take;
+            if (enc.out.len != before && d_chunk_bytes && k < max_chunks) d_chunk_bytes[(size_t)i * max_chunks + k++] = (uint32_t)(enc.out.len - before);
+        }
+        if (enc.n_pending) { const size_t before = enc.out.len; orc_ans_flush_chunk(&enc); if (d_chunk_bytes && k < max_chunks) d_chunk_bytes[(size_t)i * max_chunks + k++] = (uint32_t)(enc.out.len - before); }
+        if (enc.failed) c->status |= DIVANS_GPU_STATUS_BAD_MODEL;
+        if (enc.out.len > out_slot) { orc_ans_encoder_free(&enc); orc_lit_state_free(st); return fail(DIVANS_GPU_ECAP, "slot too small"); }
+        uint8_t* slot_end = d_out + (uint64_t)(i + 1) * out_slot;                  // right-aligned, as the rANS pass leaves it
+        if (enc.out.len) std::memcpy(slot_end - enc.out.len, enc.out.data, enc.out.len);
+        d_out_offsets[i] = (uint64_t)(i + 1) * out_slot - enc.out.len;
+        d_out_sizes[i] = (uint32_t)enc.out.len;
+        orc_ans_encoder_free(&enc); orc_lit_state_free(st);
+    }
+    return 0;
+}
+
+extern "C" int divans_gpu_pack_streams(divans_gpu_codec* c, const uint8_t* d_slots, const uint64_t* d_offsets, const uint32_t* d_sizes, uint32_t n_streams,
+                                       uint8_t* d_packed, uint64_t* d_packed_offsets, uint64_t* d_total) {
+    if (!c || !d_slots || !d_offsets || !d_sizes || !d_packed || !d_packed_offsets || !d_total) return fail(DIVANS_GPU_EINVAL, "null argument");
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        d_packed_offsets[i] = pos;
+        if (d_sizes[i]) std::memcpy(d_packed + pos, d_slots + d_offsets[i], d_sizes[i]);
+        pos += ((uint64_t)d_sizes[i] + 3u) & ~(uint64_t)3;
+    }
+    *d_total = pos;
+    return 0;
+}
+
+extern "C" int divans_gpu_lit_decode_batch(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes, uint32_t n_streams,
+                                           uint8_t* d_out, const uint64_t* d_out_offsets, const uint32_t* d_out_sizes, uint32_t stream_len) {
+    if (!c || !d_in || !d_in_offsets || !d_in_sizes || !d_out) return fail(DIVANS_GPU_EINVAL, "null argument");
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        const uint32_t len = d_out_sizes ? d_out_sizes[i] : stream_len;
+        uint8_t* out = d_out + (d_out_offsets ? d_out_offsets[i] : (uint64_t)i * stream_len);
+        if (len > c->max_len) return fail(DIVANS_GPU_EINVAL, "stream longer than the codec's bound");
+        orc_lit_state* st = orc_lit_state_new(&c->cfg);
+        orc_ans_decoder d;
+        orc_ans_decoder_init(&d, d_in + d_in_offsets[i], d_in_sizes[i] & ~3u);
+        orc_lit_decode_bytes(st, &d, out, len);
+        const bool bad = d.starved || (len && (d.state_a != (1ull << 31) || d.state_b != (1ull << 31))) || d.in_pos != (d_in_sizes[i] & ~3u);
+        if (bad) { c->status |= DIVANS_GPU_STATUS_BAD_STREAM; if (c->flags) c->flags[i] = 1; }
+        orc_lit_state_free(st);
+    }
     return 0;
 }

@@ -77,3 +77,24 @@ def build_thread_test():
     if _newer(exe, objs + [driver]):
         subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
     return exe
+
+
+BATCH_SOURCE = "divans_amd/csrc/batch.cpp"
+
+
+def build_batch_test(sanitizer="address,undefined"):
+    """tests/c/_build/hostsim_batch_<tag>: tests/c/hostsim_batch.cpp + divans_amd/csrc/batch.cpp (compiled by g++ against
+    tests/c/fakehip's stand-in for <hip/hip_runtime.h>) + the harness objects, under the given sanitizer."""
+    tag = "tsan" if sanitizer == "thread" else "san"
+    exe = os.path.join(OUT, "hostsim_batch_" + tag)
+    san = ["-O1", "-g", "-msse4.2", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer"] + (["-fno-sanitize-recover=undefined"] if tag == "san" else [])
+    objs = _objects(tag, san)
+    batch_src = os.path.join(ROOT, BATCH_SOURCE)
+    fake = os.path.join(ROOT, "tests", "c", "fakehip")
+    batch_obj = os.path.join(OUT, tag + "_batch.cpp.o")
+    if _newer(batch_obj, [batch_src, os.path.join(fake, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "divans_batch.h")]):
+        subprocess.run(["g++", "-std=c++17"] + san + ["-fPIC", "-c", batch_src, "-o", batch_obj, "-I" + fake, "-I" + os.path.join(ROOT, "include")], check=True)
+    driver = os.path.join(ROOT, "tests", "c", "hostsim_batch.cpp")
+    if _newer(exe, objs + [batch_obj, driver]):
+        subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver, batch_obj] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
+    return exe

@@ -324,3 +324,17 @@ def test_option_stage_and_state_helpers(lib, corpus):
     # null arguments are failures, not crashes (src/ffi/mod.rs:70-108,236-262)
     assert lib.divans_encode(None, None, 0, None, None, 0, None) == 3 and lib.divans_encode_flush(None, None, 0, None) == 3
     assert lib.divans_decode(None, None, 0, None, None, 0, None) == 3
+
+
+@pytest.mark.parametrize("sanitizer,rounds,largest", [("address,undefined", 3, 400), ("thread", 2, 100)])
+def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, tmp_path, corpus):
+    """include/divans_batch.h without a GPU: divans_amd/csrc/batch.cpp itself (length classes, slices on lanes, persistent thread pool,
+    plans and parsing under the "GPU work", container assembly, error paths), compiled by g++ against a stand-in for the 16 HIP runtime
+    calls it makes (tests/c/fakehip) and the oracle-backed device stub.  tests/c/hostsim_batch.cpp: batches of mixed lengths and options,
+    containers == the oracle's, two configurations interleaved through one decompress call, short buffers, a damaged container that
+    has to be named -- under AddressSanitizer + UBSan, and again under ThreadSanitizer."""
+    exe = hostsim.build_batch_test(sanitizer)
+    src = tmp_path / "in.bin"
+    corpus.tofile(src)
+    r = subprocess.run([exe, str(src), "9", str(rounds), str(largest)], capture_output=True, text=True, timeout=1500, env=SAN_ENV)
+    assert r.returncode == 0 and "all equal to the oracle's and back" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
