@@ -4,7 +4,8 @@
 //
 //   hostsim_batch <file> <seed> <rounds> [largest batch, default 700]
 //
-// Per round: a batch of streams of mixed lengths (empty, tiny, around the 64 KiB class bound, now and then several hundred KB) under
+// Per round: a batch of streams of mixed lengths (empty, tiny, around the 64 KiB class bound, now and then several hundred KB; every
+// fourth round incompressible ones) under
 // random options and a random number of host threads -> divans_batch_compress; containers compared with the oracle's
 // (orc_stream_compress_raw, same options, one call, same call buffer); a second batch under other options is mixed in and everything
 // goes through divans_batch_decompress (grouping by configuration and length class) and must come back exact; then a damaged copy of one
@@ -58,7 +59,7 @@ static bool oracle_container(const divans_batch_options& b, const uint8_t* in, s
 
 struct Batch { std::vector<const uint8_t*> ptr; std::vector<size_t> len; };
 
-static Batch random_batch(const Bytes& data, size_t max_streams) {
+static Batch random_batch(const Bytes& data, size_t max_streams, size_t from = 0) {    // from: streams start at or after this offset of `data`
     Batch b;
     const size_t n = 1 + rnd_below(max_streams);
     for (size_t i = 0; i < n; ++i) {
@@ -66,11 +67,11 @@ static Batch random_batch(const Bytes& data, size_t max_streams) {
         switch (rnd() % 8) {
             case 0: len = rnd_below(3); break;
             case 1: len = 65536 - 2 + rnd_below(5); break;                      // around the first class bound
-            case 2: len = (rnd() % 16 == 0) ? 100000 + rnd_below(data.size() - 100000) : rnd_below(70000); break;
+            case 2: len = (rnd() % 16 == 0) ? 100000 + rnd_below(data.size() - from - 100000) : rnd_below(70000); break;
             default: len = 1 + rnd_below(9000); break;
         }
-        len = std::min(len, data.size());
-        b.ptr.push_back(data.data() + rnd_below(data.size() - len + 1)); b.len.push_back(len);
+        len = std::min(len, data.size() - from);
+        b.ptr.push_back(data.data() + from + rnd_below(data.size() - from - len + 1)); b.len.push_back(len);
     }
     return b;
 }
@@ -85,12 +86,14 @@ int main(int argc, char** argv) {
     std::fclose(f);
     if (data.size() < 200000) { std::fprintf(stderr, "the input file should hold at least 200 000 bytes\n"); return 2; }
     rng_state = std::strtoull(argv[2], nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
+    const size_t noise_from = data.size();                      // incompressible tail: packed streams larger than the staging guess (5/8 of the input)
+    for (size_t i = 0; i < 300000; ++i) data.push_back((uint8_t)rnd());
     const long rounds = std::strtol(argv[3], nullptr, 0);
     const size_t largest = argc > 4 ? (size_t)std::strtoul(argv[4], nullptr, 0) : 700;
     size_t n_containers = 0, bytes_in = 0;
     for (long round = 0; round < rounds; ++round) {
         const divans_batch_options oa = random_options(), ob = random_options();
-        const Batch a = random_batch(data, round % 4 == 0 ? largest : std::min<size_t>(60, largest)), b = random_batch(data, 20);
+        const Batch a = random_batch(data, round % 4 == 0 ? largest : std::min<size_t>(60, largest), round % 4 == 2 ? noise_from : 0), b = random_batch(data, 20);
         std::vector<Bytes> containers;                      // of a, then of b
         for (int which = 0; which < 2; ++which) {
             const Batch& x = which ? b : a; const divans_batch_options& o = which ? ob : oa;
