@@ -326,7 +326,7 @@ def test_option_stage_and_state_helpers(lib, corpus):
     assert lib.divans_decode(None, None, 0, None, None, 0, None) == 3
 
 
-@pytest.mark.parametrize("sanitizer,rounds,largest", [("address,undefined", 4, 300), ("thread", 3, 60)])
+@pytest.mark.parametrize("sanitizer,rounds,largest", [("address,undefined", 3, 250), ("thread", 2, 16)])
 def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, tmp_path, corpus):
     """include/divans_batch.h without a GPU: divans_amd/csrc/batch.cpp itself (length classes, slices on lanes, persistent thread pool,
     plans and parsing under the "GPU work", container assembly, error paths), compiled by g++ against a stand-in for the 16 HIP runtime
