@@ -1,7 +1,7 @@
 """N>1 data path on CPU: gloo ranks run exactly the functions bench.py runs on RCCL --
 rank 0 scatters contiguous stream ranges, every rank codes its shard (the oracle is the stand-in coder: this is a
 test), sizes are exchanged and the coded bytes gathered to rank 0 -- and the gathered blob must be byte-identical to
-what one process produces.  World sizes 2 and 3, stream counts that do not divide evenly."""
+what one process produces.  World sizes 2 and 3, stream counts that do not divide evenly, both BASELINE configurations."""
 import os
 import sys
 
@@ -29,7 +29,11 @@ def _code_and_pack(po, cfg, blocks):
     return packed, sizes
 
 
-def _worker(rank, world, port, n_streams, q):
+def _config(po, name):
+    return po.config_simple() if name == "simple" else po.config_context_mixing()
+
+
+def _worker(rank, world, port, n_streams, cfg_name, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,7 +48,7 @@ def _worker(rank, world, port, n_streams, q):
     mine = sharding.scatter_streams(full, n_streams, BLOCK, cpu)
     b, e = sharding.shard_bounds(n_streams, rank, world)
     assert tuple(mine.shape) == (e - b, BLOCK)
-    packed, sizes = _code_and_pack(po, po.config_simple(), mine.numpy())
+    packed, sizes = _code_and_pack(po, _config(po, cfg_name), mine.numpy())
     blob, offs, allsizes = sharding.gather_coded(packed, sizes, n_streams)
     total, = sharding.sum_over_ranks([int(sizes.sum())], cpu)
     slowest = sharding.max_over_ranks(0.25 * (rank + 1), cpu)
@@ -67,12 +71,12 @@ def test_shard_bounds():
             assert max(lens) - min(lens) <= 1
 
 
-@pytest.mark.parametrize("world,n_streams", [(2, 13), (3, 10), (3, 2)])
-def test_scatter_code_gather_matches_single_process(world, n_streams):
+@pytest.mark.parametrize("world,n_streams,cfg_name", [(2, 13, "simple"), (3, 10, "mixing"), (3, 2, "simple"), (2, 9, "mixing")])
+def test_scatter_code_gather_matches_single_process(world, n_streams, cfg_name):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() * 7 + world * 131 + n_streams) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, cfg_name, q)) for r in range(world)]
     for p in procs:
         p.start()
     blob, offs, allsizes, total, slowest = q.get(timeout=180)
@@ -83,13 +87,13 @@ def test_scatter_code_gather_matches_single_process(world, n_streams):
     import pyoracle as po
     import workload
     blocks = workload.make_blocks(workload.load_corpus(), 0, n_streams, block_len=BLOCK)
-    ref_packed, ref_sizes = _code_and_pack(po, po.config_simple(), blocks)
+    ref_packed, ref_sizes = _code_and_pack(po, _config(po, cfg_name), blocks)
     assert allsizes == ref_sizes.tolist() and total == int(ref_sizes.sum())
     assert blob == ref_packed.numpy().tobytes()
     # every stream sits where the offsets say
     for i in (0, n_streams // 2, n_streams - 1):
         got = np.frombuffer(blob, dtype=np.uint8)[offs[i]:offs[i] + allsizes[i]]
-        assert (got == po.lit_encode(po.config_simple(), blocks[i])).all()
+        assert (got == po.lit_encode(_config(po, cfg_name), blocks[i])).all()
     assert abs(slowest - 0.25 * world) < 1e-9
 
 
