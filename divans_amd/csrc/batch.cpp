@@ -458,6 +458,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     const size_t ns = (n_streams + per - 1) / per;
     std::vector<divans_host::ParsedStream> parsed(n_streams);
     std::vector<int> status(n_streams, 0);
+    divans_host::ParseMemo memo;     // equal-length streams of one producer carry the same CMD bytes: decode them once (host_stream.h)
     size_t pos = 0;
 
     struct Group { divans_lit_config cfg; uint32_t bound; std::vector<size_t> members; size_t in_bytes = 0, out_bytes = 0, in_base = 0, out_base = 0, idx_base = 0; };
@@ -468,7 +469,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
         const double t0 = now_ms();
         parallel_for(e - b, opt->host_threads, [&](size_t j) {
             const size_t i = b + j;
-            status[i] = (int)divans_host::parse_container_host(containers[i], sizes[i], opt->skip_crc != 0, (size_t)1 << 30, parsed[i], nullptr);
+            status[i] = (int)divans_host::parse_container_host(containers[i], sizes[i], opt->skip_crc != 0, (size_t)1 << 30, parsed[i], nullptr, &memo);
         });
         ov.host(t0, now_ms());
         for (size_t i = b; i < e; ++i)

@@ -15,6 +15,8 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
+#include <unordered_map>
 
 namespace divans_host {
 
@@ -938,8 +940,17 @@ int StreamEncoder::flush(uint8_t* out, size_t cap, size_t* out_off) {   // divan
     return 0;
 }
 
+struct ParseMemo::Impl {
+    struct Entry { uint64_t total; divans_lit_config cfg; };
+    std::mutex mu;
+    std::unordered_map<std::string, std::unique_ptr<Entry>> map;
+    static constexpr size_t kMaxEntries = 256;      // 25 KB each (the configuration); a batch of all-different lengths stops adding
+};
+ParseMemo::ParseMemo() : p_(new Impl()) {}
+ParseMemo::~ParseMemo() { delete p_; }
+
 // Host half of decoding: framing, CRC, CMD coder.  Leaves the LIT coder's bytes, the decoded size and its configuration.
-ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed) {
+ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed, ParseMemo* memo) {
     ps = ParsedStream();
     if (n < 16) return PARSE_NEED_MORE;
     if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f) return PARSE_CORRUPT;   // divans_decompressor.rs:38-52
@@ -954,6 +965,32 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
     if (std::memcmp(tr + 4, want + 4, 4) != 0) return PARSE_CORRUPT;               // codec/mod.rs:949-1017
     if (!skip_crc && std::memcmp(tr, want, 4) != 0) return PARSE_CORRUPT;
     if (consumed) *consumed = 16 + used + 8;
+    // the literal lengths are the stream's own claim: bound them before anything is allocated for them.  A literal
+    // byte costs the LIT coder at least ~0.0007 bytes (two nibbles at the largest probability the fastest
+    // speed allows), so a stream claiming more than 4096 bytes per coded LIT byte is lying.  (The claims only grow along the
+    // CMD stream, so the same test on a remembered final sum refuses exactly the streams the walk would have refused on the way.)
+    const uint64_t most = std::min<uint64_t>(max_output, (uint64_t)mux.s[1].avail() * 4096u + 65536u);
+    auto finish = [&](uint64_t total) -> ParseStatus {
+        ps.total = (size_t)total;
+        // the kernels read whole 32-bit words; LIT streams are 16 + 4k bytes per chunk by construction
+        ps.lit.assign(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
+        if (ps.lit.size() % 4) return PARSE_CORRUPT;
+        if (total == 0 && !ps.lit.empty()) return PARSE_CORRUPT;
+        return PARSE_OK;
+    };
+    std::string key;
+    if (memo) {
+        key.assign((const char*)mux.s[0].buf.data() + mux.s[0].start, mux.s[0].avail());
+        std::lock_guard<std::mutex> g(memo->p_->mu);
+        auto it = memo->p_->map.find(key);
+        if (it != memo->p_->map.end()) {
+            const ParseMemo::Impl::Entry& e = *it->second;
+            if (e.total > 0x7fffffffu) return PARSE_UNSUPPORTED;
+            if (e.total > most) return PARSE_CORRUPT;
+            ps.cfg = e.cfg;
+            return finish(e.total);
+        }
+    }
     // CMD stream on the host
     StreamOptions o;
     CommandModel model(o);
@@ -979,25 +1016,24 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
             if (!model.literal_length(nc, 15, len)) return PARSE_CORRUPT;
             total += len; seen_literal = true;
             if (total > 0x7fffffffu) return PARSE_UNSUPPORTED;
-            // the literal lengths are the stream's own claim: bound them before anything is allocated for them.  A literal
-            // byte costs the LIT coder at least ~0.0007 bytes (two nibbles at the largest probability the fastest
-            // speed allows), so a stream claiming more than 4096 bytes per coded LIT byte is lying.
-            if (total > max_output || total > (uint64_t)mux.s[1].avail() * 4096u + 65536u) return PARSE_CORRUPT;
+            if (total > most) return PARSE_CORRUPT;
         } else return PARSE_UNSUPPORTED;   // Copy / Dict / command- and distance- block switches
         if (cd.starved) return PARSE_CORRUPT;
     }
-    ps.total = (size_t)total;
     if (have_pm) model.fill_lit_config(ps.cfg, btype);
     else {   // LiteralBookKeeping::new defaults, codec/interface.rs:244-262
         std::memset(&ps.cfg, 0, sizeof(ps.cfg));
         ps.cfg.btype = btype;
         for (auto& s : ps.cfg.literal_adaptation) s = divans_speed{0x10, 0x2000};
     }
-    // the kernels read whole 32-bit words; LIT streams are 16 + 4k bytes per chunk by construction
-    ps.lit.assign(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
-    if (ps.lit.size() % 4) return PARSE_CORRUPT;
-    if (total == 0 && !ps.lit.empty()) return PARSE_CORRUPT;
-    return PARSE_OK;
+    if (memo) {
+        std::lock_guard<std::mutex> g(memo->p_->mu);
+        if (memo->p_->map.size() < ParseMemo::Impl::kMaxEntries && !memo->p_->map.count(key)) {
+            std::unique_ptr<ParseMemo::Impl::Entry> e(new ParseMemo::Impl::Entry{total, ps.cfg});
+            memo->p_->map.emplace(std::move(key), std::move(e));
+        }
+    }
+    return finish(total);
 }
 
 // ---------------------------------------------------------------- the decompressor, one call at a time

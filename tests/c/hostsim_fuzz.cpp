@@ -280,6 +280,7 @@ int main(int argc, char** argv) {
     { Bytes t = plain; t.insert(t.end(), 100, 0x5a); back.clear(); if (decompress(t, false, true, data.size(), back) != OK || back != data) { std::fprintf(stderr, "trailing bytes changed the result\n"); return 5; } }
 
     long n_ok = 0, n_failed = 0, n_wants = 0;
+    divans_host::ParseMemo memo;
     for (long it = 0; it < iterations; ++it) {
         Bytes c = (rnd() & 1) ? plain : ragged;
         damage(c, (rnd() & 1) ? plain : ragged);
@@ -292,6 +293,13 @@ int main(int argc, char** argv) {
         // the whole-container parser of the batch interface on the same bytes
         divans_host::ParsedStream ps; size_t used = 0;
         const divans_host::ParseStatus st = divans_host::parse_container_host(c.data(), c.size(), skip_crc, data.size() + (1u << 20), ps, &used);
+        {   // and with the memo of CMD streams seen before (divans_batch_decompress uses one per call): the same answer
+            divans_host::ParsedStream pm; size_t used_m = 0;
+            const divans_host::ParseStatus sm = divans_host::parse_container_host(c.data(), c.size(), skip_crc, data.size() + (1u << 20), pm, &used_m, &memo);
+            if (sm != st || (st == divans_host::PARSE_OK && (used_m != used || pm.total != ps.total || pm.lit != ps.lit || std::memcmp(&pm.cfg, &ps.cfg, sizeof(ps.cfg)) != 0))) {
+                std::fprintf(stderr, "iteration %ld: the memo changes the parser's answer (%d vs %d)\n", it, (int)sm, (int)st); return 10;
+            }
+        }
         if (st == divans_host::PARSE_OK && (used > c.size() || ps.total > data.size() + (1u << 20))) { std::fprintf(stderr, "iteration %ld: parser out of bounds\n", it); return 8; }
         if (st == divans_host::PARSE_OK && o != OK) {
             // framing, CMD stream and CRC held, so only the literal decoder can have refused it (its final-state check) -- impossible while the CRC is checked
