@@ -294,8 +294,11 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         bound_of[i] = class_bound(sizes[i]);
     }
     // the LIT configuration follows from the options alone (the PredictionMode of the internal compressor)
+    // ... and so does the first command of every stream: its trip through the CMD model is made once (host_stream.h, PlanPrefix)
+    const std::shared_ptr<const divans_host::PlanPrefix> prefix = divans_host::make_plan_prefix(so);
+    if (!prefix) return set_last_error(DIVANS_GPU_EINVAL, "options cannot be coded");
     divans_host::StreamPlan probe;
-    int rc = divans_host::plan_stream(so, 0, nullptr, probe);
+    int rc = divans_host::plan_stream(so, 0, nullptr, probe, prefix.get());
     if (rc) return set_last_error(rc, "options cannot be coded");
     HIP_OR_FAIL(hipSetDevice(opt->device));
     std::vector<size_t> order(n_streams);
@@ -320,7 +323,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         const double t0 = now_ms();
         parallel_for(plan_slots.size(), opt->host_threads, [&](size_t k) {
             auto p = std::make_unique<divans_host::StreamPlan>();
-            const int r = divans_host::plan_stream(so, plan_len[k], nullptr, *p);
+            const int r = divans_host::plan_stream(so, plan_len[k], nullptr, *p, prefix.get());
             if (r) plan_rc = r;
             *plan_slots[k] = std::move(p);
         });

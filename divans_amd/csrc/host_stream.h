@@ -6,6 +6,7 @@
 #define DIVANS_HOST_STREAM_H_
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "../../include/divans_gpu.h"
@@ -47,7 +48,9 @@ struct StreamPlan {
     std::vector<Step> steps;
     uint32_t lit_chunks = 0;                      // 65 536-symbol chunks of the LIT stream
 };
-int plan_stream(const StreamOptions& opt, size_t n, const std::vector<size_t>* call_inputs, StreamPlan& plan);
+struct PlanPrefix;     // model and CMD coder after the PredictionMode command of the internal compressor under given options
+std::shared_ptr<const PlanPrefix> make_plan_prefix(const StreamOptions& opt);   // null when the options cannot be coded
+int plan_stream(const StreamOptions& opt, size_t n, const std::vector<size_t>* call_inputs, StreamPlan& plan, const PlanPrefix* prefix = nullptr);
 int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_size, const uint32_t* chunk_bytes, size_t call_buffer,
                        std::vector<uint8_t>& out);
 

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -205,6 +206,15 @@ static int fuzz_plan(const char* path, long iterations) {
         // the product's two phases
         divans_host::StreamPlan plan;
         if (divans_host::plan_stream(opt, n, calls.empty() ? nullptr : &calls, plan) != 0) { std::fprintf(stderr, "iteration %ld: plan_stream failed\n", it); return 3; }
+        {   // the same plan through the shared PredictionMode prefix (what divans_batch_compress does for every stream of a batch)
+            const std::shared_ptr<const divans_host::PlanPrefix> prefix = divans_host::make_plan_prefix(opt);
+            divans_host::StreamPlan q;
+            if (!prefix || divans_host::plan_stream(opt, n, calls.empty() ? nullptr : &calls, q, prefix.get()) != 0) { std::fprintf(stderr, "iteration %ld: plan with prefix failed\n", it); return 3; }
+            bool same = q.cmd == plan.cmd && q.steps.size() == plan.steps.size() && q.lit_chunks == plan.lit_chunks && q.n == plan.n && q.window == plan.window
+                        && std::memcmp(&q.cfg, &plan.cfg, sizeof(plan.cfg)) == 0;
+            for (size_t k = 0; same && k < q.steps.size(); ++k) same = q.steps[k].kind == plan.steps[k].kind && q.steps[k].value == plan.steps[k].value;
+            if (!same) { std::fprintf(stderr, "iteration %ld: the prefix changes the plan\n", it); return 3; }
+        }
         orc_lit_config cfg; std::memcpy(&cfg, &plan.cfg, sizeof(cfg));
         orc_lit_state* st = orc_lit_state_new(&cfg);
         orc_ans_encoder enc; orc_ans_encoder_init(&enc);
