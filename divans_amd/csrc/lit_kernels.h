@@ -77,7 +77,7 @@ constexpr uint32_t LIT_STATUS_BAD_STREAM = 2u;    // decode: a chunk did not end
 struct RansBatch {
     const uint32_t* sf; uint32_t n_streams, stream_len, max_stream_len; const uint32_t* in_sizes;
     uint32_t sf_stride;         // u32 elements per stream in sf (a multiple of 4): 2 * max_stream_len, or the work-array slot when the
-                                // model pass left the pairs in place (BucketBatch::sfs / MixBucketBatch::pos[0])
+                                // model pass left the pairs in place (BucketBatch::sfs / MixBucketBatch::xs[0])
     uint64_t out_base;          // added to the offsets written to out_offsets: `out` points at the first slot of a sub-batch
     uint8_t* out; uint64_t out_slot; uint64_t* out_offsets; uint32_t* out_sizes; uint32_t* status;
     uint32_t* chunk_bytes; uint32_t max_chunks;   // optional [n_streams][max_chunks] coded size of every 65 536-symbol chunk

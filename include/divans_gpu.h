@@ -214,7 +214,7 @@ int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t
  * compressor emits), or with a context map and dynamic mixing for one literal block type (divans_lit_config_context_mixing).  There it is what
  * "automatic" picks; asking for it elsewhere is DIVANS_GPU_EINVAL.  Both produce the same bytes. */
 int divans_gpu_codec_set_encode_path(divans_gpu_codec *c, uint32_t path);
-/* Streams the bucketed two-model pass takes per launch sequence (default 32768, halved until its work arrays -- 3.4 MB
+/* Streams the bucketed two-model pass takes per launch sequence (default 32768, halved until its work arrays -- 1.9 MB
  * per 64 KiB stream -- fit the device).  A tuning / test knob: the coded bytes do not depend on it. */
 int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
 
