@@ -17,6 +17,9 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace divans_host {
 
@@ -62,13 +65,32 @@ static const Speed kMud{0x10, 0x2000}, kSlow{0x20, 0x1000}, kMed{0x30, 0x4000}, 
 
 static inline int16_t wrap16(int v) { return (int16_t)(uint16_t)v; }
 
-struct Cdf {
+#if defined(__SSE2__)
+// lanes >= sym of a 16 x i16 row: sixteen zero words, then sixteen all-ones words, read 16 - sym words in
+alignas(16) static const int16_t kFromSym[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+alignas(16) static const int16_t kBias[16] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+#endif
+
+struct alignas(16) Cdf {
     int16_t c[16];
     Cdf() { for (int i = 0; i < 16; ++i) c[i] = (int16_t)(4 * (i + 1)); }        // frequentist_cdf.rs:17-23
     void blend(int sym, Speed s) {                                               // frequentist_cdf.rs:74-85
+#if defined(__SSE2__)
+        // the same wrapping i16 arithmetic, eight entries at a time (the SIMD twin of the reference does the same, simd_frequentist_cdf.rs:213-224)
+        const __m128i inc = _mm_set1_epi16(s.inc);
+        __m128i lo = _mm_load_si128((const __m128i*)c), hi = _mm_load_si128((const __m128i*)(c + 8));
+        lo = _mm_add_epi16(lo, _mm_and_si128(inc, _mm_loadu_si128((const __m128i*)(kFromSym + 16 - sym))));
+        hi = _mm_add_epi16(hi, _mm_and_si128(inc, _mm_loadu_si128((const __m128i*)(kFromSym + 24 - sym))));
+        if ((int16_t)_mm_extract_epi16(hi, 7) >= s.lim) {
+            lo = _mm_add_epi16(lo, _mm_load_si128((const __m128i*)kBias)); hi = _mm_add_epi16(hi, _mm_load_si128((const __m128i*)(kBias + 8)));
+            lo = _mm_sub_epi16(lo, _mm_srai_epi16(lo, 2)); hi = _mm_sub_epi16(hi, _mm_srai_epi16(hi, 2));
+        }
+        _mm_store_si128((__m128i*)c, lo); _mm_store_si128((__m128i*)(c + 8), hi);
+#else
         for (int i = sym; i < 16; ++i) c[i] = wrap16(c[i] + s.inc);
         if (c[15] >= s.lim)
             for (int i = 0; i < 16; ++i) { int16_t t = wrap16(c[i] + i + 1); c[i] = wrap16(t - (t >> 2)); }
+#endif
     }
     bool range(int sym, int& start, int& freq) const {                           // probability/interface.rs:97-108
         const int mx = c[15];
@@ -81,8 +103,15 @@ struct Cdf {
     }
     int find(int offset) const {                                                 // probability/interface.rs:136-198
         const int16_t r = wrap16(((int)(int16_t)offset * (int)c[15]) >> 15);
+#if defined(__SSE2__)
+        const __m128i rr = _mm_set1_epi16(r);
+        const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpgt_epi16(_mm_load_si128((const __m128i*)c), rr))
+                         | (unsigned)_mm_movemask_epi8(_mm_cmpgt_epi16(_mm_load_si128((const __m128i*)(c + 8)), rr)) << 16;
+        return m ? __builtin_ctz(m) >> 1 : 15;     // the first entry above r; entry 15 and "none" both mean symbol 15
+#else
         for (int i = 0; i < 15; ++i) if (r < c[i]) return i;
         return 15;
+#endif
     }
 };
 
