@@ -7,6 +7,9 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "c", "_build")
+# HOSTSIM_CXX / HOSTSIM_CC select the compilers (default g++ / gcc; /opt/rocm/lib/llvm/bin/clang++ is the host compiler hipcc uses for the product)
+CXX = os.environ.get("HOSTSIM_CXX", "g++")
+CC = os.environ.get("HOSTSIM_CC", "gcc")
 
 CXX_SOURCES = ["divans_amd/csrc/host_stream.cpp", "divans_amd/csrc/ffi.cpp", "divans_amd/csrc/ir.cpp", "tests/c/hostsim_device_stub.cpp"]
 C_SOURCES = ["oracle/cdf.c", "oracle/ans.c", "oracle/literal.c", "oracle/crc32c.c", "oracle/stream.c"]
@@ -28,7 +31,7 @@ def _objects(tag, flags):
         path = os.path.join(ROOT, src)
         obj = os.path.join(OUT, tag + "_" + os.path.basename(src) + ".o")
         if _newer(obj, [path]):
-            cc = ["g++", "-std=c++17"] if src.endswith(".cpp") else ["gcc", "-std=c11"]
+            cc = [CXX, "-std=c++17"] if src.endswith(".cpp") else [CC, "-std=c11"]
             subprocess.run(cc + flags + ["-fPIC", "-c", path, "-o", obj, "-I" + os.path.join(ROOT, "include")], check=True)
         objs.append(obj)
     return objs
@@ -39,7 +42,7 @@ def build_library():
     lib = os.path.join(OUT, "libdivans_hostsim.so")
     objs = _objects("so", ["-O2", "-g", "-msse4.2"])
     if _newer(lib, objs):
-        subprocess.run(["g++", "-shared", "-Wl,-Bsymbolic", "-o", lib] + objs + ["-lpthread"], check=True)   # its own divans_* symbols, whatever else the process has loaded
+        subprocess.run([CXX, "-shared", "-Wl,-Bsymbolic", "-o", lib] + objs + ["-lpthread"], check=True)   # its own divans_* symbols, whatever else the process has loaded
     return lib
 
 
@@ -50,7 +53,7 @@ def build_fuzzer():
     objs = _objects("san", san)
     driver = os.path.join(ROOT, "tests", "c", "hostsim_fuzz.cpp")
     if _newer(exe, objs + [driver]):
-        subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
+        subprocess.run([CXX, "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
     return exe
 
 
@@ -62,9 +65,9 @@ def build_program(name, source, lang="c++", sanitize_main=True):
     objs = _objects("san", san + ["-msse4.2"])
     if _newer(exe, objs + [source]):
         obj = os.path.join(OUT, name + ".main.o")
-        cc = ["g++", "-std=c++14"] if lang == "c++" else ["gcc", "-Wno-unused-result"]
+        cc = [CXX, "-std=c++14"] if lang == "c++" else [CC, "-Wno-unused-result"]
         subprocess.run(cc + (san if sanitize_main else ["-O1", "-g"]) + ["-c", source, "-o", obj, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(source)], check=True)
-        subprocess.run(["g++"] + san + ["-o", exe, obj] + objs + ["-lpthread"], check=True)
+        subprocess.run([CXX] + san + ["-o", exe, obj] + objs + ["-lpthread"], check=True)
     return exe
 
 
@@ -75,7 +78,7 @@ def build_thread_test():
     objs = _objects("tsan", san)
     driver = os.path.join(ROOT, "tests", "c", "hostsim_threads.cpp")
     if _newer(exe, objs + [driver]):
-        subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
+        subprocess.run([CXX, "-std=c++17"] + san + ["-o", exe, driver] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
     return exe
 
 
@@ -93,8 +96,8 @@ def build_batch_test(sanitizer="address,undefined"):
     fake = os.path.join(ROOT, "tests", "c", "fakehip")
     batch_obj = os.path.join(OUT, tag + "_batch.cpp.o")
     if _newer(batch_obj, [batch_src, os.path.join(fake, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "divans_batch.h")]):
-        subprocess.run(["g++", "-std=c++17"] + san + ["-fPIC", "-c", batch_src, "-o", batch_obj, "-I" + fake, "-I" + os.path.join(ROOT, "include")], check=True)
+        subprocess.run([CXX, "-std=c++17"] + san + ["-fPIC", "-c", batch_src, "-o", batch_obj, "-I" + fake, "-I" + os.path.join(ROOT, "include")], check=True)
     driver = os.path.join(ROOT, "tests", "c", "hostsim_batch.cpp")
     if _newer(exe, objs + [batch_obj, driver]):
-        subprocess.run(["g++", "-std=c++17"] + san + ["-o", exe, driver, batch_obj] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
+        subprocess.run([CXX, "-std=c++17"] + san + ["-o", exe, driver, batch_obj] + objs + ["-I" + os.path.join(ROOT, "include"), "-lpthread"], check=True)
     return exe
