@@ -66,6 +66,16 @@ class BatchOptions(ctypes.Structure):
                 ("device", ctypes.c_int32), ("host_threads", ctypes.c_int32), ("skip_crc", ctypes.c_uint8)]
 
 
+class ContainerProbe(ctypes.Structure):
+    """divans_container_probe (include/divans_batch.h)."""
+    _fields_ = [("status", ctypes.c_int32), ("window", ctypes.c_uint8), ("crc_ok", ctypes.c_uint8), ("have_prediction_mode", ctypes.c_uint8),
+                ("stopped_at_command", ctypes.c_uint8), ("cmd_bytes", ctypes.c_uint32), ("lit_bytes", ctypes.c_uint32), ("commands", ctypes.c_uint32),
+                ("cmd_nibbles", ctypes.c_uint32), ("first_literal_length", ctypes.c_uint32), ("literal_bytes", ctypes.c_uint64), ("cfg", LitConfig)]
+
+
+WIRE_HEAD, WIRE_WASM_EXAMPLE = 0, 1
+
+
 class BatchTiming(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_double), ("gpu_ms", ctypes.c_double), ("host_overlapped_ms", ctypes.c_double), ("host_serial_ms", ctypes.c_double)]
 
@@ -151,6 +161,7 @@ def load_library():
     L.divans_batch_compress_bound.argtypes = [sz]; L.divans_batch_compress_bound.restype = sz
     L.divans_batch_compress.argtypes = [ctypes.POINTER(BatchOptions), vp, vp, sz, vp, sz, vp, vp, ctypes.POINTER(BatchTiming)]
     L.divans_batch_decompress.argtypes = [ctypes.POINTER(BatchOptions), vp, vp, sz, vp, sz, vp, vp, ctypes.POINTER(BatchTiming)]
+    L.divans_probe_container.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(ContainerProbe)]
     L.divans_ir_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]
     L.divans_ir_free.argtypes = [vp]
     L.divans_ir_free.restype = None
@@ -186,7 +197,8 @@ def exported_symbols():
 
 def exported_batch_symbols():
     """Entry points include/divans_batch.h declares."""
-    return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress", "divans_batch_release"]
+    return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress", "divans_batch_release",
+            "divans_probe_container"]
 
 
 def exported_ir_symbols():
@@ -609,6 +621,14 @@ def _batch_call(fn, what, options, items, cap):
     _check(fn(ctypes.byref(options), ptrs, sizes, n, out.ctypes.data, cap, offs, osz, ctypes.byref(t)), what)
     res = [out[offs[i]:offs[i] + osz[i]].copy() for i in range(n)]
     return res, dict(total_ms=t.total_ms, gpu_ms=t.gpu_ms, host_overlapped_ms=t.host_overlapped_ms, host_serial_ms=t.host_serial_ms)
+
+
+def probe_container(container, wire=WIRE_HEAD):
+    """divans_probe_container (include/divans_batch.h): host-only report on one container -> ContainerProbe."""
+    c = np.ascontiguousarray(container, dtype=np.uint8)
+    pr = ContainerProbe()
+    _check(load_library().divans_probe_container(c.ctypes.data, c.size, wire, ctypes.byref(pr)), "divans_probe_container")
+    return pr
 
 
 def batch_compress(inputs, options=None):

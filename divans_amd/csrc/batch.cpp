@@ -599,4 +599,17 @@ void divans_batch_release(void) {
     pool().device = -1;
 }
 
+// Host-only report on one container (divans_batch.h).
+int divans_probe_container(const uint8_t* in, size_t n, int wire, divans_container_probe* out) {
+    if (!out || (!in && n) || (wire != DIVANS_WIRE_HEAD && wire != DIVANS_WIRE_WASM_EXAMPLE)) return DIVANS_GPU_EINVAL;
+    divans_host::divans_container_probe_fields f;
+    divans_host::probe_container_host(in, n, wire, f);
+    std::memset(out, 0, sizeof(*out));
+    out->status = f.status; out->window = f.window; out->crc_ok = f.crc_ok; out->have_prediction_mode = f.have_pm;
+    out->stopped_at_command = f.stopped_at; out->cmd_bytes = f.cmd_bytes; out->lit_bytes = f.lit_bytes; out->commands = f.commands;
+    out->cmd_nibbles = f.cmd_nibbles; out->first_literal_length = f.first_literal_length; out->literal_bytes = f.literal_bytes;
+    out->cfg = f.cfg;
+    return 0;
+}
+
 }  // extern "C"

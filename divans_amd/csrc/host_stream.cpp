@@ -189,7 +189,9 @@ class RansDecoder {
 struct NibbleCoder {
     RansEncoder* enc = nullptr; RansDecoder* dec = nullptr;
     std::function<void()> before;   // drain_or_fill_internal_buffer_cmd runs before every CMD nibble (e.g. codec/mod.rs:663)
+    uint32_t nibbles = 0;
     int code(int v, Cdf& prior, Speed sp) {
+        ++nibbles;
         if (before) before();
         if (enc) { int s, f; if (!prior.range(v, s, f)) enc->failed = true; else enc->put(s, f); }
         else v = dec->get(prior);
@@ -224,7 +226,7 @@ class CommandModel {
         mixing = o.dynamic_context_mixing;
         if (o.force_stride != 0 && mixing == 0 && o.use_context_map) mixing = 1;   // codec/interface.rs:360-365
         prior_depth = o.has_prior_depth ? o.prior_depth : 0;
-        do_context_map = o.use_context_map; force_stride = o.force_stride;
+        do_context_map = o.use_context_map; force_stride = o.force_stride; wire = o.wire;
         has_adaptation = o.has_literal_adaptation;
         for (int i = 0; i < 4; ++i) adaptation[i] = Speed{o.literal_adaptation[i].inc, o.literal_adaptation[i].lim};
         pm_cmap.assign(DIVANS_GPU_MAX_LITERAL_CONTEXT_MAP_SIZE, 0);
@@ -241,6 +243,7 @@ class CommandModel {
     std::array<uint8_t, 3> btype_max{};
     uint8_t last_4_states = 0;
     uint8_t mixing = 0, prior_depth = 0, force_stride = 9;
+    int wire = 0;                           // DIVANS_WIRE_*: 1 = the build behind wasm/wasm.html's example (two prior rows differ, below)
     bool do_context_map = true, has_adaptation = false;
     Speed adaptation[4];
     std::vector<uint8_t> pm_cmap, pm_mixing, pm_dmap;     // the codec's own PredictionModeContextMap (persists, context_map.rs:84-94)
@@ -300,7 +303,9 @@ class CommandModel {
                     for (int i = 0; i < 13; ++i) if (lru[i] == target) mn = i;
                     if (target == (uint8_t)(*std::max_element(lru.begin(), lru.end()) + 1)) mn = 13;
                 }
-                mn = nc.code(mn, pred[6 + type], kMed);
+                // HEAD: Mnemonic is a member of PredictionModePriors (offset 6 + type).  The example's build coded the mnemonics of both
+                // maps under row 27 -- its two mnemonic nibbles read "end of map" there and nowhere else
+                mn = nc.code(mn, pred[wire == 1 ? 27 : 6 + type], kMed);
                 if (mn == 14) { if (type == 0) for (int i = 0; i < 13; ++i) lru[i] = (uint8_t)i; break; }
                 uint8_t val;
                 if (mn == 15) {
@@ -317,7 +322,7 @@ class CommandModel {
         }
         for (uint32_t index = 0; index < DIVANS_GPU_NUM_MIXING_VALUES; ++index) {
             int nib = !do_context_map ? 4 : (!combine ? 0 : ((in && in->has_context_speeds && !in->mixing_values.empty()) ? in->mixing_values[index] : 0));
-            const int prior = index >= 256 ? (pm_mixing[index - 256] & 0xf) : 16;
+            const int prior = (index >= 256 && wire != 1) ? (pm_mixing[index - 256] & 0xf) : 16;   // the example's build: row 16 throughout
             nib = nc.code(nib, pred[10 + prior], kPlane);
             pm_mixing[index] = (uint8_t)nib;
         }
@@ -1080,6 +1085,51 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
         }
     }
     return finish(total);
+}
+
+void probe_container_host(const uint8_t* in, size_t n, int wire, divans_container_probe_fields& pr) {
+    pr = divans_container_probe_fields();
+    std::memset(&pr.cfg, 0, sizeof(pr.cfg));
+    for (auto& s : pr.cfg.literal_adaptation) s = divans_speed{0x10, 0x2000};
+    if (n < 16) { pr.status = 1; return; }
+    if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f || in[5] < 10 || in[5] >= 25) { pr.status = 2; return; }
+    pr.window = in[5];
+    Mux mux;
+    const size_t used = mux.deserialize(in + 16, n - 16);
+    pr.cmd_bytes = (uint32_t)mux.s[0].avail(); pr.lit_bytes = (uint32_t)mux.s[1].avail();
+    if (mux.eof != 3) { pr.status = (16 + used < n) ? 2 : 1; return; }
+    if (n - 16 - used < 8) { pr.status = 1; return; }
+    const uint8_t* tr = in + 16 + used;
+    const uint32_t crc = crc32c(0, in, 16 + used);
+    const uint8_t want[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
+    if (std::memcmp(tr + 4, want + 4, 4) != 0) { pr.status = 2; return; }
+    pr.crc_ok = std::memcmp(tr, want, 4) == 0;
+    StreamOptions o; o.wire = wire;
+    CommandModel model(o);
+    RansDecoder cd(mux.s[0].buf.data() + mux.s[0].start, mux.s[0].avail());
+    NibbleCoder nc; nc.dec = &cd;
+    uint8_t btype = 0;
+    pr.status = 0;
+    for (;;) {
+        const int code = model.command_type(nc, 0);
+        if (cd.starved) { pr.status = 2; break; }
+        if (code == 0xf) break;
+        if (code == 7 && !pr.literal_bytes && !pr.have_pm) {
+            if (!model.prediction_mode(nc, nullptr) || cd.starved) { pr.status = 2; break; }
+            pr.have_pm = 1;
+        } else if (code == 4 && !pr.literal_bytes) {
+            model.block_switch_literal(nc, 0, 0, btype);
+        } else if (code == 3) {
+            uint32_t len;
+            if (!model.literal_length(nc, 15, len) || cd.starved) { pr.status = 2; break; }
+            if (!pr.literal_bytes) pr.first_literal_length = len;
+            pr.literal_bytes += len;
+        } else { pr.status = 3; pr.stopped_at = (uint8_t)code; break; }
+        if (cd.starved) { pr.status = 2; break; }
+        pr.commands += 1;
+    }
+    pr.cmd_nibbles = nc.nibbles;
+    if (pr.have_pm) model.fill_lit_config(pr.cfg, btype); else pr.cfg.btype = btype;
 }
 
 // ---------------------------------------------------------------- the decompressor, one call at a time

@@ -21,6 +21,7 @@ struct StreamOptions {            // DivansCompressorOptions, src/interface.rs:4
     uint8_t force_stride = 9;     // StrideSelection: 0..8, 9 = UseBrotliRec
     bool has_literal_adaptation = false; divans_speed literal_adaptation[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int use_brotli = 1;           // BrotliCompressionSetting (only 0 = internal command selection is implemented)
+    int wire = 0;                 // DIVANS_WIRE_* (divans_batch.h): which build's PredictionMode prior rows the CMD model uses; the coders use HEAD
 };
 
 struct PredictionModeIn {                 // the PredictionMode command as the encoder receives it (raw_to_cmd/mod.rs:115-143, bin/divans.rs:199-316)
@@ -107,6 +108,14 @@ class ParseMemo {
 // The host half of parse_container: framing + CRC + CMD coder; `ps` gets the LIT-coder bytes, the decoded size and the LIT configuration.
 ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed,
                                  ParseMemo* memo = nullptr);
+
+// divans_probe_container (divans_batch.h): the same walk, reporting instead of refusing
+struct divans_container_probe_fields {
+    int status = 2; uint8_t window = 0, crc_ok = 0, have_pm = 0, stopped_at = 0;
+    uint32_t cmd_bytes = 0, lit_bytes = 0, commands = 0, cmd_nibbles = 0, first_literal_length = 0; uint64_t literal_bytes = 0;
+    divans_lit_config cfg;
+};
+void probe_container_host(const uint8_t* in, size_t n, int wire, divans_container_probe_fields& pr);
 
 uint32_t crc32c(uint32_t crc, const uint8_t* p, size_t n);   // src/codec/crc32.rs (SSE4.2 crc32 where the CPU has it)
 uint32_t crc32c_portable(uint32_t crc, const uint8_t* p, size_t n);   // the table walk, always

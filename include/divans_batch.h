@@ -73,6 +73,28 @@ int divans_batch_decompress(const divans_batch_options *opt, const uint8_t *cons
  * This returns everything; the next call builds the lanes again. */
 void divans_batch_release(void);
 
+/* Why does (or does not) this library take a container?  Host only, no GPU work: header, Mux framing, end marker, CRC-32C
+ * trailer (src/codec/mod.rs:518-554), then the CMD coder's commands (src/codec/mod.rs:652-792) as far as this library decodes them.
+ * `wire`: DIVANS_WIRE_HEAD = the reference tree as it stands; DIVANS_WIRE_WASM_EXAMPLE = the older build that wrote the one
+ * compressed vector the tree holds (wasm/wasm.html:98-107), which coded the context-map mnemonics and the mixing values of the
+ * PredictionMode command under other prior-table rows -- the probe reads both, the decoders read HEAD. */
+enum { DIVANS_WIRE_HEAD = 0, DIVANS_WIRE_WASM_EXAMPLE = 1 };
+typedef struct divans_container_probe {
+    int32_t status;               /* 0 walked to the end marker (a stream divans_decode takes); 1 input ends early; 2 damaged (framing, trailer,
+                                     CRC or CMD coder); 3 stopped at a command outside the literal-only scope (stopped_at_command) */
+    uint8_t window;               /* header byte 5 */
+    uint8_t crc_ok;               /* CRC-32C of header + body == the trailer's */
+    uint8_t have_prediction_mode;
+    uint8_t stopped_at_command;   /* the command nibble at which status 3 stopped: 1 Copy, 2 Dict, 5 / 6 command / distance block switch, 7 a second PredictionMode */
+    uint32_t cmd_bytes, lit_bytes;/* the two demultiplexed coder streams */
+    uint32_t commands;            /* commands decoded before the stop, the end marker not counted */
+    uint32_t cmd_nibbles;         /* CMD-coder symbols decoded, the stopping command nibble included */
+    uint32_t first_literal_length;
+    uint64_t literal_bytes;       /* sum of the Literal lengths decoded */
+    divans_lit_config cfg;        /* what the LIT coder runs under after the commands read (divans_gpu.h) */
+} divans_container_probe;
+int divans_probe_container(const uint8_t *in, size_t n, int wire, divans_container_probe *out);
+
 #ifdef __cplusplus
 }
 #endif

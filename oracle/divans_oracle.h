@@ -6,10 +6,18 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; the shipped GPU path (divans_amd/csrc) never links it.
  *
- * PARITY STATUS: "compressed bytes unpinned".  The reference is 100% Rust and
- * cannot be built in this environment (no rustc/cargo, crates not vendored),
- * and its own tests hold no golden .divans file or ANS byte vector.  What IS
- * pinned against the reference's own tests (see tests/test_oracle_*.py):
+ * PARITY STATUS: pinned on the one compressed vector the reference tree holds
+ * (wasm/wasm.html:98-107, 113 bytes from a real Rust build; tests/golden/
+ * ref_wasm_example.divans, tests/test_reference_vectors.py): header, Mux
+ * framing, end marker, CRC-32C trailer, all 8253 nibbles of its CMD stream
+ * (final rANS states = the encoder's start states, every byte consumed) and all
+ * 28 literal bytes of its LIT stream decode with this code, and re-encoding the
+ * decoded literals gives the example's 36 LIT bytes back.  That build's wire
+ * format is older than HEAD in two prior-table rows of the PredictionMode
+ * command (ORC_WIRE_WASM_EXAMPLE), so bytes of a HEAD build remain unpinned for
+ * those rows, for context maps / mixing, and for streams past one rANS chunk:
+ * the reference is 100% Rust and cannot be built here (no rustc/cargo, crates
+ * not vendored).  Also pinned against the reference's own tests (tests/test_oracle_*.py):
  *   - CDF identities            src/probability/common_tests.rs:3-126
  *   - exact division            src/probability/numeric.rs:73-85, make_div_lut.rs
  *   - Speed f8 codec            src/probability/interface.rs:590-616
@@ -205,6 +213,29 @@ size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, s
 int orc_stream_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len);
 int orc_lit_config_from_prediction_mode(const orc_stream_options *o, const orc_prediction_mode *pm, uint8_t btype, orc_lit_config *cfg);
 int orc_mux_demux(const uint8_t *in, size_t n, uint8_t *s0, size_t *n0, uint8_t *s1, size_t *n1, size_t *consumed);
+
+/* ---- walking a CMD-coder stream the REFERENCE wrote (the pin on wasm/wasm.html:98-107, tests/test_reference_vectors.py) ----
+ * Decodes every command of a CMD stream -- PredictionMode, the three block switches, Literal lengths, Copy (codec/copy.rs),
+ * Dict (codec/dict.rs: nibbles only, no dictionary), end marker -- with the oracle's own CDF / rANS / prior-table code and
+ * reports what it saw.  rANS is an exact inverse, so a walk that used the right model for EVERY nibble ends with both decoder
+ * states at the encoder's start state 2^31 and all bytes consumed; a single wrong (start, freq) anywhere cannot.
+ * `wire`: ORC_WIRE_HEAD = /root/reference as it stands; ORC_WIRE_WASM_EXAMPLE = the older build that wrote the example, which
+ * differs in two prior-table rows of the PredictionMode command (stream.c code_prediction_mode). */
+enum { ORC_WIRE_HEAD = 0, ORC_WIRE_WASM_EXAMPLE = 1 };
+typedef struct { uint8_t kind; uint8_t a, b; uint32_t x, y; } orc_walk_command; /* kind = command nibble (15 = end);
+    Literal: x = length.  Copy: x = distance, y = length.  Dict: a = word size, b = transform, x = word id.
+    Block switch: a = block type, b = stride (literal switch only). */
+typedef struct {
+    orc_walk_command cmds[64]; uint32_t n_cmds;
+    uint32_t nibbles;                 /* symbols decoded */
+    uint64_t state_a, state_b;        /* decoder states after the last symbol */
+    size_t consumed;                  /* bytes of the stream the decoder took */
+    int starved;
+    orc_prediction_mode_result pm;    /* of the last PredictionMode command (pointers into the walk's own storage: copied below) */
+    uint8_t literal_context_map_nonzero, mixing_value_min, mixing_value_max;
+} orc_cmd_walk;
+/* returns 0 when the walk reached the end marker, <0 where it stopped (-10 unknown command nibble, -11 more than 64 commands, -5 starved) */
+int orc_cmd_stream_walk(const uint8_t *cmd, size_t n, int wire, orc_cmd_walk *w);
 
 /* ---- CRC-32C, src/codec/crc32.rs ---- */
 uint32_t orc_crc32c_update(uint32_t crc, const uint8_t *buf, size_t len);

@@ -49,6 +49,25 @@ class StreamCommand(ctypes.Structure):
                 ("data", ctypes.c_void_p), ("len", ctypes.c_size_t)]
 
 
+class PredictionModeResult(ctypes.Structure):
+    _fields_ = [("prediction_mode", ctypes.c_uint8), ("mixing_math", ctypes.c_uint8), ("literal_adaptation", Speed * 4),
+                ("literal_context_map", ctypes.c_void_p), ("mixing_values", ctypes.c_void_p)]
+
+
+class WalkCommand(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint8), ("a", ctypes.c_uint8), ("b", ctypes.c_uint8), ("x", ctypes.c_uint32), ("y", ctypes.c_uint32)]
+
+
+class CmdWalk(ctypes.Structure):
+    _fields_ = [("cmds", WalkCommand * 64), ("n_cmds", ctypes.c_uint32), ("nibbles", ctypes.c_uint32),
+                ("state_a", ctypes.c_uint64), ("state_b", ctypes.c_uint64), ("consumed", ctypes.c_size_t), ("starved", ctypes.c_int),
+                ("pm", PredictionModeResult), ("literal_context_map_nonzero", ctypes.c_uint8),
+                ("mixing_value_min", ctypes.c_uint8), ("mixing_value_max", ctypes.c_uint8)]
+
+
+WIRE_HEAD, WIRE_WASM_EXAMPLE = 0, 1
+
+
 class Cdf16(ctypes.Structure):
     _fields_ = [("cdf", ctypes.c_int16 * 16)]
 
@@ -143,6 +162,8 @@ def lib(native=False):
     L.orc_mux_demux.restype = ctypes.c_int
     L.orc_mux_demux.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t),
                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    L.orc_cmd_stream_walk.restype = ctypes.c_int
+    L.orc_cmd_stream_walk.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(CmdWalk)]
     if not native:
         _LIB = L
     return L
@@ -247,6 +268,24 @@ def stream_decompress(coded, max_out):
     if rc != 0:
         raise RuntimeError(f"oracle stream decompress failed rc={rc}")
     return out[:n.value].copy()
+
+
+def mux_demux(body):
+    """(CMD stream, LIT stream, bytes of `body` up to and including the ff fe ff end marker) of a container body (after the 16-byte header)."""
+    body = np.ascontiguousarray(body, dtype=np.uint8)
+    s0 = np.empty(body.size + 1, np.uint8); s1 = np.empty(body.size + 1, np.uint8)
+    n0 = ctypes.c_size_t(s0.size); n1 = ctypes.c_size_t(s1.size); used = ctypes.c_size_t(0)
+    if lib().orc_mux_demux(body.ctypes.data, body.size, s0.ctypes.data, ctypes.byref(n0), s1.ctypes.data, ctypes.byref(n1), ctypes.byref(used)) != 0:
+        raise RuntimeError("oracle demux failed")
+    return s0[:n0.value].copy(), s1[:n1.value].copy(), used.value
+
+
+def cmd_stream_walk(cmd, wire=WIRE_HEAD):
+    """(rc, CmdWalk) of orc_cmd_stream_walk: every command of a CMD-coder stream, final rANS states, bytes consumed."""
+    cmd = np.ascontiguousarray(cmd, dtype=np.uint8)
+    w = CmdWalk()
+    rc = lib().orc_cmd_stream_walk(cmd.ctypes.data, cmd.size, wire, ctypes.byref(w))
+    return rc, w
 
 
 def lit_segments_encode(cfg, lit, seg_len, seg_btype, seg_last8):

@@ -260,6 +260,7 @@ typedef struct {
     uint8_t distance_context_map[4 * 256];
     uint8_t btype_lru[3][2], btype_max_seen[3];
     uint8_t last_4_states;
+    int wire;                          /* ORC_WIRE_HEAD / ORC_WIRE_WASM_EXAMPLE (divans_oracle.h) */
     /* options */
     uint8_t desired_prior_depth, desired_context_mixing, desired_force_stride;
     int desired_do_context_map, has_desired_adaptation;
@@ -306,10 +307,11 @@ static void cmd_state_init(cmd_state *c, const orc_stream_options *o) {
 }
 
 /* one "get_or_put_nibble + blend" on the CMD coder */
-typedef struct { orc_ans_encoder *enc; orc_ans_decoder *dec; } cmd_coder;
+typedef struct { orc_ans_encoder *enc; orc_ans_decoder *dec; uint32_t nibbles; } cmd_coder;
 static uint8_t cmd_nibble(cmd_coder *cc, uint8_t nib, orc_cdf16 *prior, orc_speed sp) {
     if (cc->enc) orc_ans_put_nibble(cc->enc, nib, prior, NULL);
     else nib = orc_ans_get_nibble(cc->dec, prior, NULL);
+    ++cc->nibbles;
     orc_cdf_blend(prior, nib, sp);
     return nib;
 }
@@ -407,7 +409,11 @@ static int code_prediction_mode(cmd_state *c, cmd_coder *cc, void (*drain)(void 
                 for (int i = 0; i < CONTEXT_MAP_CACHE_SIZE; ++i) if (c->cmap_lru[i] == target) mn = (uint8_t)i;
                 if (target == lru_max_plus_one(c)) mn = 13;
             }
-            mn = cmd_nibble(cc, mn, &c->prediction_priors[PM_MNEMONIC(type)], SP_MED);
+            /* HEAD lists Mnemonic in PredictionModePriors (codec/priors.rs:125-133) -> offset 6 + type.  The build that wrote
+             * wasm/wasm.html's example coded the mnemonics of BOTH maps under row 27, the row DynamicContextMixingSpeed / PriorDepth
+             * alias (priors.rs:226-237): its two mnemonic nibbles decode to "end of map" only there (slot 32507 is symbol 14 with
+             * freq 220 under that row, symbol 15 under a fresh one), and only then do 8192 mixing values of 4 follow. */
+            mn = cmd_nibble(cc, mn, &c->prediction_priors[c->wire == ORC_WIRE_WASM_EXAMPLE ? PM_ALIAS_LAST : PM_MNEMONIC(type)], SP_MED);
             if (mn == 14) {
                 if (type == 0) for (int i = 0; i < CONTEXT_MAP_CACHE_SIZE; ++i) c->cmap_lru[i] = (uint8_t)i; /* :303-306 */
                 break;
@@ -435,6 +441,8 @@ static int code_prediction_mode(cmd_state *c, cmd_coder *cc, void (*drain)(void 
         drain(drain_ctx);
         uint8_t nib = !c->desired_do_context_map ? 4 : (!combine ? 0 : ((pm && pm->has_context_speeds && pm->mixing_values) ? pm->mixing_values[index] : 0));
         uint32_t prior = index >= 256 ? (uint32_t)(c->pm_mixing[index - 256] & 0xf) : 16; /* the codec's own pm always has_context_speeds */
+        if (c->wire == ORC_WIRE_WASM_EXAMPLE) prior = 16; /* that build coded all 8192 values under PriorMixingValue[16]: with :396-400's row
+                                                             `value 256 places back` the example's nibble 256 would be 6, with [16] it is 4 x 8192 */
         nib = cmd_nibble(cc, nib, &c->prediction_priors[PM_MIXING(prior)], SP_PLANE);
         c->pm_mixing[index] = nib;
     }
@@ -584,7 +592,7 @@ static size_t stream_compress_impl(const orc_stream_options *o, const orc_stream
     e.out.call_buf = o->call_buffer_size ? o->call_buffer_size : 65536;
     cmd_state *c = (cmd_state *)malloc(sizeof(cmd_state));
     cmd_state_init(c, o);
-    cmd_coder cc = {&e.cmd, NULL};
+    cmd_coder cc = {&e.cmd, NULL, 0};
     orc_lit_config *cfg = (orc_lit_config *)calloc(1, sizeof(orc_lit_config));
     /* LiteralBookKeeping::new, codec/interface.rs:244-262 (+ reset on construction = zeroed map) */
     for (int i = 0; i < 4; ++i) cfg->literal_adaptation[i] = SP_MUD;
@@ -764,7 +772,7 @@ int orc_lit_config_from_prediction_mode(const orc_stream_options *o, const orc_p
     cmd_state_init(c, o);
     orc_ans_encoder enc;
     orc_ans_encoder_init(&enc);
-    cmd_coder cc = {&enc, NULL};
+    cmd_coder cc = {&enc, NULL, 0};
     code_command_type(c, &cc, no_drain, NULL, 7);
     orc_prediction_mode_result r;
     int rc = code_prediction_mode(c, &cc, no_drain, NULL, pm, &r);
@@ -792,7 +800,7 @@ int orc_stream_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
     orc_ans_decoder cd, ld;
     orc_ans_decoder_init(&cd, m.s[0].buf ? m.s[0].buf + m.s[0].start : (const uint8_t *)"", m.s[0].end - m.s[0].start);
     orc_ans_decoder_init(&ld, m.s[1].buf ? m.s[1].buf + m.s[1].start : (const uint8_t *)"", m.s[1].end - m.s[1].start);
-    cmd_coder cc = {NULL, &cd};
+    cmd_coder cc = {NULL, &cd, 0};
     orc_lit_config *cfg = (orc_lit_config *)calloc(1, sizeof(orc_lit_config));
     for (int i = 0; i < 4; ++i) cfg->literal_adaptation[i] = SP_MUD;
     orc_lit_state *ls = orc_lit_state_new(cfg);
@@ -822,5 +830,169 @@ int orc_stream_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
     }
     if (out_len) *out_len = produced;
     free(cfg); orc_lit_state_free(ls); free(c); mux_free(&m);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ walking a reference-written CMD stream (test pin) */
+/* prior tables the literal-only path never touches: CopyCommandPriors / DictCommandPriors, codec/priors.rs:73-99; rows are
+ * (ctype or distance prior) + 256 * index, types in the order the struct lists them (priors.rs:211-259) */
+enum { CP_DIST_BEG = 0, CP_DIST_MNEM = CP_DIST_BEG + 256 * 64, CP_DIST_LAST = CP_DIST_MNEM + 256 * 2, CP_DIST_MANT = CP_DIST_LAST + 256,
+       CP_COUNT_SMALL = CP_DIST_MANT + 256 * 5, CP_COUNT_BEG = CP_COUNT_SMALL + 256 * 64, CP_COUNT_LAST = CP_COUNT_BEG + 256 * 64,
+       CP_COUNT_MANT = CP_COUNT_LAST + 256 * 64, CP_TOTAL = CP_COUNT_MANT + 256 * 64 };
+enum { DC_SIZE_BEG = 0, DC_SIZE_LAST = 256, DC_INDEX = 512, DC_TRANSFORM = DC_INDEX + 256 * 5, DC_TOTAL = DC_TRANSFORM + 2 * 25 };
+typedef struct {
+    cmd_state c;
+    orc_cdf16 copy_priors[CP_TOTAL], dict_priors[DC_TOTAL];
+    uint32_t distance_lru[4], last_llen;     /* codec/interface.rs:153,161,371-373,396 */
+    uint8_t last_clen, last_dlen;
+} walk_state;
+
+static uint8_t bit_length32(uint32_t v) { return (uint8_t)(v ? 32 - __builtin_clz(v) : 0); }
+static uint32_t walk_distance_prior(const walk_state *s, uint32_t copy_len) {       /* get_distance_prior, codec/interface.rs:426-430 */
+    uint32_t l = copy_len < 2 ? 2 : copy_len;
+    return s->c.distance_context_map[(uint32_t)s->c.btype_lru[2][0] * 4 + (l - 2 < 3 ? l - 2 : 3)];
+}
+static void walk_obs_state(walk_state *s, uint8_t bits) { s->c.last_4_states = (uint8_t)((s->c.last_4_states >> 2) | bits); }
+
+/* CopyState::encode_or_decode as a decoder, codec/copy.rs:49-290 */
+static int walk_copy(walk_state *s, cmd_coder *cc, orc_walk_command *out) {
+    const uint32_t ctype = s->c.btype_lru[1][0];
+    uint32_t index = ((s->c.last_4_states >> 4) & 3) + 4 * (s->last_llen - 1 < 3 ? s->last_llen - 1 : 3);
+    uint32_t num_bytes;
+    uint8_t sc = cmd_nibble(cc, 0, &s->copy_priors[CP_COUNT_SMALL + ctype + 256 * index], SP_MUD);
+    if (sc == 15) {
+        uint8_t beg = cmd_nibble(cc, 0, &s->copy_priors[CP_COUNT_BEG + ctype], SP_FAST), rem; uint32_t dec;
+        if (beg == 15) {
+            uint8_t last = cmd_nibble(cc, 0, &s->copy_priors[CP_COUNT_LAST + ctype], SP_FAST);
+            s->last_clen = (uint8_t)(last + 19); rem = round_up_mod_4((uint8_t)(last + 18)); dec = (uint32_t)1 << (last + 18);
+        } else { s->last_clen = (uint8_t)(beg + 4); rem = round_up_mod_4((uint8_t)(beg + 3)); dec = (uint32_t)1 << (beg + 3); }
+        for (uint8_t done = 0;; done += 4) {
+            uint8_t next = (uint8_t)(rem - 4);
+            uint32_t mi = done == 0 ? (uint32_t)(s->last_clen % 4) + 1 : 0;
+            dec |= (uint32_t)cmd_nibble(cc, 0, &s->copy_priors[CP_COUNT_MANT + ctype + 256 * mi], SP_SLOW) << next;
+            if (!next) break;
+            rem = next;
+        }
+        num_bytes = dec;
+    } else { num_bytes = sc; s->last_clen = bit_length32(num_bytes); }
+    const uint32_t prior = walk_distance_prior(s, num_bytes);
+    uint32_t distance;
+    uint8_t mn = cmd_nibble(cc, 0, &s->copy_priors[CP_DIST_MNEM + prior + 256 * (s->last_llen < 8)], SP_SLOW);
+    if (mn != 15) {                                   /* get_distance_from_mnemonic_code, codec/interface.rs:979-1009 */
+        int32_t d;
+        if (mn < 4) d = (int32_t)s->distance_lru[mn];
+        else { int32_t us = mn >> 2, ss = us - (((-(int32_t)(mn & 1)) & us) << 1); d = (int32_t)s->distance_lru[(mn & 2) >> 1] + ss; }
+        if (d <= 0) return -12;
+        distance = (uint32_t)d; s->last_dlen = bit_length32(distance);
+    } else {
+        uint8_t beg = cmd_nibble(cc, 0, &s->copy_priors[CP_DIST_BEG + prior + 256 * (bit_length32(num_bytes) >> 2)], SP_SLOW);
+        if (beg == 15) { distance = s->distance_lru[1] - 3; s->last_dlen = bit_length32(distance); }
+        else {
+            uint8_t rem = 0; uint32_t dec = 1;
+            if (beg == 14) {
+                uint8_t last = cmd_nibble(cc, 0, &s->copy_priors[CP_DIST_LAST + prior], SP_ROCKET);
+                s->last_dlen = (uint8_t)(last + 15); rem = round_up_mod_4((uint8_t)(last + 14)); dec = (uint32_t)1 << (last + 14);
+            } else { s->last_dlen = (uint8_t)(beg + 1); if (beg) { rem = round_up_mod_4(beg); dec = (uint32_t)1 << beg; } }
+            uint8_t done = 0;
+            for (int sr2 = ((int)rem + 3) >> 2; sr2-- > 0; done += 4) {
+                uint32_t mi = done == 0 ? (uint32_t)(s->last_dlen & 3) + 1 : 0;
+                orc_speed sp = {(int16_t)(0x4 << ((mi & 6) << ((mi & 2) >> 1))), 0x4000};
+                dec |= (uint32_t)cmd_nibble(cc, 0, &s->copy_priors[CP_DIST_MANT + prior + 256 * mi], sp) << (sr2 << 2);
+            }
+            distance = dec;
+        }
+    }
+    uint32_t *l = s->distance_lru;                     /* obs_distance, codec/interface.rs:509-527 */
+    if (distance == l[1]) { l[1] = l[0]; l[0] = distance; }
+    else if (distance == l[2]) { l[2] = l[1]; l[1] = l[0]; l[0] = distance; }
+    else if (distance != l[0]) { l[3] = l[2]; l[2] = l[1]; l[1] = l[0]; l[0] = distance; }
+    out->x = distance; out->y = num_bytes;
+    return 0;
+}
+
+/* DictState::encode_or_decode as a decoder, codec/dict.rs:36-190 (nibbles only) */
+static int walk_dict(walk_state *s, cmd_coder *cc, orc_walk_command *out) {
+    static const uint8_t DICT_BITS[25] = {0, 0, 0, 0, 10, 10, 11, 11, 10, 10, 10, 10, 10, 9, 9, 8, 7, 7, 8, 7, 7, 6, 6, 5, 5};
+    const uint32_t ctype = s->c.btype_lru[1][0];
+    uint8_t ws = cmd_nibble(cc, 0, &s->dict_priors[DC_SIZE_BEG + ctype], SP_MUD);
+    ws = ws == 15 ? (uint8_t)(cmd_nibble(cc, 0, &s->dict_priors[DC_SIZE_LAST + ctype], SP_MUD) + 19) : (uint8_t)(ws + 4);
+    if (ws > 24) return -13;
+    uint8_t rem = round_up_mod_4(DICT_BITS[ws]); uint32_t id = 0;
+    for (uint8_t done = 0;; done += 4) {
+        uint8_t next = (uint8_t)(rem - 4);
+        uint32_t mi = done == 0 ? (uint32_t)(DICT_BITS[ws] % 4) + 1 : 0;
+        id |= (uint32_t)cmd_nibble(cc, 0, &s->dict_priors[DC_INDEX + walk_distance_prior(s, ws) + 256 * mi], SP_MUD) << next;
+        if (!next) break;
+        rem = next;
+    }
+    uint8_t hi = cmd_nibble(cc, 0, &s->dict_priors[DC_TRANSFORM + 0 + 2 * (ws >> 1)], SP_FAST);
+    uint8_t lo = cmd_nibble(cc, 0, &s->dict_priors[DC_TRANSFORM + 1 + 2 * hi], SP_FAST);
+    out->a = ws; out->b = (uint8_t)((hi << 4) | lo); out->x = id;
+    return 0;
+}
+
+int orc_cmd_stream_walk(const uint8_t *cmd, size_t n, int wire, orc_cmd_walk *w) {
+    memset(w, 0, sizeof(*w));
+    walk_state *s = (walk_state *)malloc(sizeof(walk_state));
+    if (!s) return -1;
+    orc_stream_options o;
+    orc_stream_options_default(&o);
+    cmd_state_init(&s->c, &o);
+    s->c.wire = wire;
+    for (size_t i = 0; i < CP_TOTAL; ++i) orc_cdf_default(&s->copy_priors[i]);
+    for (size_t i = 0; i < DC_TOTAL; ++i) orc_cdf_default(&s->dict_priors[i]);
+    s->distance_lru[0] = 4; s->distance_lru[1] = 11; s->distance_lru[2] = 15; s->distance_lru[3] = 16;
+    s->last_llen = 1; s->last_clen = 1; s->last_dlen = 1;
+    orc_ans_decoder cd;
+    orc_ans_decoder_init(&cd, cmd, n);
+    cmd_coder cc = {NULL, &cd, 0};
+    int rc = 0;
+    for (;;) {
+        uint8_t code = cmd_nibble(&cc, 0, &s->c.cc_priors[s->c.last_4_states >> 4], SP_ROCKET); /* codec/mod.rs:662-688 */
+        if (cd.starved) { rc = -5; break; }
+        if (w->n_cmds == 64) { rc = -11; break; }
+        orc_walk_command *k = &w->cmds[w->n_cmds++];
+        k->kind = code;
+        if (code == 0xf) break;
+        if (code == 7) {
+            if (code_prediction_mode(&s->c, &cc, no_drain, NULL, NULL, &w->pm)) { rc = -6; break; }
+            w->mixing_value_min = 255;
+            for (size_t i = 0; i < ORC_NUM_MIXING_VALUES; ++i) {
+                if (s->c.pm_mixing[i] < w->mixing_value_min) w->mixing_value_min = s->c.pm_mixing[i];
+                if (s->c.pm_mixing[i] > w->mixing_value_max) w->mixing_value_max = s->c.pm_mixing[i];
+            }
+            for (size_t i = 0; i < ORC_MAX_LITERAL_CONTEXT_MAP_SIZE; ++i) if (s->c.pm_literal_context_map[i]) w->literal_context_map_nonzero = 1;
+            w->pm.literal_context_map = NULL; w->pm.mixing_values = NULL;   /* the storage dies with the walk */
+        } else if (code == 4) {
+            code_block_switch_literal(&s->c, &cc, no_drain, NULL, 0, 0, &k->a, &k->b);
+        } else if (code == 5 || code == 6) {            /* BlockTypeState for the command / distance switch, codec/block_type.rs:31-107 */
+            const int idx = code - 4;
+            uint8_t v = cmd_nibble(&cc, 0, &s->c.btype_priors[BT_MNEMONIC(idx)], SP_SLOW), b;
+            if (v == 0) b = s->c.btype_lru[idx][1];
+            else if (v == 1) b = (uint8_t)(s->c.btype_max_seen[idx] + 1);
+            else if (v == 15) {
+                uint8_t first = cmd_nibble(&cc, 0, &s->c.btype_priors[BT_FIRST(idx)], SP_SLOW);
+                b = (uint8_t)((cmd_nibble(&cc, 0, &s->c.btype_priors[BT_SECOND(idx)], SP_SLOW) << 4) | first);
+            } else b = (uint8_t)(v - 2);
+            s->c.last_4_states >>= 2;
+            s->c.btype_lru[idx][1] = s->c.btype_lru[idx][0]; s->c.btype_lru[idx][0] = b;
+            if (b > s->c.btype_max_seen[idx]) s->c.btype_max_seen[idx] = b;
+            k->a = b;
+        } else if (code == 3) {
+            walk_obs_state(s, 128);
+            if (code_literal_length(&s->c, &cc, no_drain, NULL, 15, &k->x)) { rc = -7; break; }
+            /* last_llen: set on the count-small and mantissa exits only, codec/literal.rs:587,649 -- the two-nibble lengths 15 / 16 leave it */
+            if (k->x < 15 || k->x > 16) s->last_llen = k->x;
+        } else if (code == 1) {
+            walk_obs_state(s, 64);
+            if ((rc = walk_copy(s, &cc, k)) != 0) break;
+        } else if (code == 2) {
+            walk_obs_state(s, 192);
+            if ((rc = walk_dict(s, &cc, k)) != 0) break;
+        } else { rc = -10; break; }
+        if (cd.starved) { rc = -5; break; }
+    }
+    w->nibbles = cc.nibbles; w->state_a = cd.state_a; w->state_b = cd.state_b; w->consumed = cd.in_pos; w->starved = cd.starved;
+    free(s);
     return rc;
 }

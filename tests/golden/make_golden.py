@@ -103,6 +103,15 @@ def main():
         with lzma.open(f"{OUT}/ir_{name}.ir.xz", "wb", preset=9 | lzma.PRESET_EXTREME) as f:
             f.write(open(f"{REF}/testdata/{name}.ir", "rb").read())
     np.frombuffer(open(f"{REF}/testdata/ends_with_truncated_dictionary", "rb").read(), dtype=np.uint8).tofile(f"{OUT}/ends_with_truncated_dictionary.bin")
+    # 8. the ONE compressed vector the reference tree holds: `_example_dv_file` in wasm/wasm.html:98-107, a 113-byte .divans
+    #    container written by a real Rust build (brotli front end; the sentence "It snowed, rained, and hailed ..." seven times).
+    #    tests/test_reference_vectors.py decodes it; DESIGN.md section 4 says what it pins and where its wire format is older
+    #    than the tree's HEAD.
+    html = open(f"{REF}/wasm/wasm.html").read()
+    k = html.index("var _example_dv_file = [")
+    ex = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{2})", html[k:html.index("];", k)])]
+    assert len(ex) == 113 and ex[:4] == [0xff, 0xe5, 0x8c, 0x9f] and ex[-4:] == list(b"ans~")
+    np.array(ex, dtype=np.uint8).tofile(f"{OUT}/ref_wasm_example.divans")
     print("golden fixtures written to", OUT)
 
 

@@ -1,14 +1,20 @@
-"""Compressed-byte parity against the REAL reference build -- armed by data, not by code.
+"""Compressed-byte parity against the REAL reference build.
 
-The reference (Rust) cannot be built in this image and ships no golden compressed vector, so the oracle's compressed bytes
-are pinned only by construction (oracle/divans_oracle.h, DESIGN.md section 4: parity "partial").  tests/golden/
+Part 1 (always runs): the one compressed vector the reference tree holds -- `_example_dv_file` in wasm/wasm.html:98-107, 113 bytes
+written by a real Rust build with the brotli front end (tests/golden/ref_wasm_example.divans, extracted by make_golden.py).  The
+oracle, the product's host parser and the HIP literal decoder all read it: header, Mux framing, end marker, CRC-32C trailer, all 8253
+nibbles of the CMD stream (ending exactly on the encoder's start states -- rANS is an exact inverse, so one wrong (start, freq)
+anywhere cannot), all 28 literal bytes; and re-ENCODING the decoded literals gives the example's 36 LIT bytes back.  That build is
+older than the tree's HEAD in two prior-table rows of the PredictionMode command (ORC_WIRE_WASM_EXAMPLE).
+
+Part 2 (armed by data): the reference (Rust) cannot be built in this image, so vectors of a HEAD build come from outside.  tests/golden/
 make_reference_vectors.rs is a test to append to the reference's src/bin/benchmark.rs; wherever a Rust toolchain exists,
 `cargo test --release --bin divans dump_reference_vectors` writes ref_container_<variant>_<size>.divans files.  Once those are
 copied into tests/golden/, this module compares byte for byte:
   1. the whole container with the oracle's for the same command list, options and 65 536-byte call buffers,
   2. the LIT-coder stream inside it (demuxed) with the oracle's stand-alone literal coder,
   3. (GPU box) that LIT stream with the HIP kernels' output, and decodes the reference's container through the product ABI.
-With no vector files present every test here skips: the skip is the honest status."""
+With no such files present the tests of part 2 skip."""
 import ctypes
 import glob
 import os
@@ -83,3 +89,154 @@ def test_gpu_matches_the_reference_build(path, shuffle384):
     assert int(sizes[0]) == lit.size and (packed[:lit.size] == lit).all(), "the HIP kernels' LIT stream differs from the reference build's"
     codec.close()
     assert (ffi_decompress(ref, data.size) == data).all()
+
+
+# ------------------------------------------------------------------ part 1: wasm/wasm.html:98-107
+EXAMPLE = os.path.join(GOLDEN, "ref_wasm_example.divans")
+SENTENCE_LITERALS = (b"It snowed, rain", b"and hailed ", b".\n")     # the Literal commands of the example, in order
+EXAMPLE_COMMANDS = [  # (command nibble, fields) of its CMD stream: codec/mod.rs:143-158
+    (7, {}), (4, {"a": 0, "b": 0}), (3, {"x": 15}), (1, {"x": 8, "y": 4}), (3, {"x": 11}),
+    (2, {"a": 9, "b": 0, "x": 648}), (2, {"a": 7, "b": 0, "x": 352}), (3, {"x": 2}), (1, {"x": 48, "y": 288}), (15, {})]
+
+
+def _example():
+    c = np.fromfile(EXAMPLE, dtype=np.uint8)
+    assert c.size == 113
+    return c
+
+
+def _last8(history):
+    """last_8_literals as the codec reloads it from the ring buffer after a Copy / Dict command, codec/mod.rs:771-783"""
+    return int.from_bytes((b"\0" * 8 + history)[-8:], "little")
+
+
+def _example_segments(unknown_prev):
+    """The three Literal commands as segments.  The first starts from the all-zero history of a fresh codec; the second follows
+    Copy(distance 8, 4 bytes) = "ed, "; the third follows two dictionary words this tree does not hold (brotli's static dictionary,
+    words 648 / 9 letters and 352 / 7 letters): under this stream's configuration -- context map all zero, every mixing value 4 =
+    stride 1 -- only the LAST byte before a literal selects a row, and it is the one unknown."""
+    seg = np.zeros(3, dtype=np.dtype([("len", "<u4"), ("btype", "<u4"), ("last8", "<u8")]))
+    seg[0] = (15, 0, 0)
+    seg[1] = (11, 0, _last8(b"It snowed, rained, "))
+    seg[2] = (2, 0, _last8(bytes([unknown_prev])))
+    return seg
+
+
+def _example_config():
+    cfg = po.config_simple()            # context map all zero, mixing values all 4, no mixing, four default speeds
+    cfg.prediction_mode = 2             # UTF8 (what the PredictionMode command says; irrelevant under an all-zero context map)
+    return cfg
+
+
+def test_example_framing_header_mux_end_marker_and_crc_trailer():
+    """divans_compressor.rs:126-131 (header), mux.rs (two streams, 2-byte lengths), the ff fe ff end marker, codec/mod.rs:518-554
+    (CRC-32C of everything before it, little-endian, then "ans~")"""
+    c = _example()
+    assert bytes(c[:4]) == b"\xff\xe5\x8c\x9f" and c[4] == 0 and c[5] == 22 and not c[6:16].any()
+    cmd, lit, used = po.mux_demux(c[16:])
+    assert (cmd.size, lit.size, used) == (44, 36, 89) and bytes(c[16 + used - 3:16 + used]) == b"\xff\xfe\xff"
+    crc = po.lib().orc_crc32c_update(0, c.ctypes.data, 16 + used)
+    assert bytes(c[16 + used:]) == int(crc).to_bytes(4, "little") + b"ans~"
+
+
+def test_oracle_walks_the_examples_whole_cmd_stream_to_the_encoders_start_states():
+    c = _example()
+    cmd, _, _ = po.mux_demux(c[16:])
+    rc, w = po.cmd_stream_walk(cmd, po.WIRE_WASM_EXAMPLE)
+    assert rc == 0 and not w.starved
+    got = [(k.kind, k.a, k.b, k.x, k.y) for k in w.cmds[:w.n_cmds]]
+    want = [(kind, f.get("a", 0), f.get("b", 0), f.get("x", 0), f.get("y", 0)) for kind, f in EXAMPLE_COMMANDS]
+    assert got == want
+    # 1 command-type + 3 + 16 speed + 2 mnemonic + 8192 mixing nibbles of the PredictionMode, then the nine commands after it
+    assert w.nibbles == 8253
+    assert w.consumed == cmd.size and w.state_a == 1 << 31 and w.state_b == 1 << 31      # ENC_START_STATE, ans.rs:135-136
+    assert (w.pm.prediction_mode, w.pm.mixing_math) == (2, 0)
+    assert [(s.inc, s.lim) for s in w.pm.literal_adaptation] == [(16, 8192)] * 4         # f8 (0x28, 0x70) = Speed::MUD four times
+    assert (w.mixing_value_min, w.mixing_value_max, w.literal_context_map_nonzero) == (4, 4, 0)
+    # the sentence: 15 + 4 + 11 + 9 + 7 + 2 bytes, then itself six more times
+    assert 15 + 4 + 11 + 9 + 7 + 2 == 48 and 48 + 288 == 7 * 48
+
+
+def test_head_wire_rows_do_not_read_the_example():
+    """the two rows in which HEAD differs (Mnemonic is a listed prior type there, and a mixing value past the 256th is coded under
+    the row of the value 256 places back: codec/priors.rs:125-133, context_map.rs:396-400) turn the example into noise"""
+    cmd, _, _ = po.mux_demux(_example()[16:])
+    rc, w = po.cmd_stream_walk(cmd, po.WIRE_HEAD)
+    assert rc != 0
+
+
+def test_oracle_decodes_and_reencodes_the_examples_lit_stream():
+    _, lit, _ = po.mux_demux(_example()[16:])
+    cfg = _example_config()
+    want = b"".join(SENTENCE_LITERALS)
+    # first Literal alone, through the plain stream decoder (the 15 bytes VERDICT r03 read)
+    assert bytes(po.lit_decode(cfg, lit, 15)) == SENTENCE_LITERALS[0]
+    seen_prev = {0} | set(SENTENCE_LITERALS[0][:-1]) | {ord(" ")} | set(SENTENCE_LITERALS[1][:-1]) | set(SENTENCE_LITERALS[2][:-1])
+    # ^ rows already adapted when the third literal starts, and the row its own first byte selects for its second
+    good = []
+    for prev in range(256):
+        seg = _example_segments(prev)
+        out = po.lit_segments_decode(cfg, lit, 28, seg["len"], seg["btype"], seg["last8"])
+        back = po.lit_segments_encode(cfg, out, seg["len"], seg["btype"], seg["last8"])
+        if back.size == lit.size and (back == lit).all():
+            assert bytes(out) == want
+            good.append(prev)
+    # every previous byte whose order-1 row is still untouched gives the same answer (the true one is a letter ending a dictionary word)
+    assert set(good) == set(range(256)) - seen_prev
+
+
+def test_product_host_parser_reads_the_example_up_to_its_first_copy_command():
+    """divans_probe_container = the product's own Mux / CRC / CMD model (host_stream.cpp), no GPU: PredictionMode, BlockSwitchLiteral and
+    the first Literal (15 bytes) decode, then a Copy command stops it (outside the literal-only scope)"""
+    import divans_amd as da
+    c = _example()
+    p = da.probe_container(c, da.WIRE_WASM_EXAMPLE)
+    assert (p.status, p.stopped_at_command, p.window, p.crc_ok, p.cmd_bytes, p.lit_bytes) == (3, 1, 22, 1, 44, 36)
+    assert (p.have_prediction_mode, p.commands, p.first_literal_length, p.literal_bytes) == (1, 3, 15, 15)
+    assert p.cmd_nibbles == 1 + 3 + 16 + 2 + 8192 + 1 + 2 + 1 + 2 + 1
+    assert bytes(p.cfg) == bytes(_example_config())          # the LIT configuration the oracle derives
+    assert da.probe_container(c, da.WIRE_HEAD).status == 2
+    damaged = c.copy(); damaged[40] ^= 1
+    assert da.probe_container(damaged, da.WIRE_WASM_EXAMPLE).crc_ok == 0
+
+
+@pytest.mark.gpu
+def test_gpu_decodes_and_reencodes_the_examples_lit_stream():
+    """the HIP literal decoder on the reference's own bytes: first Literal through divans_gpu_lit_decode_batch (the stream goes on
+    after it, so the integrity bit is set and only the bytes are asserted), then all three Literal commands as a segment list --
+    every coded word consumed, both final states back at 2^31: a clean status -- and the HIP encoder gives the 36 bytes back"""
+    import torch
+    import divans_amd as da
+    _, lit, _ = po.mux_demux(_example()[16:])
+    want = b"".join(SENTENCE_LITERALS)
+    cfg = da.LitConfig.from_buffer_copy(bytes(_example_config()))
+    dev = torch.device("cuda")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_coded = t(np.concatenate([lit, np.zeros(64, np.uint8)]))
+    d_off = t(np.zeros(1, np.int64)); d_csz = t(np.array([lit.size], np.int32))
+    for gen in (1, 2, 3):
+        codec = da.LiteralCodec(cfg, 64)
+        codec.set_decoder(gen)
+        out = torch.zeros(64 + 64, dtype=torch.uint8, device=dev)
+        codec.decode_batch(d_coded, d_off, d_csz, 1, 15, out)
+        assert bytes(out[:15].cpu().numpy()) == SENTENCE_LITERALS[0], f"decoder generation {gen}"
+        codec.close()
+    seg = _example_segments(ord("g"))
+    d_sb = t(np.array([0, 3], np.int32)); d_segs = t(seg.view(np.uint8))
+    d_lsz = t(np.array([28], np.int32))
+    for gen in (1, 2, 3):
+        codec = da.LiteralCodec(cfg, 64)
+        codec.set_decoder(gen)
+        back = torch.zeros(64 + 64, dtype=torch.uint8, device=dev)
+        codec.decode_segments_batch(d_coded, d_off, d_csz, 1, 28, d_sb, d_segs, back, d_off, d_lsz)
+        assert codec.status() == 0, f"decoder generation {gen}: integrity check"
+        assert bytes(back[:28].cpu().numpy()) == want
+        codec.close()
+    codec = da.LiteralCodec(cfg, 64)
+    outs = codec.alloc_encode_outputs(1, 64)
+    d_lit = t(np.concatenate([np.frombuffer(want, np.uint8), np.zeros(64, np.uint8)]))
+    codec.encode_segments_batch(d_lit, d_off, d_lsz, 1, 28, d_sb, d_segs, outs)
+    assert codec.status() == 0
+    o = int(outs["offsets"][0]); n = int(outs["sizes"][0])
+    assert n == lit.size and (outs["out"][o:o + n].cpu().numpy() == lit).all(), "the HIP encoder's LIT bytes differ from the reference build's"
+    codec.close()

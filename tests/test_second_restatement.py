@@ -78,3 +78,42 @@ def test_random_configurations(seed, corpus):
             o = int(rng.integers(0, corpus.size - n))
             data = corpus[o:o + n].copy()
         check(cfg, data)
+
+
+def test_second_restatement_reads_the_reference_trees_own_compressed_vector():
+    """wasm/wasm.html:98-107 (tests/golden/ref_wasm_example.divans) through the Python restatement alone: every command of the CMD
+    stream (tests/ref_cmd_walk.py) down to the encoder's start states, then the three Literal commands out of the LIT stream down to
+    ITS start states, and the literals re-encoded give the example's LIT bytes back"""
+    import os
+    import ref_cmd_walk as rw
+    c = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wasm_example.divans"), dtype=np.uint8)
+    cmd, lit, _ = po.mux_demux(c[16:])
+    w = rw.CmdWalk(cmd, example_build=True)
+    assert w.run() == [(7, None), (4, (0, 0)), (3, 15), (1, (8, 4)), (3, 11), (2, (9, 648, 0)), (2, (7, 352, 0)), (3, 2), (1, (48, 288)), (15, None)]
+    assert (w.nibbles, w.d.pos, w.d.state_a, w.d.state_b) == (8253, 44, 1 << 31, 1 << 31)
+    assert w.pm["mode"] == 2 and w.pm["mixing_math"] == 0 and w.pm["speeds"] == [(16, 8192)] * 4
+    assert set(w.pm["mixing_values"]) == {4} and w.pm["literal_context_map"] == [] and w.pm["distance_context_map"] == []
+    with pytest.raises(Exception):
+        bad = rw.CmdWalk(cmd, example_build=False)          # HEAD's two rows: noise
+        bad.run()
+        assert (bad.d.pos, bad.d.state_a, bad.d.state_b) == (44, 1 << 31, 1 << 31)
+    cfg = dict(context_map=bytes(16384), mixing_mask=bytes([4]) * 8192, prediction_mode=w.pm["mode"], btype=0, mixing_param=0, speeds=w.pm["speeds"])
+    history = lambda b: int.from_bytes((b"\0" * 8 + b)[-8:], "little")
+    dec = rr.AnsDecoder(bytes(lit) + b"\0" * 16)
+    lc = rr.LiteralCoder(**cfg)
+    out = [lc.code_bytes(None, 15, dec=dec)]
+    lc.last_8 = history(out[0] + b"ed, ")                   # Copy(distance 8, 4 bytes)
+    out.append(lc.code_bytes(None, 11, dec=dec))
+    lc.last_8 = history(b"g")                               # after two dictionary words: any byte whose row is still untouched
+    out.append(lc.code_bytes(None, 2, dec=dec))
+    assert out == [b"It snowed, rain", b"and hailed ", b".\n"]
+    assert (dec.pos, dec.state_a, dec.state_b) == (36, 1 << 31, 1 << 31)
+    enc = rr.AnsEncoder()
+    lc = rr.LiteralCoder(**cfg)
+    lc.code_bytes(out[0], 15, enc=enc)
+    lc.last_8 = history(out[0] + b"ed, ")
+    lc.code_bytes(out[1], 11, enc=enc)
+    lc.last_8 = history(b"g")
+    lc.code_bytes(out[2], 2, enc=enc)
+    enc.flush_chunk()
+    assert bytes(enc.out) == bytes(lit)
