@@ -162,6 +162,7 @@ def load_library():
     L.divans_batch_compress.argtypes = [ctypes.POINTER(BatchOptions), vp, vp, sz, vp, sz, vp, vp, ctypes.POINTER(BatchTiming)]
     L.divans_batch_decompress.argtypes = [ctypes.POINTER(BatchOptions), vp, vp, sz, vp, sz, vp, vp, ctypes.POINTER(BatchTiming)]
     L.divans_probe_container.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(ContainerProbe)]
+    L.divans_batch_last_phases.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]; L.divans_batch_last_phases.restype = None
     L.divans_ir_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]
     L.divans_ir_free.argtypes = [vp]
     L.divans_ir_free.restype = None
@@ -186,7 +187,7 @@ def exported_symbols():
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
-        "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_codec_status", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
+        "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
         "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
@@ -198,7 +199,7 @@ def exported_symbols():
 def exported_batch_symbols():
     """Entry points include/divans_batch.h declares."""
     return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress", "divans_batch_release",
-            "divans_probe_container"]
+            "divans_probe_container", "divans_batch_last_phases"]
 
 
 def exported_ir_symbols():
@@ -364,6 +365,12 @@ class LiteralCodec:
         i = GpuInfo()
         _check(self._lib.divans_gpu_codec_info(self._h, ctypes.byref(i)), "divans_gpu_codec_info")
         return i
+
+    def last_decode_kernel(self):
+        """the decode kernel instance the last decode call launched, as rocprofv3 names it"""
+        buf = ctypes.create_string_buffer(160)
+        _check(self._lib.divans_gpu_codec_last_decode_kernel(self._h, buf, 160), "divans_gpu_codec_last_decode_kernel")
+        return buf.value.decode()
 
     def status(self):
         """Synchronises and returns (then clears) the sticky device status word: 1 = invalid (start,freq) in an encode
@@ -621,6 +628,13 @@ def _batch_call(fn, what, options, items, cap):
     _check(fn(ctypes.byref(options), ptrs, sizes, n, out.ctypes.data, cap, offs, osz, ctypes.byref(t)), what)
     res = [out[offs[i]:offs[i] + osz[i]].copy() for i in range(n)]
     return res, dict(total_ms=t.total_ms, gpu_ms=t.gpu_ms, host_overlapped_ms=t.host_overlapped_ms, host_serial_ms=t.host_serial_ms)
+
+
+def batch_last_phases():
+    """divans_batch_last_phases: dict of the last batch call's host phases in milliseconds"""
+    out = (ctypes.c_double * 8)()
+    load_library().divans_batch_last_phases(out, 8)
+    return dict(zip(("cmd_coders_ms", "stage_ms", "wait_gpu_ms", "finish_ms", "gather_ms"), (round(float(x), 2) for x in out[:5])))
 
 
 def probe_container(container, wire=WIRE_HEAD):

@@ -201,8 +201,10 @@ struct CodecKey {
 
 struct Lane {
     hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-    struct Entry { divans_gpu_codec* c; uint32_t full_grid; };   // full_grid: the persistent grid the codec chose for a full GPU
-    std::map<CodecKey, Entry> codecs;
+    struct Entry { divans_gpu_codec* c; uint32_t full_grid; uint64_t used; };   // full_grid: the persistent grid the codec chose for a full GPU
+    std::map<CodecKey, Entry> codecs;     // at most kCodecsPerLane: a long-running process that sees many PredictionModes / length classes
+    uint64_t tick = 0;                    // would otherwise pile up tables and scratch until hipMalloc fails
+    static constexpr size_t kCodecsPerLane = 6;
     PinnedBuf h_in, h_off, h_sz, h_ooff, h_osz, h_out, h_chunks, h_total, h_flags;
     DeviceBuf d_in, d_off, d_sz, d_slots, d_ooff, d_osz, d_packed, d_poff, d_total, d_chunks, d_out, d_flags;
     long slice = -1;                 // slice in flight on this lane
@@ -221,13 +223,21 @@ struct Lane {
         CodecKey key; key.cfg = cfg; key.bound = bound;
         auto it = codecs.find(key);
         if (it == codecs.end()) {
+            while (codecs.size() >= kCodecsPerLane) {          // evict the least recently used one; its launches are behind us after the sync
+                auto lru = codecs.begin();
+                for (auto j = codecs.begin(); j != codecs.end(); ++j) if (j->second.used < lru->second.used) lru = j;
+                HIP_OR_FAIL(hipStreamSynchronize(stream));
+                divans_gpu_codec_destroy(lru->second.c);
+                codecs.erase(lru);
+            }
             divans_gpu_codec* c = nullptr;
             const int rc = divans_gpu_codec_create(&c, &cfg, device, stream, bound);
             if (rc) return rc;
             divans_gpu_info info;
             if (divans_gpu_codec_info(c, &info)) { divans_gpu_codec_destroy(c); return DIVANS_GPU_EHIP; }
-            it = codecs.emplace(key, Entry{c, info.blocks}).first;
+            it = codecs.emplace(key, Entry{c, info.blocks, 0}).first;
         }
+        it->second.used = ++tick;
         // a small slice does not need the full persistent grid's worth of CDF tables; a later, larger one gets the grid back
         const uint32_t want = (uint32_t)std::max<size_t>(1, std::min<size_t>(it->second.full_grid, (n_streams + 15) / 16));
         divans_gpu_info info;
@@ -256,6 +266,10 @@ struct LanePool {
     }
 };
 LanePool& pool() { static LanePool p; return p; }
+
+// Where the host's time went in the last call (divans_batch_last_phases): a diagnostic, overwritten by every call
+double g_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+enum { PH_PARSE_OR_PLAN = 0, PH_STAGE = 1, PH_WAIT = 2, PH_FINISH = 3, PH_GATHER = 4 };
 
 // wall-clock bookkeeping of the overlap: host work counts as overlapped while at least one slice is in flight on the GPU
 struct Overlap {
@@ -319,6 +333,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     for (auto& kv : plans) { plan_slots.push_back(&kv.second); plan_len.push_back(kv.first); }
     std::atomic<int> plan_rc{0};
     bool plans_done = false;
+    for (double& v : g_phases) v = 0;
     auto make_plans = [&]() {
         const double t0 = now_ms();
         parallel_for(plan_slots.size(), opt->host_threads, [&](size_t k) {
@@ -328,7 +343,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
             *plan_slots[k] = std::move(p);
         });
         plans_done = true;
-        ov.host(t0, now_ms());
+        ov.host(t0, now_ms()); g_phases[PH_PARSE_OR_PLAN] += now_ms() - t0;
     };
 
     auto issue = [&](size_t k) -> int {
@@ -359,6 +374,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         HIP_OR_FAIL(hipMemcpyAsync(L.d_off.p, L.h_off.p, 8 * m, hipMemcpyHostToDevice, L.stream));
         HIP_OR_FAIL(hipMemcpyAsync(L.d_sz.p, L.h_sz.p, 4 * m, hipMemcpyHostToDevice, L.stream));
         HIP_OR_FAIL(hipMemsetAsync(L.d_chunks.p, 0, 4ull * m * max_chunks, L.stream));
+        r = divans_gpu_codec_clear_status(codec); if (r) return r;          // the codec outlives the call: no bit of an earlier, abandoned slice
         r = divans_gpu_lit_encode_batch_chunks(codec, L.d_in.as<uint8_t>(), L.d_off.as<uint64_t>(), L.d_sz.as<uint32_t>(), s.bound, (uint32_t)m,
                                                L.d_slots.as<uint8_t>(), slot, L.d_ooff.as<uint64_t>(), L.d_osz.as<uint32_t>(), L.d_chunks.as<uint32_t>(), max_chunks);
         if (r) return r;
@@ -375,7 +391,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         HIP_OR_FAIL(hipEventRecord(L.done, L.stream));
         L.slice = (long)k;
         const double t1 = now_ms();
-        ov.host(t0, t1);
+        ov.host(t0, t1); g_phases[PH_STAGE] += t1 - t0;
         if (ov.gpu_first < 0) ov.gpu_first = t0;
         ov.in_flight += 1;
         return 0;
@@ -388,7 +404,9 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         const Slice& s = slices[k];
         const size_t m = s.members.size();
         const uint32_t max_chunks = (uint32_t)std::max<uint64_t>(1, (2ull * s.bound + 65535ull) / 65536ull);
+        const double tw = now_ms();
         HIP_OR_FAIL(hipEventSynchronize(L.done));
+        g_phases[PH_WAIT] += now_ms() - tw;
         const uint64_t packed_total = *L.h_total.as<uint64_t>();
         const size_t guess = std::min<size_t>(divans_gpu_lit_encode_bound(s.bound) * m, s.bytes / 8 * 5 + 64 * m + 4096);
         if (packed_total > guess) {   // incompressible input: a larger staging buffer, the whole slice again
@@ -413,7 +431,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
                                                            L.h_chunks.as<uint32_t>() + j * max_chunks, call_buffer, results[i]);
             if (rr) asm_rc = rr;
         });
-        ov.host(t0, now_ms());
+        ov.host(t0, now_ms()); g_phases[PH_FINISH] += now_ms() - t0;
         L.slice = -1;
         if (asm_rc) return set_last_error(asm_rc, "container assembly failed");
         return 0;
@@ -433,7 +451,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
     parallel_for(n_streams, opt->host_threads, [&](size_t i) { std::memcpy(out + out_offsets[i], results[i].data(), results[i].size()); });
     const double t_end = now_ms();
-    ov.host(t_out0, t_end);
+    ov.host(t_out0, t_end); g_phases[PH_GATHER] += t_end - t_out0;
     if (timing) {
         timing->total_ms = t_end - t_begin; timing->gpu_ms = ov.gpu_last - ov.gpu_first;
         timing->host_overlapped_ms = ov.overlapped; timing->host_serial_ms = ov.serial;
@@ -452,37 +470,57 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     int rc = pool().acquire(opt->device, &lanes); if (rc) return rc;
     struct Drain { Lane* l; ~Drain() { for (int i = 0; i < kLanes; ++i) if (l[i].stream) (void)hipStreamSynchronize(l[i].stream); } } drain{lanes};   // no early return with copies in flight
     Overlap ov;
+    for (double& v : g_phases) v = 0;
     const size_t budget = device_budget();
     // Slices in stream order (the output offsets are the running sum of the decoded sizes): one per lane, 128 .. 8192
     // containers.  While the GPU decodes the slices in flight (concurrently: a stream is a serial chain of tens of
     // milliseconds), host threads parse the next one (framing, CRC, CMD coder -> decoded sizes and LIT configuration, which
     // the launch needs) and copy out the ones that have finished.
     const size_t per = std::min<size_t>(8192, std::max<size_t>(128, (n_streams + kLanes - 1) / kLanes));
-    const size_t ns = (n_streams + per - 1) / per;
+    const size_t n_blocks = (n_streams + per - 1) / per;      // parse blocks; a block is then cut into the slices that are issued
+    struct Range { size_t b, e; };
+    std::vector<Range> slices;                                // in issue order; slice k runs on lane k % kLanes
     std::vector<divans_host::ParsedStream> parsed(n_streams);
     std::vector<int> status(n_streams, 0);
     divans_host::ParseMemo memo;     // equal-length streams of one producer carry the same CMD bytes: decode them once (host_stream.h)
     size_t pos = 0;
 
     struct Group { divans_lit_config cfg; uint32_t bound; std::vector<size_t> members; size_t in_bytes = 0, out_bytes = 0, in_base = 0, out_base = 0, idx_base = 0; };
-    std::vector<std::vector<Group>> slice_groups(ns);
+    std::vector<std::vector<Group>> slice_groups;
 
-    auto parse = [&](size_t k) -> int {
-        const size_t b = k * per, e = std::min(n_streams, b + per);
+    // What a decoding slice costs on the device: its coded bytes in, its decoded bytes out, offsets / sizes / flags.  (The codec's
+    // tables belong to the persistent grid, not to the slice.)  A parse block is cut into slices that stay under the lane's budget;
+    // only a single stream that does not fit by itself fails the call.
+    auto decode_bytes_of = [&](size_t i) -> size_t { return parsed[i].lit_size + parsed[i].total + 192; };
+    auto cut_block = [&](size_t b, size_t e) -> int {
+        size_t sb = b, acc = 0;
+        for (size_t i = b; i < e; ++i) {
+            const size_t need = decode_bytes_of(i);
+            if (need > budget * 2) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ENOMEM, "container " + std::to_string(i) + " does not fit the device by itself"); }
+            if (i > sb && acc + need > budget) { slices.push_back({sb, i}); sb = i; acc = 0; }
+            acc += need;
+        }
+        if (e > sb) slices.push_back({sb, e});
+        slice_groups.resize(slices.size());
+        return 0;
+    };
+
+    auto parse = [&](size_t kb) -> int {
+        const size_t b = kb * per, e = std::min(n_streams, b + per);
         const double t0 = now_ms();
         parallel_for(e - b, opt->host_threads, [&](size_t j) {
             const size_t i = b + j;
-            status[i] = (int)divans_host::parse_container_host(containers[i], sizes[i], opt->skip_crc != 0, (size_t)1 << 30, parsed[i], nullptr, &memo);
+            status[i] = (int)divans_host::parse_container_host(containers[i], sizes[i], opt->skip_crc != 0, (size_t)1 << 30, parsed[i], nullptr, &memo, true);
         });
-        ov.host(t0, now_ms());
+        ov.host(t0, now_ms()); g_phases[PH_PARSE_OR_PLAN] += now_ms() - t0;
         for (size_t i = b; i < e; ++i)
             if (status[i] != divans_host::PARSE_OK) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ECORRUPT, "container " + std::to_string(i) + " is truncated, corrupt or not a literal-only stream"); }
-        return 0;
+        return cut_block(b, e);
     };
 
     auto issue = [&](size_t k) -> int {
         Lane& L = lanes[k % kLanes];
-        const size_t b = k * per, e = std::min(n_streams, b + per);
+        const size_t b = slices[k].b, e = slices[k].e;
         const double t0 = now_ms();
         // group the slice by LIT configuration and length class (one codec = one configuration and one table / scratch size)
         std::vector<Group>& groups = slice_groups[k];
@@ -493,13 +531,11 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             Group* g = nullptr;
             for (auto& q : groups) if (q.bound == bound && std::memcmp(&q.cfg, &parsed[i].cfg, sizeof(divans_lit_config)) == 0) { g = &q; break; }
             if (!g) { groups.emplace_back(); g = &groups.back(); g->cfg = parsed[i].cfg; g->bound = bound; }
-            g->members.push_back(i); g->in_bytes += parsed[i].lit.size(); g->out_bytes += parsed[i].total;
+            g->members.push_back(i); g->in_bytes += parsed[i].lit_size; g->out_bytes += parsed[i].total;
         }
         if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
         size_t in_total = 0, out_total = 0, m_total = 0;
         for (auto& g : groups) {
-            if (device_bytes_per_stream(g.bound) * g.members.size() > budget * 2)
-                return set_last_error(DIVANS_GPU_ENOMEM, "a slice of the batch does not fit the device: split the call");
             g.in_base = in_total; g.out_base = out_total; g.idx_base = m_total;
             in_total += (g.in_bytes + 127) & ~(size_t)63; out_total += (g.out_bytes + 63) & ~(size_t)63; m_total += g.members.size();
         }
@@ -516,13 +552,15 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             for (size_t j = 0; j < g.members.size(); ++j) {
                 const divans_host::ParsedStream& ps = parsed[g.members[j]];
                 ioff[j] = ip;
-                L.h_off.as<uint64_t>()[g.idx_base + j] = ip; L.h_sz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.lit.size();
+                L.h_off.as<uint64_t>()[g.idx_base + j] = ip; L.h_sz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.lit_size;
                 L.h_ooff.as<uint64_t>()[g.idx_base + j] = op; L.h_osz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.total;
-                ip += ps.lit.size(); op += ps.total;
+                ip += ps.lit_size; op += ps.total;
             }
             parallel_for(g.members.size(), opt->host_threads, [&](size_t j) {
                 const divans_host::ParsedStream& ps = parsed[g.members[j]];
-                std::memcpy(L.h_in.as<uint8_t>() + g.in_base + ioff[j], ps.lit.data(), ps.lit.size());
+                // straight from the caller's container into page-locked memory (the parser left spans, not a copy)
+                if (!ps.lit_spans.empty()) ps.copy_lit(containers[g.members[j]], L.h_in.as<uint8_t>() + g.in_base + ioff[j]);
+                else if (ps.lit_size) std::memcpy(L.h_in.as<uint8_t>() + g.in_base + ioff[j], ps.lit.data(), ps.lit_size);
             });
         }
         HIP_OR_FAIL(hipMemcpyAsync(L.d_in.p, L.h_in.p, in_total + 128, hipMemcpyHostToDevice, L.stream));
@@ -535,6 +573,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             divans_gpu_codec* codec = nullptr;
             int r = L.codec_for(g.cfg, g.bound, opt->device, g.members.size(), &codec); if (r) return r;
             r = divans_gpu_codec_set_stream_flags(codec, L.d_flags.as<uint8_t>() + g.idx_base); if (r) return r;
+            r = divans_gpu_codec_clear_status(codec); if (r) return r;      // the codec outlives the call: no bit of an earlier, abandoned slice
             r = divans_gpu_lit_decode_batch(codec, L.d_in.as<uint8_t>() + g.in_base, L.d_off.as<uint64_t>() + g.idx_base, L.d_sz.as<uint32_t>() + g.idx_base,
                                             (uint32_t)g.members.size(), L.d_out.as<uint8_t>() + g.out_base, L.d_ooff.as<uint64_t>() + g.idx_base,
                                             L.d_osz.as<uint32_t>() + g.idx_base, g.bound);
@@ -544,7 +583,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
         HIP_OR_FAIL(hipMemcpyAsync(L.h_flags.p, L.d_flags.p, m_total, hipMemcpyDeviceToHost, L.stream));
         HIP_OR_FAIL(hipEventRecord(L.done, L.stream));
         const double t1 = now_ms();
-        ov.host(t0, t1);
+        ov.host(t0, t1); g_phases[PH_STAGE] += t1 - t0;
         if (ov.gpu_first < 0) ov.gpu_first = t0;
         ov.in_flight += 1;
         return 0;
@@ -552,8 +591,10 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
 
     auto complete = [&](size_t k) -> int {
         Lane& L = lanes[k % kLanes];
-        const size_t b = k * per, e = std::min(n_streams, b + per);
+        const size_t b = slices[k].b, e = slices[k].e;
+        const double tw = now_ms();
         HIP_OR_FAIL(hipEventSynchronize(L.done));
+        g_phases[PH_WAIT] += now_ms() - tw;
         ov.in_flight -= 1; ov.gpu_last = now_ms();
         const double t0 = now_ms();
         std::vector<Group>& groups = slice_groups[k];
@@ -562,7 +603,10 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             int r = L.codec_for(g.cfg, g.bound, opt->device, g.members.size(), &codec); if (r) return r;
             uint32_t st = 0;
             if (divans_gpu_codec_status(codec, &st)) return DIVANS_GPU_EHIP;
-            if (st & DIVANS_GPU_STATUS_BAD_STREAM) {
+            // the per-stream flags are the kernels' own record (the status word is the codec's, and a codec may have been rebuilt)
+            bool flagged = false;
+            for (size_t j = 0; j < g.members.size() && !flagged; ++j) flagged = L.h_flags.as<uint8_t>()[g.idx_base + j] != 0;
+            if ((st & DIVANS_GPU_STATUS_BAD_STREAM) || flagged) {
                 size_t first = g.members.front();
                 for (size_t j = 0; j < g.members.size(); ++j) if (L.h_flags.as<uint8_t>()[g.idx_base + j]) { first = g.members[j]; out_sizes[first] = (size_t)-1; break; }
                 return set_last_error(DIVANS_GPU_ECORRUPT, "the LIT stream of container " + std::to_string(first) + " failed the decoder's integrity check");
@@ -572,19 +616,22 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
                 std::memcpy(out + out_offsets[i], L.h_out.as<uint8_t>() + g.out_base + L.h_ooff.as<uint64_t>()[g.idx_base + j], parsed[i].total);
             });
         }
-        for (size_t i = b; i < e; ++i) { std::vector<uint8_t>().swap(parsed[i].lit); }
+        for (size_t i = b; i < e; ++i) { std::vector<uint8_t>().swap(parsed[i].lit); std::vector<std::pair<uint32_t, uint32_t>>().swap(parsed[i].lit_spans); }
         groups.clear();
-        ov.host(t0, now_ms());
+        ov.host(t0, now_ms()); g_phases[PH_FINISH] += now_ms() - t0;
         return 0;
     };
 
-    // software pipeline: parse k, issue k; then complete the oldest slice once kLanes are in flight
-    for (size_t k = 0; k < ns; ++k) {
-        if (k >= (size_t)kLanes) { rc = complete(k - kLanes); if (rc) return rc; }
-        rc = parse(k); if (rc) return rc;
-        rc = issue(k); if (rc) return rc;
+    // software pipeline: parse a block, issue its slices; the oldest slice is completed once kLanes are in flight
+    size_t issued = 0, completed = 0;
+    for (size_t kb = 0; kb < n_blocks; ++kb) {
+        rc = parse(kb); if (rc) return rc;
+        while (issued < slices.size()) {
+            if (issued - completed >= (size_t)kLanes) { rc = complete(completed++); if (rc) return rc; }
+            rc = issue(issued++); if (rc) return rc;
+        }
     }
-    for (size_t k = ns > (size_t)kLanes ? ns - kLanes : 0; k < ns; ++k) { rc = complete(k); if (rc) return rc; }
+    while (completed < issued) { rc = complete(completed++); if (rc) return rc; }
     if (timing) {
         timing->total_ms = now_ms() - t_begin; timing->gpu_ms = ov.gpu_last - ov.gpu_first;
         timing->host_overlapped_ms = ov.overlapped; timing->host_serial_ms = ov.serial;
@@ -597,6 +644,13 @@ void divans_batch_release(void) {
     std::lock_guard<std::mutex> pool_lock(pool().mu);
     pool().lanes.reset();
     pool().device = -1;
+}
+
+// Where the calling thread's time went in the last batch call (milliseconds): [0] CMD coders -- plans (compress) / container parsing
+// (decompress), [1] staging into page-locked memory + enqueueing, [2] waiting for the GPU, [3] container assembly (compress) / copy-out
+// (decompress), [4] final gather of the containers (compress).  A diagnostic: overwritten by every call, not thread-safe across calls.
+void divans_batch_last_phases(double* out, int n) {
+    for (int i = 0; i < n && i < 8; ++i) out[i] = g_phases[i];
 }
 
 // Host-only report on one container (divans_batch.h).

@@ -104,10 +104,14 @@ struct divans_gpu_codec {
     bool cache_unified = false;
     // decoder generation: 2 = lit_decode2.hip (direct-mapped row caches, LDS word ring), 1 = lit_decode_kernel of lit_kernels.hip
     uint32_t decode_gen = 2;
-    bool dm_auto = true;          // nobody chose between direct-mapped and 2-way caches (divans_gpu_codec_set_decoder): pick per batch
+#ifndef DIVANS_DM_AUTO_DEFAULT    // experiment switch (scripts/build_variants.sh dm_auto): 0 = always the codec's own organisation (2-way)
+#define DIVANS_DM_AUTO_DEFAULT 1
+#endif
+    bool dm_auto = DIVANS_DM_AUTO_DEFAULT != 0;          // nobody chose between direct-mapped and 2-way caches (divans_gpu_codec_set_decoder): pick per batch
     uint32_t dm_log2 = 0, dm_shift = 0;   // LitBatch::dm_log2 / dm_shift
     uint32_t blocks2 = 0;                 // persistent grid of lit_decode2_kernel
     bool user_geometry = false;           // set_geometry / set_split_cache / set_decoder were called: set_block_types keeps their choices
+    char last_decode_kernel[128] = "";    // divans_gpu_codec_last_decode_kernel
     uint8_t* d_stream_flags = nullptr;    // caller-owned per-stream failure flags of the decode entry points (divans_gpu_codec_set_stream_flags)
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
@@ -496,13 +500,19 @@ extern "C" int divans_gpu_codec_set_bucket_batch(divans_gpu_codec* c, uint32_t s
 // Decoder generation and the geometry of lit_decode2_kernel: rows[i] of the four direct-mapped caches (high stride, high
 // context-map, low stride, low context-map rows; 0 = not cached, else a power of two in [4, 256]), their hash shifts, and
 // the persistent grid (0 = keep).
+static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks, bool by_user);
 extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks) {
+    return set_decoder_impl(c, generation, rows, shifts, blocks, true);
+}
+// by_user = false: the grid follows divans_gpu_codec_set_geometry; who chooses between direct-mapped and 2-way caches per batch
+// (dm_auto) and whether a later set_block_types keeps the geometry (user_geometry) stay as they were
+static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks, bool by_user) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    c->user_geometry = true;
+    if (by_user) c->user_geometry = true;
     if (generation < 1u || generation > 3u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches) or 3 (second generation, 2-way caches)");
     HIP_TRY(hipSetDevice(c->device));
     const bool two_way = generation == 3u;
-    c->dm_auto = false;
+    if (by_user) c->dm_auto = false;
     if (generation == 3u) generation = 2u;
     c->dm_shift = (c->dm_shift & 0x7fffffffu) | (two_way ? 0x80000000u : 0u);
     if (generation == 2u && rows && shifts) {
@@ -550,7 +560,7 @@ extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t block
         c->blocks = blocks;
         if (c->blocks2) {    // the second-generation decoder follows, as far as its LDS use allows
             const uint32_t gen = c->decode_gen;
-            int rc = divans_gpu_codec_set_decoder(c, (c->dm_shift >> 31) ? 3 : 2, nullptr, nullptr, blocks); if (rc) return rc;
+            int rc = set_decoder_impl(c, (c->dm_shift >> 31) ? 3 : 2, nullptr, nullptr, blocks, false); if (rc) return rc;   // grid only: dm_auto stays
             c->decode_gen = gen;
         }
     }
@@ -795,8 +805,8 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    if (use_decode2(c)) HIP_TRY(launch_decode2(b, c->mix, c->blocks2, c->stream));
-    else HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream));
+    if (use_decode2(c)) { lit_decode2_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode2(b, c->mix, c->blocks2, c->stream)); }
+    else { lit_decode_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream)); }
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     c->timing_pending_dec = true;
     return 0;
@@ -859,6 +869,19 @@ extern "C" int divans_gpu_codec_status(divans_gpu_codec* c, uint32_t* status) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (h) HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(h), c->stream));
     *status = h;
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_last_decode_kernel(divans_gpu_codec* c, char* buf, size_t cap) {
+    if (!c || !buf || !cap) return fail(DIVANS_GPU_EINVAL, "null argument");
+    snprintf(buf, cap, "%s", c->last_decode_kernel);
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_clear_status(divans_gpu_codec* c) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
     return 0;
 }
 

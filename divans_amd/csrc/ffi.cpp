@@ -101,7 +101,8 @@ static bool start(DivansCompressorState* s) {
     // reference decoder accepts -- larger than a brotli-assisted one -- so c/example.c, which sets no
     // options, round-trips through this library unchanged.
     if (s->opt.dynamic_context_mixing >= 15) s->failed = true;   // codec/interface.rs:359 assert
-    if (!s->failed) s->enc = new (std::nothrow) divans_host::StreamEncoder(s->opt, 0);
+    // (the object's members allocate too -- the 2^window ring, vectors: no exception may leave an extern "C" function)
+    if (!s->failed) { try { s->enc = new divans_host::StreamEncoder(s->opt, 0); } catch (...) { s->enc = nullptr; } }
     if (!s->enc) s->failed = true;
     return !s->failed;
 }
@@ -114,7 +115,8 @@ DivansResult divans_encode(struct DivansCompressorState* s, const uint8_t* in, s
     if (!s || !in_off || !out_off || *in_off > in_size || *out_off > out_size) return DIVANS_FAILURE;
     if (!s->started && !start(s)) return DIVANS_FAILURE;
     if (s->failed || s->flushing) return DIVANS_FAILURE;       // NotAllowedToEncodeAfterFlush
-    const int rc = s->enc->encode(in, in_size, in_off, out, out_size, out_off);
+    int rc;
+    try { rc = s->enc->encode(in, in_size, in_off, out, out_size, out_off); } catch (...) { rc = -1; }
     if (rc < 0) { s->failed = true; return DIVANS_FAILURE; }
     return rc == 1 ? DIVANS_NEEDS_MORE_OUTPUT : DIVANS_NEEDS_MORE_INPUT;
 }
@@ -125,7 +127,8 @@ DivansResult divans_encode_flush(struct DivansCompressorState* s, uint8_t* out, 
     if (!s->started && !start(s)) return DIVANS_FAILURE;
     if (s->failed) return DIVANS_FAILURE;
     s->flushing = true;
-    const int rc = s->enc->flush(out, out_size, out_off);
+    int rc;
+    try { rc = s->enc->flush(out, out_size, out_off); } catch (...) { rc = -1; }
     if (rc < 0) { s->failed = true; return DIVANS_FAILURE; }
     return rc == 1 ? DIVANS_NEEDS_MORE_OUTPUT : DIVANS_SUCCESS;
 }
@@ -161,10 +164,11 @@ DivansResult divans_decode(struct DivansDecompressorState* s, const uint8_t* in,
     if (!s || !in_off || !out_off || *in_off > in_size || *out_off > out_size) return DIVANS_FAILURE;
     if (s->failed) return DIVANS_FAILURE;
     if (!s->dec) {
-        s->dec = new (std::nothrow) divans_host::StreamDecoder(s->skip_crc, s->max_output, 0);
+        try { s->dec = new divans_host::StreamDecoder(s->skip_crc, s->max_output, 0); } catch (...) { s->dec = nullptr; }
         if (!s->dec) { s->failed = true; return DIVANS_FAILURE; }
     }
-    const int rc = s->dec->decode(in, in_size, in_off, out, out_size, out_off);
+    int rc;
+    try { rc = s->dec->decode(in, in_size, in_off, out, out_size, out_off); } catch (...) { rc = -1; }
     if (rc < 0) { s->failed = true; return DIVANS_FAILURE; }
     return rc == 0 ? DIVANS_SUCCESS : (rc == 1 ? DIVANS_NEEDS_MORE_INPUT : DIVANS_NEEDS_MORE_OUTPUT);
 }

@@ -1001,14 +1001,49 @@ ParseMemo::ParseMemo() : p_(new Impl()) {}
 ParseMemo::~ParseMemo() { delete p_; }
 
 // Host half of decoding: framing, CRC, CMD coder.  Leaves the LIT coder's bytes, the decoded size and its configuration.
-ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed, ParseMemo* memo) {
+// Demultiplexing a COMPLETE container without copying its LIT slices (mux.rs:445-561 read back): the CMD stream (a few hundred bytes) is
+// collected, every LIT slice is recorded as (offset in `in`, length).  Returns the bytes used up to and including the end marker,
+// 0 when the framing is damaged or the input ends before the marker (the caller then takes the copying path, which tells the two apart).
+static size_t scan_container_body(const uint8_t* in, size_t n, size_t base, std::vector<uint8_t>& cmd, std::vector<std::pair<uint32_t, uint32_t>>& spans, size_t& lit_size) {
+    size_t pos = 0;
+    lit_size = 0;
+    while (pos < n) {
+        const uint8_t c = in[pos];
+        if (c == 0xff) {
+            if (n - pos < 3 || in[pos + 1] != 0xfe || in[pos + 2] != 0xff) return 0;
+            return pos + 3;
+        }
+        size_t count;
+        if (c < 16) {
+            if (n - pos < 3) return 0;
+            count = ((size_t)in[pos + 1] | ((size_t)in[pos + 2] << 8)) + 1; pos += 3;
+        } else { count = (size_t)1024u << ((c >> 4) << 1); pos += 1; }
+        if (count > n - pos || base + pos > 0xffffffffu) return 0;
+        if (c & 1) { spans.emplace_back((uint32_t)(base + pos), (uint32_t)count); lit_size += count; }
+        else cmd.insert(cmd.end(), in + pos, in + pos + count);
+        pos += count;
+    }
+    return 0;
+}
+
+ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed, ParseMemo* memo, bool spans_only) {
     ps = ParsedStream();
     if (n < 16) return PARSE_NEED_MORE;
     if (in[0] != 0xff || in[1] != 0xe5 || in[2] != 0x8c || in[3] != 0x9f) return PARSE_CORRUPT;   // divans_decompressor.rs:38-52
     if (in[5] < 10 || in[5] >= 25) return PARSE_CORRUPT;
     Mux mux;
-    const size_t used = mux.deserialize(in + 16, n - 16);
-    if (mux.eof != 3) return (16 + used < n) ? PARSE_CORRUPT : PARSE_NEED_MORE;
+    size_t used = 0;
+    std::vector<uint8_t> cmd_bytes;
+    bool scanned = false;
+    if (spans_only) {
+        used = scan_container_body(in + 16, n - 16, 16, cmd_bytes, ps.lit_spans, ps.lit_size);
+        scanned = used != 0;
+        if (!scanned) { ps.lit_spans.clear(); ps.lit_size = 0; cmd_bytes.clear(); }
+    }
+    if (!scanned) {
+        used = mux.deserialize(in + 16, n - 16);
+        if (mux.eof != 3) return (16 + used < n) ? PARSE_CORRUPT : PARSE_NEED_MORE;
+    }
     if (n - 16 - used < 8) return PARSE_NEED_MORE;
     const uint8_t* tr = in + 16 + used;
     const uint32_t crc = crc32c(0, in, 16 + used);
@@ -1016,22 +1051,28 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
     if (std::memcmp(tr + 4, want + 4, 4) != 0) return PARSE_CORRUPT;               // codec/mod.rs:949-1017
     if (!skip_crc && std::memcmp(tr, want, 4) != 0) return PARSE_CORRUPT;
     if (consumed) *consumed = 16 + used + 8;
+    const uint8_t* cmd_ptr = scanned ? cmd_bytes.data() : mux.s[0].buf.data() + mux.s[0].start;
+    const size_t cmd_len = scanned ? cmd_bytes.size() : mux.s[0].avail();
+    const size_t lit_len = scanned ? ps.lit_size : mux.s[1].avail();
     // the literal lengths are the stream's own claim: bound them before anything is allocated for them.  A literal
     // byte costs the LIT coder at least ~0.0007 bytes (two nibbles at the largest probability the fastest
     // speed allows), so a stream claiming more than 4096 bytes per coded LIT byte is lying.  (The claims only grow along the
     // CMD stream, so the same test on a remembered final sum refuses exactly the streams the walk would have refused on the way.)
-    const uint64_t most = std::min<uint64_t>(max_output, (uint64_t)mux.s[1].avail() * 4096u + 65536u);
+    const uint64_t most = std::min<uint64_t>(max_output, (uint64_t)lit_len * 4096u + 65536u);
     auto finish = [&](uint64_t total) -> ParseStatus {
         ps.total = (size_t)total;
         // the kernels read whole 32-bit words; LIT streams are 16 + 4k bytes per chunk by construction
-        ps.lit.assign(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
-        if (ps.lit.size() % 4) return PARSE_CORRUPT;
-        if (total == 0 && !ps.lit.empty()) return PARSE_CORRUPT;
+        if (!scanned) {
+            ps.lit.assign(mux.s[1].buf.begin() + (long)mux.s[1].start, mux.s[1].buf.begin() + (long)mux.s[1].end);
+            ps.lit_size = ps.lit.size();
+        }
+        if (ps.lit_size % 4) return PARSE_CORRUPT;
+        if (total == 0 && ps.lit_size != 0) return PARSE_CORRUPT;
         return PARSE_OK;
     };
     std::string key;
     if (memo) {
-        key.assign((const char*)mux.s[0].buf.data() + mux.s[0].start, mux.s[0].avail());
+        key.assign((const char*)cmd_ptr, cmd_len);
         std::lock_guard<std::mutex> g(memo->p_->mu);
         auto it = memo->p_->map.find(key);
         if (it != memo->p_->map.end()) {
@@ -1045,7 +1086,7 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
     // CMD stream on the host
     StreamOptions o;
     CommandModel model(o);
-    RansDecoder cd(mux.s[0].buf.data() + mux.s[0].start, mux.s[0].avail());
+    RansDecoder cd(cmd_ptr, cmd_len);
     NibbleCoder nc; nc.dec = &cd;
     uint8_t btype = 0; bool have_pm = false, seen_literal = false;
     uint64_t total = 0;

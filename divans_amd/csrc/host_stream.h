@@ -6,6 +6,8 @@
 #define DIVANS_HOST_STREAM_H_
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+#include <utility>
 #include <memory>
 #include <vector>
 
@@ -91,7 +93,15 @@ class StreamDecoder {
 };
 
 enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
-struct ParsedStream { divans_lit_config cfg; size_t total = 0; std::vector<uint8_t> lit; };
+struct ParsedStream {
+    divans_lit_config cfg; size_t total = 0;
+    std::vector<uint8_t> lit;                                // the LIT coder's bytes (left empty when parse_container_host is asked for spans)
+    std::vector<std::pair<uint32_t, uint32_t>> lit_spans;    // ... or where they lie in the container: (offset, length) of every LIT slice, in order
+    size_t lit_size = 0;                                     // their total either way
+    void copy_lit(const uint8_t* container, uint8_t* dst) const {   // gathers the spans (the batch interface stages them straight into page-locked memory)
+        for (const auto& sp : lit_spans) { std::memcpy(dst, container + sp.first, sp.second); dst += sp.second; }
+    }
+};
 // What a CMD stream decodes to is a function of its bytes alone, and a batch of equal-length literal-only streams coded under the same
 // options carries the same few hundred CMD bytes in every container (PredictionMode + one literal length per ring lap): the memo keeps
 // (CMD bytes -> decoded size, LIT configuration) of the streams parsed so far, so that the 8.2 k nibbles of a PredictionMode are walked
@@ -106,8 +116,9 @@ class ParseMemo {
     Impl* p_;
 };
 // The host half of parse_container: framing + CRC + CMD coder; `ps` gets the LIT-coder bytes, the decoded size and the LIT configuration.
+// spans_only: the whole container is at hand and stays there -- the LIT bytes are not copied out, ps.lit_spans says where they are.
 ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, size_t max_output, ParsedStream& ps, size_t* consumed,
-                                 ParseMemo* memo = nullptr);
+                                 ParseMemo* memo = nullptr, bool spans_only = false);
 
 // divans_probe_container (divans_batch.h): the same walk, reporting instead of refusing
 struct divans_container_probe_fields {

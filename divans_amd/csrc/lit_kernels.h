@@ -141,6 +141,8 @@ hipError_t launch_model_encode(const LitBatch& b, bool mix, uint32_t blocks, hip
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st);
 hipError_t launch_decode(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 hipError_t launch_decode2(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
+void lit_decode_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);    // the instances the two launchers pick, as rocprofv3 spells them
+void lit_decode2_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);
 uint32_t lit_decode2_effective_caches(uint32_t dm_log2, bool mix, bool seg);   // the caches of dm_log2 a kernel instance exists for
 uint32_t lit_decode2_stream_lds(uint32_t dm_log2);   // LDS bytes one stream takes in lit_decode2_kernel (word ring + row caches)
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,

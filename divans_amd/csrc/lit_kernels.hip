@@ -23,6 +23,7 @@
 //   CTXC : the context map is constant (context = geom.ctx_const), else context comes from the LDS tables
 //   MIX  : CodecTraits::MIXING_PRIORS (specializations.rs:27-36)
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 
 #include "lit_device.h"
@@ -826,6 +827,13 @@ hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
     uint32_t blocks = (b.n_streams + RANS_THREADS - 1) / RANS_THREADS;
     hipLaunchKernelGGL(rans_encode_kernel, dim3(blocks), dim3(RANS_THREADS), 0, st, b);
     return hipGetLastError();
+}
+void lit_decode_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap) {   // as rocprofv3 spells the instance launch_decode picks
+    const int mm = effective_mm(b.geom.mm_uniform);
+    const bool seg = b.segs != nullptr;
+    const int cache = seg ? (b.cache_mode == 2u ? 2 : 0) : (b.cache_mode >= 1u && b.cache_mode <= 3u ? (int)b.cache_mode : 0);
+    snprintf(buf, cap, "divans_hip::lit_decode_kernel<%d, %s, %s, %d, %s>", mm, b.geom.ctx_const >= 0 ? "true" : "false", mix ? "true" : "false", cache,
+             seg ? "true" : "false");
 }
 hipError_t launch_decode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStream_t st) {
     const LitBatch& b = b_in;

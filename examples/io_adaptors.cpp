@@ -1,4 +1,4 @@
-// Round trips through include/divans_io.hpp, the C++ form of the reference's writer / reader adaptors
+// Round trips through examples/divans_io.hpp, the C++ form of the reference's writer / reader adaptors
 // (src/writer.rs, src/reader.rs; their own tests: writer.rs:298-420, reader.rs:329-470 -- odd chunk sizes in, odd chunk
 // sizes out, the compressed stream as an in-memory buffer).  usage: io_adaptors <input file> <out.divans>
 #include <cstdio>

@@ -73,6 +73,11 @@ int divans_batch_decompress(const divans_batch_options *opt, const uint8_t *cons
  * This returns everything; the next call builds the lanes again. */
 void divans_batch_release(void);
 
+/* Diagnostic: where the calling thread's time went in the last batch call, milliseconds: out[0] CMD coders (plans / container
+ * parsing), [1] staging into page-locked memory + enqueueing, [2] waiting for the GPU, [3] container assembly / copy-out,
+ * [4] final gather of the containers (compress only).  Overwritten by every call. */
+void divans_batch_last_phases(double *out, int n);
+
 /* Why does (or does not) this library take a container?  Host only, no GPU work: header, Mux framing, end marker, CRC-32C
  * trailer (src/codec/mod.rs:518-554), then the CMD coder's commands (src/codec/mod.rs:652-792) as far as this library decodes them.
  * `wire`: DIVANS_WIRE_HEAD = the reference tree as it stands; DIVANS_WIRE_WASM_EXAMPLE = the older build that wrote the one

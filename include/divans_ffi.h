@@ -17,7 +17,7 @@
  * it demultiplexes the container as it arrives, reads the CMD coder as far as its bytes reach and decodes the literals one or two
  * 65 536-symbol chunks at a time on the GPU as soon as the commands read so far cover them, handing the bytes out in the same call;
  * it accepts literal-only streams (one PredictionMode before the first Literal).
- * include/divans_io.hpp wraps this ABI in the reference's writer / reader adaptors (src/writer.rs, src/reader.rs).
+ * examples/divans_io.hpp wraps this ABI in the reference's writer / reader adaptors (src/writer.rs, src/reader.rs).
  */
 #ifndef DIVANS_FFI_H_
 #define DIVANS_FFI_H_

@@ -155,6 +155,9 @@ int divans_gpu_lit_stream_decode(divans_gpu_codec *c, const uint8_t *coded, size
 #define DIVANS_GPU_STATUS_BAD_STREAM 2u
 #define DIVANS_GPU_STATUS_BAD_SEGMENT 4u   /* a segment's literal block type lies outside the tables divans_gpu_codec_set_block_types built */
 int divans_gpu_codec_status(divans_gpu_codec *c, uint32_t *status);
+/* Clears the word without waiting (stream-ordered, before the launches that follow): for callers that keep a codec across calls
+ * and may have abandoned a launch sequence without reading its status. */
+int divans_gpu_codec_clear_status(divans_gpu_codec *c);
 /* Which stream: `d_flags` (device memory, >= n_streams bytes, zeroed by the caller; NULL = off) receives a 1 for every stream
  * of the following decode calls that fails that integrity check. */
 int divans_gpu_codec_set_stream_flags(divans_gpu_codec *c, uint8_t *d_flags);
@@ -203,6 +206,9 @@ typedef struct divans_gpu_info {
     float last_model_ms, last_rans_ms, last_decode_ms; /* hipEvent timings of the last batch calls */
 } divans_gpu_info;
 int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);
+/* The kernel instance the last decode call launched, spelt as rocprofv3 --kernel-trace reports it
+ * (e.g. "divans_hip::lit_decode2_kernel_w7<4, true, false, false, 17>"); "" before the first decode. */
+int divans_gpu_codec_last_decode_kernel(divans_gpu_codec *c, char *buf, size_t cap);
 /* tuning knobs: `blocks` = persistent grid of 256-thread workgroups (0 keeps the current value);
  * `cache_rows` = rows of one unified per-stream LDS row cache (0 = off, power of two in [16,256], 0xffffffff keeps). */
 int divans_gpu_codec_set_geometry(divans_gpu_codec *c, uint32_t blocks, uint32_t cache_rows);

@@ -14,6 +14,15 @@ build () {  # name, extra flags
 }
 if [ "$1" = "noperm" ]; then
   build noperm "-DDIVANS_D2_PERM=0" &
+elif [ "$1" = "dm_auto" ]; then    # the batch ABI with and without the per-batch choice of direct-mapped caches (capi.cpp)
+  OBJS2=$(ls divans_amd/build/*.o | grep -v capi)
+  /opt/rocm/bin/hipcc $FLAGS -DDIVANS_DM_AUTO_DEFAULT=0 -x hip -c divans_amd/csrc/capi.cpp -o gpurun_exp/capi_nodmauto.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_exp/libdivans_nodmauto.so $OBJS2 gpurun_exp/capi_nodmauto.o
+  rm gpurun_exp/capi_nodmauto.o
+elif [ "$1" = "pad_valu" ]; then   # +N four-cycle VALU instructions per byte: how much of the time is VALU issue?
+  build pad10 "-DDIVANS_D2_PAD_VALU=10" &
+  build pad26 "-DDIVANS_D2_PAD_VALU=26" &
+  build pad52 "-DDIVANS_D2_PAD_VALU=52" &
 elif [ "$1" = "cache_policy" ]; then
   build ldnt "-DDIVANS_D2_LOAD_AUX=2" &
   build stnt "-DDIVANS_D2_STORE_AUX=2" &

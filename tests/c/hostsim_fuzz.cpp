@@ -310,6 +310,21 @@ int main(int argc, char** argv) {
                 std::fprintf(stderr, "iteration %ld: the memo changes the parser's answer (%d vs %d)\n", it, (int)sm, (int)st); return 10;
             }
         }
+        {   // and without copying the LIT slices out (the batch interface stages them from where they lie): the same answer, the same bytes
+            divans_host::ParsedStream pp; size_t used_p = 0;
+            const divans_host::ParseStatus sp = divans_host::parse_container_host(c.data(), c.size(), skip_crc, data.size() + (1u << 20), pp, &used_p, nullptr, true);
+            bool same = sp == st;
+            if (same && st == divans_host::PARSE_OK) {
+                std::vector<uint8_t> gathered(pp.lit_size + 1);
+                for (const auto& span : pp.lit_spans) if ((size_t)span.first + span.second > c.size()) same = false;
+                if (same) {
+                    if (!pp.lit_spans.empty()) pp.copy_lit(c.data(), gathered.data()); else if (pp.lit_size) std::memcpy(gathered.data(), pp.lit.data(), pp.lit_size);
+                    gathered.resize(pp.lit_size);
+                    same = used_p == used && pp.total == ps.total && pp.lit_size == ps.lit.size() && gathered == ps.lit && std::memcmp(&pp.cfg, &ps.cfg, sizeof(ps.cfg)) == 0;
+                }
+            }
+            if (!same) { std::fprintf(stderr, "iteration %ld: the span parser disagrees with the copying parser (%d vs %d)\n", it, (int)sp, (int)st); return 11; }
+        }
         if (st == divans_host::PARSE_OK && (used > c.size() || ps.total > data.size() + (1u << 20))) { std::fprintf(stderr, "iteration %ld: parser out of bounds\n", it); return 8; }
         if (st == divans_host::PARSE_OK && o != OK) {
             // framing, CMD stream and CRC held, so only the literal decoder can have refused it (its final-state check) -- impossible while the CRC is checked

@@ -154,9 +154,9 @@ SAN_ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_s
 
 
 def test_c_harness_and_cpp_adaptors_under_sanitizers(tmp_path, corpus):
-    """tests/c/ffi_roundtrip.c (c/example.c's calling pattern with a counting allocator) and tests/c/io_adaptors.cpp
-    (include/divans_io.hpp: the reference's writer.rs / reader.rs adaptors), the programs the GPU tier links against the product
-    library, here against the harness objects: same exit codes, container == the oracle's, nothing for ASan / UBSan / LSan to report"""
+    """tests/c/ffi_roundtrip.c (c/example.c's calling pattern with a counting allocator; the GPU tier links it against the product
+    library) and examples/io_adaptors.cpp (examples/divans_io.hpp: the reference's writer.rs / reader.rs adaptors as a usage example of
+    the drop-in ABI -- this is the one tier that runs it), here against the harness objects: same exit codes, container == the oracle's, nothing for ASan / UBSan / LSan to report"""
     src = tmp_path / "in.bin"
     data = corpus[:200000]
     data.tofile(src)
@@ -165,7 +165,7 @@ def test_c_harness_and_cpp_adaptors_under_sanitizers(tmp_path, corpus):
     r = _run([exe, str(src), str(dv), "5=0", "4=2", "9=0"], env=SAN_ENV, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-3000:])
     assert (po.stream_decompress(np.fromfile(dv, dtype=np.uint8), data.size) == data).all()
-    exe = hostsim.build_program("io_adaptors", os.path.join(ROOT, "tests", "c", "io_adaptors.cpp"))
+    exe = hostsim.build_program("io_adaptors", os.path.join(ROOT, "examples", "io_adaptors.cpp"))
     dv = tmp_path / "b.divans"
     r = _run([exe, str(src), str(dv)], env=SAN_ENV, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-3000:])
