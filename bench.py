@@ -200,30 +200,33 @@ def spawn_ranks(args):
     os.execv(sys.executable, cmd)
 
 
+def alloc_packed_outputs(torch, N, L, dev):
+    """What divans_gpu_lit_encode_packed fills: the coded streams contiguous (room for 1.125 x the input: text codes to 0.46, random bytes
+    to 1.003; DIVANS_GPU_STATUS_OUTPUT_FULL = status bit 8 would say it was not enough), their offsets, sizes and total."""
+    return {"packed": torch.empty(N * (L + L // 8) + 4096, dtype=torch.uint8, device=dev),
+            "packed_offsets": torch.empty(N, dtype=torch.int64, device=dev), "sizes": torch.empty(N, dtype=torch.int32, device=dev),
+            "packed_total": torch.zeros(1, dtype=torch.int64, device=dev)}
+
+
 def timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, warmup, barrier):
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     rec = {"enc": [], "dec": [], "model": [], "rans": [], "dkern": [], "pack": []}
-    # the coded streams leave the encoder contiguous (divans_gpu_pack_streams is part of the timed encode: that is what
-    # north_star's "gather of coded streams" ships) and the decoder reads them from there
-    packed = torch.empty(outs["out"].numel(), dtype=torch.uint8, device=d_in.device)
-    poff = torch.empty(N, dtype=torch.int64, device=d_in.device)
-    ptotal = torch.zeros(1, dtype=torch.int64, device=d_in.device)
-    outs["packed"], outs["packed_offsets"], outs["packed_total"] = packed, poff, ptotal
+    # the coded streams leave the encoder contiguous (the pack launches are part of the timed encode: that is what north_star's
+    # "gather of coded streams" ships) and the decoder reads them from there
+    packed, poff, ptotal = outs["packed"], outs["packed_offsets"], outs["packed_total"]
 
     def step(record):
         # the codec launches on torch's current stream, so these events bracket its kernels
         ev[0].record()
-        codec.encode_batch(d_in, N, L, outs)
-        ev[3].record()
-        codec.pack_into(outs, N, packed, poff, ptotal)
+        codec.encode_packed(d_in, N, L, packed, poff, outs["sizes"], ptotal)
         ev[1].record()
         codec.decode_batch(packed, poff, outs["sizes"], N, L, d_back)
         ev[2].record()
         if record:
             torch.cuda.synchronize()
-            rec["enc"].append(ev[0].elapsed_time(ev[1])); rec["dec"].append(ev[1].elapsed_time(ev[2])); rec["pack"].append(ev[3].elapsed_time(ev[1]))
+            rec["enc"].append(ev[0].elapsed_time(ev[1])); rec["dec"].append(ev[1].elapsed_time(ev[2]))
             inf = codec.info()   # hipEvent timings taken inside the C ABI around each kernel launch, on the launch stream
-            rec["model"].append(inf.last_model_ms); rec["rans"].append(inf.last_rans_ms); rec["dkern"].append(inf.last_decode_ms)
+            rec["model"].append(inf.last_model_ms); rec["rans"].append(inf.last_rans_ms); rec["dkern"].append(inf.last_decode_ms); rec["pack"].append(inf.last_pack_ms)
 
     for _ in range(warmup):
         step(False)
@@ -240,20 +243,20 @@ def verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, n_check)
     skipped work), outside the timed region: exact round trip of every stream + coded bytes == oracle on a spread of
     n_check streams (the oracle encodes them on every usable host core, oracle/literal.c orc_lit_batch_check)."""
     import numpy as np
-    codec.encode_batch(d_in, N, L, outs)
-    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
+    codec.encode_packed(d_in, N, L, outs["packed"], outs["packed_offsets"], outs["sizes"], outs["packed_total"])
+    codec.decode_batch(outs["packed"], outs["packed_offsets"], outs["sizes"], N, L, d_back)
     torch.cuda.synchronize()
     ok = bool(torch.equal(d_back, d_in)) and codec.status() == 0
     picks = sorted(set([0, N // 2, N - 1] + list(range(0, N, max(1, N // max(n_check, 1))))))
     idx = torch.tensor(picks, dtype=torch.int64, device=d_in.device)
     host_in = d_in[idx].cpu().numpy()
-    offs = outs["offsets"][idx].cpu().numpy().astype(np.int64); sz = outs["sizes"][idx].cpu().numpy().astype(np.int64)
+    offs = outs["packed_offsets"][idx].cpu().numpy().astype(np.int64); sz = outs["sizes"][idx].cpu().numpy().astype(np.int64)
     # gather the picked streams' coded bytes into one host blob
     starts = np.concatenate([[0], np.cumsum(sz[:-1])]).astype(np.int64)
     pos = torch.arange(int(sz.sum()), device=d_in.device, dtype=torch.int64)
     seg = torch.repeat_interleave(torch.arange(len(picks), device=d_in.device), torch.tensor(sz, device=d_in.device))
     src = torch.tensor(offs, device=d_in.device)[seg] + (pos - torch.tensor(starts, device=d_in.device)[seg])
-    blob = outs["out"][src].cpu().numpy()
+    blob = outs["packed"][src].cpu().numpy()
     bad, first = po.lit_batch_check(ocfg, host_in, blob, starts.astype(np.uint64), sz.astype(np.uint32), threads=usable_parallelism()["usable"])
     if bad:
         sys.stderr.write(f"bench: {bad} of {len(picks)} checked streams differ from the oracle, first: stream {picks[first]}\n")
@@ -279,7 +282,7 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     if args.split_cache:
         hi_rows, lo_rows = (int(x) for x in args.split_cache.split(","))
         codec.set_split_cache(hi_rows, lo_rows)
-    outs = codec.alloc_encode_outputs(N, L)
+    outs = alloc_packed_outputs(torch, N, L, dev)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
     ok, checked = True, 0
     if not args.no_verify:

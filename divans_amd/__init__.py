@@ -86,6 +86,7 @@ class GpuInfo(ctypes.Structure):
         ("blocks", ctypes.c_uint32), ("threads", ctypes.c_uint32),
         ("table_bytes", ctypes.c_uint64), ("scratch_bytes", ctypes.c_uint64),
         ("last_model_ms", ctypes.c_float), ("last_rans_ms", ctypes.c_float), ("last_decode_ms", ctypes.c_float),
+        ("last_pack_ms", ctypes.c_float),
     ]
 
 
@@ -149,7 +150,10 @@ def load_library():
     L.divans_gpu_lit_stream_decode.argtypes = [vp, vp, ctypes.c_size_t, u32, u64, vp, ctypes.POINTER(ctypes.c_size_t)]
     L.divans_gpu_speed_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
     L.divans_gpu_speed_supported.restype = ctypes.c_int
+    L.divans_gpu_speed_accepted.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    L.divans_gpu_speed_accepted.restype = ctypes.c_int
     L.divans_gpu_codec_status.argtypes = [vp, ctypes.POINTER(u32)]
+    L.divans_gpu_lit_encode_packed.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp, vp, vp, u32]
     L.divans_gpu_selftest_cdf_ops.argtypes = [vp, vp, u32, vp]
     L.divans_gpu_selftest_rans_pairs.argtypes = [vp, vp, u32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.divans_gpu_codec_set_block_types.argtypes = [vp, u32]
@@ -184,10 +188,10 @@ def exported_symbols():
     return [
         "divans_lit_config_simple", "divans_lit_config_context_mixing", "divans_gpu_codec_create",
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
-        "divans_gpu_lit_encode_batch", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
+        "divans_gpu_lit_encode_batch", "divans_gpu_lit_encode_packed", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
-        "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
+        "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
         "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
@@ -289,6 +293,11 @@ def config_context_mixing():
 def speed_supported(inc, lim):
     """True when (inc, lim) is a literal_adaptation speed the GPU coder accepts (no row count ever leaves i16 under it)."""
     return bool(load_library().divans_gpu_speed_supported(int(inc), int(lim)))
+
+
+def speed_accepted(inc, lim):
+    """divans_gpu_speed_accepted: the codec takes the speed (possibly on the wrap-checked streaming kernels)"""
+    return bool(load_library().divans_gpu_speed_accepted(int(inc), int(lim)))
 
 
 def encode_bound(n):
@@ -425,6 +434,15 @@ class LiteralCodec:
             in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams),
             outputs["out"].data_ptr(), int(outputs["slot"]), outputs["offsets"].data_ptr(),
             outputs["sizes"].data_ptr()), "divans_gpu_lit_encode_batch")
+
+    def encode_packed(self, d_in, n_streams, stream_len, packed, packed_offsets, sizes, total, in_offsets=None, in_sizes=None, sub_batch=0):
+        """divans_gpu_lit_encode_packed: coded streams contiguous in the uint8 tensor `packed` (int64 `packed_offsets`, int32 `sizes`,
+        int64[1] `total`), coded in sub-batches through slots the codec owns.  status() & 8: they did not fit."""
+        _check(self._lib.divans_gpu_lit_encode_packed(
+            self._h, d_in.data_ptr(), in_offsets.data_ptr() if in_offsets is not None else None,
+            in_sizes.data_ptr() if in_sizes is not None else None, int(stream_len), int(n_streams),
+            packed.data_ptr(), int(packed.numel()), packed_offsets.data_ptr(), sizes.data_ptr(), total.data_ptr(), int(sub_batch)),
+            "divans_gpu_lit_encode_packed")
 
     def set_block_types(self, n_btypes):
         """Context tables for literal block types 0 .. n_btypes-1 (general streams with BlockSwitchLiteral commands)."""

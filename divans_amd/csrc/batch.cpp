@@ -27,6 +27,9 @@
 #include <vector>
 
 #include <sched.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "host_stream.h"
 
@@ -153,6 +156,29 @@ struct PinnedBuf {
 // ---- length classes and slices ---------------------------------------------------------------------------------------
 // class bound of a stream length: 65536 for everything up to 64 KiB (one codec with the bucketed encoder passes), then the
 // next power of two
+// A copy whose destination will not be read again by this thread (decoded payloads into the caller's buffer, coded bytes into
+// page-locked staging memory): streaming stores spare the read-for-ownership of every destination line -- a third of the memory
+// traffic of a plain memcpy for blocks far larger than any cache share.
+void stream_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+#if defined(__SSE2__)
+    if (n >= 4096) {
+        const size_t head = (size_t)(-(intptr_t)dst) & 63u;
+        std::memcpy(dst, src, head); dst += head; src += head; n -= head;
+        const size_t blocks = n / 64;
+        for (size_t i = 0; i < blocks; ++i) {
+            const __m128i a = _mm_loadu_si128((const __m128i*)(src) + 0), b = _mm_loadu_si128((const __m128i*)(src) + 1);
+            const __m128i c = _mm_loadu_si128((const __m128i*)(src) + 2), d = _mm_loadu_si128((const __m128i*)(src) + 3);
+            _mm_stream_si128((__m128i*)(dst) + 0, a); _mm_stream_si128((__m128i*)(dst) + 1, b);
+            _mm_stream_si128((__m128i*)(dst) + 2, c); _mm_stream_si128((__m128i*)(dst) + 3, d);
+            src += 64; dst += 64;
+        }
+        _mm_sfence();
+        n -= blocks * 64;
+    }
+#endif
+    std::memcpy(dst, src, n);
+}
+
 uint32_t class_bound(size_t len) {
     uint32_t b = 65536u;
     while ((size_t)b < len) b <<= 1;
@@ -366,7 +392,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
             uint64_t* off = L.h_off.as<uint64_t>(); uint32_t* sz = L.h_sz.as<uint32_t>(); uint8_t* dst = L.h_in.as<uint8_t>();
             uint64_t pos = 0;
             for (size_t j = 0; j < m; ++j) { off[j] = pos; sz[j] = (uint32_t)sizes[s.members[j]]; pos += sizes[s.members[j]]; }
-            parallel_for(m, opt->host_threads, [&](size_t j) { if (sz[j]) std::memcpy(dst + off[j], inputs[s.members[j]], sz[j]); });
+            parallel_for(m, opt->host_threads, [&](size_t j) { if (sz[j]) stream_copy(dst + off[j], inputs[s.members[j]], sz[j]); });
         }
         divans_gpu_codec* codec = nullptr;
         int r = L.codec_for(probe.cfg, s.bound, opt->device, m, &codec); if (r) return r;
@@ -449,7 +475,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     size_t pos = 0;
     for (size_t i = 0; i < n_streams; ++i) { out_offsets[i] = pos; out_sizes[i] = results[i].size(); pos += results[i].size(); }
     if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
-    parallel_for(n_streams, opt->host_threads, [&](size_t i) { std::memcpy(out + out_offsets[i], results[i].data(), results[i].size()); });
+    parallel_for(n_streams, opt->host_threads, [&](size_t i) { stream_copy(out + out_offsets[i], results[i].data(), results[i].size()); });
     const double t_end = now_ms();
     ov.host(t_out0, t_end); g_phases[PH_GATHER] += t_end - t_out0;
     if (timing) {
@@ -485,7 +511,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     divans_host::ParseMemo memo;     // equal-length streams of one producer carry the same CMD bytes: decode them once (host_stream.h)
     size_t pos = 0;
 
-    struct Group { divans_lit_config cfg; uint32_t bound; std::vector<size_t> members; size_t in_bytes = 0, out_bytes = 0, in_base = 0, out_base = 0, idx_base = 0; };
+    struct Group { divans_lit_config cfg; int cfg_id; uint32_t bound; std::vector<size_t> members; size_t in_bytes = 0, out_bytes = 0, in_base = 0, out_base = 0, idx_base = 0; };
     std::vector<std::vector<Group>> slice_groups;
 
     // What a decoding slice costs on the device: its coded bytes in, its decoded bytes out, offsets / sizes / flags.  (The codec's
@@ -529,8 +555,9 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             if (parsed[i].total == 0) continue;
             const uint32_t bound = class_bound(parsed[i].total);
             Group* g = nullptr;
-            for (auto& q : groups) if (q.bound == bound && std::memcmp(&q.cfg, &parsed[i].cfg, sizeof(divans_lit_config)) == 0) { g = &q; break; }
-            if (!g) { groups.emplace_back(); g = &groups.back(); g->cfg = parsed[i].cfg; g->bound = bound; }
+            for (auto& q : groups)    // the memo's configuration ids spare the 25 KB comparison per container
+                if (q.bound == bound && ((q.cfg_id >= 0 && q.cfg_id == parsed[i].cfg_id) || ((q.cfg_id < 0 || parsed[i].cfg_id < 0) && std::memcmp(&q.cfg, &parsed[i].cfg, sizeof(divans_lit_config)) == 0))) { g = &q; break; }
+            if (!g) { groups.emplace_back(); g = &groups.back(); g->cfg = parsed[i].cfg; g->cfg_id = parsed[i].cfg_id; g->bound = bound; }
             g->members.push_back(i); g->in_bytes += parsed[i].lit_size; g->out_bytes += parsed[i].total;
         }
         if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
@@ -613,7 +640,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             }
             parallel_for(g.members.size(), opt->host_threads, [&](size_t j) {
                 const size_t i = g.members[j];
-                std::memcpy(out + out_offsets[i], L.h_out.as<uint8_t>() + g.out_base + L.h_ooff.as<uint64_t>()[g.idx_base + j], parsed[i].total);
+                stream_copy(out + out_offsets[i], L.h_out.as<uint8_t>() + g.out_base + L.h_ooff.as<uint64_t>()[g.idx_base + j], parsed[i].total);
             });
         }
         for (size_t i = b; i < e; ++i) { std::vector<uint8_t>().swap(parsed[i].lit); std::vector<std::pair<uint32_t, uint32_t>>().swap(parsed[i].lit_spans); }

@@ -120,7 +120,11 @@ struct divans_gpu_codec {
     // bucketed encoder model pass (lit_bucket.hip)
     bool bucket_ok = false;       // the configuration allows it: order-1 rows (see configure_from_geometry), no mixing, streams <= 64 KiB
     bool bucket_mix_ok = false;   // two-model configuration the bucketed pass of lit_bucket_mix.hip covers
-    uint32_t bucket_mix_batch = 32768;   // streams per launch sequence of that pass
+    uint32_t bucket_mix_batch = 32768;   // streams per launch sequence of the bucketed passes (work arrays are sized for this many)
+    uint8_t* d_slots = nullptr; size_t slots_bytes = 0;      // divans_gpu_lit_encode_packed: right-aligned output slots of ONE sub-batch
+    uint64_t* d_slot_off = nullptr; size_t slot_off_cap = 0;
+    std::vector<hipEvent_t> ev_span; size_t enc_spans = 0;   // ... and its events: per sub-batch (start, before the pack, end)
+    float last_pack_ms = 0;
     uint32_t encode_path = 0;     // 0 automatic (bucketed when bucket_ok), 1 streaming kernels, 2 bucketed
     uint8_t* d_bk = nullptr;      size_t bk_bytes = 0; uint32_t bk_streams = 0;
     uint8_t* d_rs = nullptr;      size_t rs_bytes = 0;
@@ -138,14 +142,13 @@ struct divans_gpu_codec {
     bool timing_pending_enc = false, timing_pending_dec = false;
 };
 
-// A speed the kernels can run: every count of a row stays inside i16 for ever.  blend (probability/frequentist_cdf.rs:74-85) adds
-// `inc` to cdf[15] on every update whatever the symbol and then takes a quarter off once if the total reached `lim`, so the total
-// follows ONE trajectory from the default row's 64 -- with a large `inc` it settles near 4 * inc, far above `lim` -- and the
-// other entries stay below it.  The reference's i16 arithmetic wraps where this leaves 32767 (its row total turns negative and
-// the (start, freq) it derives stop describing a distribution); the kernels' 32-bit lanes do not, so such speeds are refused
-// instead of coded differently.
+// A speed whose every row count stays inside i16 for ever.  blend (probability/frequentist_cdf.rs:74-85) adds `inc` to cdf[15] on
+// every update whatever the symbol and then takes a quarter off once if the total reached `lim`, so the total follows ONE trajectory
+// from the default row's 64 -- with a large `inc` it settles near 4 * inc, far above `lim` -- and the other entries stay below it.
+// Such speeds run on every kernel (the reference's debug_asserts `inc, lim <= 0x4000`, probability/interface.rs:341-365, are not
+// part of a release build and no arithmetic needs them: only the trajectory counts).
 extern "C" int divans_gpu_speed_supported(int32_t inc, int32_t lim) {
-    if (inc < 0 || lim <= 0 || inc > 0x4000 || lim > 0x4000) return 0;     // probability/interface.rs:341-365 (debug_asserts)
+    if (inc < 0 || inc > 0x7fff || lim < -0x8000 || lim > 0x7fff) return 0;
     std::vector<uint8_t> seen(32768, 0);
     int32_t v = 64;
     while (!seen[v]) {
@@ -160,6 +163,16 @@ extern "C" int divans_gpu_speed_supported(int32_t inc, int32_t lim) {
     }
     return 1;
 }
+// A speed the coder takes at all: every i16 pair with inc >= 0, i.e. everything the wire format's f8 pairs decode to except a negative
+// increment (rows that count DOWN leave the valid range at their first update; nothing writes such a stream).  Where the trajectory
+// above leaves i16 the reference's total wraps negative and the NEXT nibble coded with that row is no longer a distribution
+// (ans.rs:281-285): a stream in which that happens cannot be read back by the reference itself, one in which it does not -- short
+// streams, rows that wrap on their last update -- is coded exactly as the reference codes it.  These speeds run on the streaming
+// kernels without row caches (LitGeometry::wrap_check), which report a stream that codes with a wrapped row: status bit BAD_MODEL
+// when encoding, BAD_STREAM (+ the per-stream flag) when decoding.
+extern "C" int divans_gpu_speed_accepted(int32_t inc, int32_t lim) {
+    return inc >= 0 && inc <= 0x7fff && lim >= -0x8000 && lim <= 0x7fff;
+}
 
 // Tables are built for the literal block types [bt_first, bt_first + n_btypes): one for a batch of single-segment
 // streams (cfg.btype), all of 0..max for streams with BlockSwitchLiteral commands between their segments.
@@ -170,8 +183,8 @@ static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint
     if (cfg.context_mixing >= 15) return fail(DIVANS_GPU_EINVAL, "context_mixing must be < 15 (codec/interface.rs:359)");
     for (int i = 0; i < 4; ++i) {
         const divans_speed s = cfg.literal_adaptation[i];
-        if (!divans_gpu_speed_supported(s.inc, s.lim))
-            return fail(DIVANS_GPU_EINVAL, "literal_adaptation speed outside the supported range (divans_gpu_speed_supported)");
+        if (!divans_gpu_speed_accepted(s.inc, s.lim))
+            return fail(DIVANS_GPU_EINVAL, "literal_adaptation speed with a negative increment (divans_gpu_speed_accepted)");
     }
     const uint32_t mix_off = LIT_BLOB_CTXF + LIT_CTXF_BYTES * n_btypes;
     blob.assign(mix_off + DIVANS_GPU_NUM_MIXING_VALUES, 0);
@@ -236,12 +249,19 @@ static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint
     g.inc1 = cfg.literal_adaptation[1].inc; g.lim1 = cfg.literal_adaptation[1].lim;
     g.inc2 = cfg.literal_adaptation[2].inc; g.lim2 = cfg.literal_adaptation[2].lim;
     g.inc3 = cfg.literal_adaptation[3].inc; g.lim3 = cfg.literal_adaptation[3].lim;
+    // speeds [1] is never read by the literal coder (literal.rs:320,354 use [0] for both nibbles); [2] / [3] only with mixing
+    g.wrap_check = 0;
+    const bool mixing = cfg.context_mixing > 1;
+    for (int i = 0; i < 4; ++i) {
+        if (i == 1 || (!mixing && i >= 2)) continue;
+        if (!divans_gpu_speed_supported(cfg.literal_adaptation[i].inc, cfg.literal_adaptation[i].lim)) g.wrap_check = 1;
+    }
     return 0;
 }
 
 static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
-    // 0 none, 1 unified, 2 high-nibble rows only, 3 separate high / low caches
-    if (c->cache_high == 0) { b.cache_mode = 0; b.cache_rows_high = b.cache_rows_low = 0; }   // (a low-only cache is not offered)
+    // 0 none, 1 unified, 2 high-nibble rows only, 3 separate high / low caches; wrap_check: the post-stream scan reads the table in HBM
+    if (c->cache_high == 0 || c->geom.wrap_check) { b.cache_mode = 0; b.cache_rows_high = b.cache_rows_low = 0; }   // (a low-only cache is not offered)
     else if (c->cache_unified) { b.cache_mode = 1; b.cache_rows_high = c->cache_high; b.cache_rows_low = 0; }
     else if (c->cache_low == 0) { b.cache_mode = 2; b.cache_rows_high = c->cache_high; b.cache_rows_low = 0; }
     else { b.cache_mode = 3; b.cache_rows_high = c->cache_high; b.cache_rows_low = c->cache_low; }
@@ -249,7 +269,7 @@ static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
 }
 
 static uint32_t groups_per_block(const divans_gpu_codec*) { return LIT_THREADS / 16; }
-static bool use_decode2(const divans_gpu_codec* c) { return c->decode_gen == 2u && c->blocks2 != 0u; }
+static bool use_decode2(const divans_gpu_codec* c) { return c->decode_gen == 2u && c->blocks2 != 0u && !c->geom.wrap_check; }
 static uint32_t resident_groups(const divans_gpu_codec* c) { return std::max(c->blocks, use_decode2(c) ? c->blocks2 : 0u) * groups_per_block(c); }
 
 static int ensure_tables(divans_gpu_codec* c) {
@@ -360,6 +380,9 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->d_bk) (void)hipFree(c->d_bk);
+    if (c->d_slots) (void)hipFree(c->d_slots);
+    if (c->d_slot_off) (void)hipFree(c->d_slot_off);
+    for (hipEvent_t e : c->ev_span) (void)hipEventDestroy(e);
     if (c->d_rs) (void)hipFree(c->d_rs);
     if (c->d_sp) (void)hipFree(c->d_sp);
     if (c->d_wstate) (void)hipFree(c->d_wstate);
@@ -380,8 +403,8 @@ static uint32_t bucket_pieces(const divans_gpu_codec* c) { return (c->max_stream
 // the power-of-two stride changes nothing (profiles/r02c), so it stays 0.
 constexpr uint32_t BUCKET_SLOT_PAD = 0;
 static uint32_t bucket_slot(const divans_gpu_codec* c) { return bucket_pieces(c) * 8192u + BUCKET_SLOT_PAD; }
-static bool use_bucket_mix(const divans_gpu_codec* c) { return c->bucket_mix_ok && c->encode_path != 1u; }
-static bool use_bucket(const divans_gpu_codec* c) { return c->bucket_ok && c->encode_path != 1u; }   // task ids are stream * 256 + byte in 32 bits: callers keep n_streams < 2^24
+static bool use_bucket_mix(const divans_gpu_codec* c) { return c->bucket_mix_ok && c->encode_path != 1u && !c->geom.wrap_check; }
+static bool use_bucket(const divans_gpu_codec* c) { return c->bucket_ok && c->encode_path != 1u && !c->geom.wrap_check; }   // task ids are stream * 256 + byte in 32 bits: callers keep n_streams < 2^24
 
 // one allocation carved into the five work arrays of BucketBatch
 static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b) {
@@ -599,17 +622,26 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
     if (use_bucket(c) && n_streams < (1u << 24) && !d_segs) {   // segment lists (context reloads between Literal commands) go through the streaming kernels
         BucketBatch k;
         std::memset(&k, 0, sizeof(k));
-        rc = ensure_bucket(c, n_streams, k); if (rc) return rc;
-        k.in = d_in; k.in_offsets = d_in_offsets; k.in_sizes = d_in_sizes;
-        k.n_streams = n_streams; k.stream_len = stream_len; k.max_stream_len = c->max_stream_len;
+        // launch sequences of at most bucket_mix_batch streams (work arrays are sized for one of them: 11.2 bytes per input byte of
+        // 32 768 streams instead of the whole batch's; whatever consumes the pairs is enqueued in between, as in the two-model pass)
+        const uint32_t sub = std::min(n_streams, c->bucket_mix_batch);
+        rc = ensure_bucket(c, sub, k); if (rc) return rc;
+        k.stream_len = stream_len; k.max_stream_len = c->max_stream_len;
         k.pieces = bucket_pieces(c); k.slot = bucket_slot(c);
         k.sf = (uint32_t*)k.sfs; k.sf_stride = 2u * k.slot;     // bucket_unsort_kernel works in place
         k.inc = c->geom.inc0; k.lim = c->geom.lim0;
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        HIP_TRY(launch_bucket_model(k, c->num_cus * 4u, c->stream));
         view.sf = k.sf; view.stride = k.sf_stride;
-        view.spare = (uint8_t*)k.inv; view.spare_bytes = (size_t)n_streams * k.slot * 3u;
-        return after(0u, n_streams, view);
+        view.spare = (uint8_t*)k.inv; view.spare_bytes = (size_t)sub * k.slot * 3u;
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        for (uint32_t s0 = 0; s0 < n_streams; s0 += sub) {
+            k.n_streams = std::min(sub, n_streams - s0);
+            k.in = d_in_offsets ? d_in : d_in + (size_t)s0 * stream_len;
+            k.in_offsets = d_in_offsets ? d_in_offsets + s0 : nullptr;
+            k.in_sizes = d_in_sizes ? d_in_sizes + s0 : nullptr;
+            HIP_TRY(launch_bucket_model(k, c->num_cus * 4u, c->stream));
+            rc = after(s0, k.n_streams, view); if (rc) return rc;
+        }
+        return 0;
     }
     if (use_bucket_mix(c) && !d_segs) {
         MixBucketBatch k;
@@ -665,6 +697,28 @@ static int rans_event_pair(divans_gpu_codec* c, size_t i, hipEvent_t*& pair) {
     return 0;
 }
 
+// Encoder pass 2 for `count` streams whose pairs the model pass left in `v`: coded bytes right-aligned in their slots at `out`
+// (`out_base` = where `out` lies in the buffer the reported offsets refer to).
+static int rans_pass(divans_gpu_codec* c, const SfView& v, uint32_t count, uint32_t stream_len, const uint32_t* d_in_sizes, uint8_t* out, uint64_t out_base,
+                     uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes, uint32_t* d_chunk_bytes, uint32_t max_chunks, size_t& pairs) {
+    const bool chunk_lanes = c->max_stream_len > 32768u && c->max_stream_len <= 65536u;   // two chunks per stream slot: one lane per chunk
+    RansBatch r;
+    r.sf = v.sf; r.sf_stride = v.stride; r.n_streams = count; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
+    r.in_sizes = d_in_sizes;
+    r.out = out; r.out_base = out_base; r.out_slot = out_slot;
+    r.out_offsets = d_out_offsets; r.out_sizes = d_out_sizes;
+    r.status = c->d_status; r.chunk_bytes = d_chunk_bytes; r.max_chunks = max_chunks;
+    r.scratch = nullptr; r.scratch_stride = 0; r.chunk0_sizes = nullptr;
+    if (chunk_lanes) { int rr = ensure_rans_scratch(c, count, v, r); if (rr) return rr; }
+    hipEvent_t* pair = nullptr;
+    int rr = rans_event_pair(c, pairs, pair); if (rr) return rr;
+    HIP_TRY(hipEventRecord(pair[0], c->stream));
+    HIP_TRY(launch_rans_encode(r, c->stream));
+    HIP_TRY(hipEventRecord(pair[1], c->stream));
+    ++pairs;
+    return 0;
+}
+
 static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                              const uint32_t* d_in_sizes, uint32_t stream_len, uint32_t n_streams,
                              uint8_t* d_out, uint64_t out_slot, uint64_t* d_out_offsets, uint32_t* d_out_sizes,
@@ -691,29 +745,59 @@ static int encode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     if (out_slot % 16 != 0 || out_slot < divans_gpu_lit_encode_bound(d_in_sizes ? c->max_stream_len : stream_len))
         return fail(DIVANS_GPU_ECAP, "out_slot must be a multiple of 16 and >= divans_gpu_lit_encode_bound()");
     HIP_TRY(hipSetDevice(c->device));
-    const bool chunk_lanes = c->max_stream_len > 32768u && c->max_stream_len <= 65536u;   // two chunks per stream slot: one lane per chunk
     size_t pairs = 0;
     int rc = model_pass(c, d_in, d_in_offsets, d_in_sizes, stream_len, n_streams, d_seg_begin, d_segs,
                         [&](uint32_t first, uint32_t count, const SfView& v) -> int {
-        RansBatch r;
-        r.sf = v.sf; r.sf_stride = v.stride; r.n_streams = count; r.stream_len = stream_len; r.max_stream_len = c->max_stream_len;
-        r.in_sizes = d_in_sizes ? d_in_sizes + first : nullptr;
-        r.out = d_out + (uint64_t)first * out_slot; r.out_base = (uint64_t)first * out_slot; r.out_slot = out_slot;
-        r.out_offsets = d_out_offsets + first; r.out_sizes = d_out_sizes + first;
-        r.status = c->d_status; r.chunk_bytes = d_chunk_bytes ? d_chunk_bytes + (size_t)first * max_chunks : nullptr; r.max_chunks = max_chunks;
-        r.scratch = nullptr; r.scratch_stride = 0; r.chunk0_sizes = nullptr;
-        if (chunk_lanes) { int rr = ensure_rans_scratch(c, count, v, r); if (rr) return rr; }
-        hipEvent_t* pair = nullptr;
-        int rr = rans_event_pair(c, pairs, pair); if (rr) return rr;
-        HIP_TRY(hipEventRecord(pair[0], c->stream));
-        HIP_TRY(launch_rans_encode(r, c->stream));
-        HIP_TRY(hipEventRecord(pair[1], c->stream));
-        ++pairs;
-        return 0;
+        return rans_pass(c, v, count, stream_len, d_in_sizes ? d_in_sizes + first : nullptr, d_out + (uint64_t)first * out_slot, (uint64_t)first * out_slot, out_slot,
+                         d_out_offsets + first, d_out_sizes + first, d_chunk_bytes ? d_chunk_bytes + (size_t)first * max_chunks : nullptr, max_chunks, pairs);
     });
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    c->rans_pairs = pairs;
+    c->rans_pairs = pairs; c->enc_spans = 0;
+    c->timing_pending_enc = true;
+    return 0;
+}
+
+// Coded streams contiguous, through slots that hold ONE sub-batch (include/divans_gpu.h).
+extern "C" int divans_gpu_lit_encode_packed(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes,
+                                            uint32_t stream_len, uint32_t n_streams, uint8_t* d_packed, uint64_t packed_cap,
+                                            uint64_t* d_packed_offsets, uint32_t* d_sizes, uint64_t* d_total, uint32_t sub_batch) {
+    if (!c || !d_in || !d_packed || !d_packed_offsets || !d_sizes || !d_total) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if ((d_in_offsets == nullptr) != (d_in_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
+    if (stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "stream_len exceeds the codec's max_stream_len");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), c->stream));
+    if (n_streams == 0) return 0;
+    const uint64_t slot = divans_gpu_lit_encode_bound(d_in_sizes ? c->max_stream_len : stream_len);
+    uint32_t sub = std::min(n_streams, sub_batch ? sub_batch : c->bucket_mix_batch);
+    while ((uint64_t)sub * slot > ((uint64_t)1 << 36) && sub > 1024u) sub = (sub + 1u) / 2u;      // at most 64 GiB of slots
+    if ((size_t)sub * slot > c->slots_bytes) {
+        if (c->d_slots) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_slots)); c->d_slots = nullptr; c->slots_bytes = 0; }
+        if (hipMalloc(&c->d_slots, (size_t)sub * slot) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(output slots of a sub-batch) failed");
+        c->slots_bytes = (size_t)sub * slot;
+    }
+    if (sub > c->slot_off_cap) {
+        if (c->d_slot_off) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_slot_off)); c->d_slot_off = nullptr; c->slot_off_cap = 0; }
+        if (hipMalloc(&c->d_slot_off, (size_t)sub * sizeof(uint64_t)) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(slot offsets) failed");
+        c->slot_off_cap = sub;
+    }
+    const size_t n_sub = (n_streams + sub - 1u) / sub;
+    while (c->ev_span.size() < 3u * n_sub) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); c->ev_span.push_back(e); }
+    size_t pairs = 0, span = 0;
+    for (uint32_t b0 = 0; b0 < n_streams; b0 += sub, ++span) {
+        const uint32_t m = std::min(sub, n_streams - b0);
+        HIP_TRY(hipEventRecord(c->ev_span[3u * span], c->stream));
+        int rc = model_pass(c, d_in_offsets ? d_in : d_in + (size_t)b0 * stream_len, d_in_offsets ? d_in_offsets + b0 : nullptr, d_in_sizes ? d_in_sizes + b0 : nullptr,
+                            stream_len, m, nullptr, nullptr, [&](uint32_t first, uint32_t count, const SfView& v) -> int {
+            return rans_pass(c, v, count, stream_len, d_in_sizes ? d_in_sizes + b0 + first : nullptr, c->d_slots + (uint64_t)first * slot, (uint64_t)first * slot, slot,
+                             c->d_slot_off + first, d_sizes + b0 + first, nullptr, 0, pairs);
+        });
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_span[3u * span + 1u], c->stream));
+        HIP_TRY(launch_pack(c->d_slots, c->d_slot_off, d_sizes + b0, m, d_packed, d_packed_offsets + b0, d_total, c->stream, true, packed_cap, c->d_status));
+        HIP_TRY(hipEventRecord(c->ev_span[3u * span + 2u], c->stream));
+    }
+    c->rans_pairs = pairs; c->enc_spans = span;
     c->timing_pending_enc = true;
     return 0;
 }
@@ -825,6 +909,22 @@ extern "C" int divans_gpu_pack_streams(divans_gpu_codec* c, const uint8_t* d_slo
 extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info) {
     if (!c || !info) return fail(DIVANS_GPU_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->timing_pending_enc && c->enc_spans) {      // divans_gpu_lit_encode_packed: per sub-batch (start, before the pack, end)
+        HIP_TRY(hipEventSynchronize(c->ev_span[3u * c->enc_spans - 1u]));
+        float coding = 0.f, pack = 0.f, rans = 0.f;
+        for (size_t i = 0; i < c->enc_spans; ++i) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, c->ev_span[3u * i], c->ev_span[3u * i + 1u])); coding += t;
+            HIP_TRY(hipEventElapsedTime(&t, c->ev_span[3u * i + 1u], c->ev_span[3u * i + 2u])); pack += t;
+        }
+        for (size_t i = 0; i < c->rans_pairs; ++i) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, c->ev_rans[2u * i], c->ev_rans[2u * i + 1u]));
+            rans += t;
+        }
+        c->last_rans_ms = rans; c->last_model_ms = coding - rans; c->last_pack_ms = pack;
+        c->timing_pending_enc = false;
+    }
     if (c->timing_pending_enc) {
         HIP_TRY(hipEventSynchronize(c->ev[2]));
         float total = 0.f, rans = 0.f;
@@ -846,7 +946,8 @@ extern "C" int divans_gpu_codec_info(divans_gpu_codec* c, divans_gpu_info* info)
     info->resident_groups = resident_groups(c);
     info->blocks = c->blocks; info->threads = LIT_THREADS;
     info->table_bytes = (uint64_t)resident_groups(c) * c->geom.total_rows * 32u;
-    info->scratch_bytes = c->sf_bytes + c->bk_bytes + c->rs_bytes;
+    info->scratch_bytes = c->sf_bytes + c->bk_bytes + c->rs_bytes + c->slots_bytes;
+    info->last_pack_ms = c->last_pack_ms;
     info->last_model_ms = c->last_model_ms; info->last_rans_ms = c->last_rans_ms; info->last_decode_ms = c->last_decode_ms;
     return 0;
 }

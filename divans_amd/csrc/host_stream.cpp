@@ -992,10 +992,18 @@ int StreamEncoder::flush(uint8_t* out, size_t cap, size_t* out_off) {   // divan
 }
 
 struct ParseMemo::Impl {
-    struct Entry { uint64_t total; divans_lit_config cfg; };
+    struct Entry { uint64_t total; int cfg_id; };
     std::mutex mu;
-    std::unordered_map<std::string, std::unique_ptr<Entry>> map;
-    static constexpr size_t kMaxEntries = 256;      // 25 KB each (the configuration); a batch of all-different lengths stops adding
+    std::unordered_map<std::string, Entry> map;
+    std::vector<std::unique_ptr<divans_lit_config>> cfgs;   // the distinct LIT configurations seen (25 KB each): entries name one by index
+    static constexpr size_t kMaxEntries = 65536;    // ~100 bytes each: a batch of all-different lengths still fits
+    static constexpr size_t kMaxConfigs = 64;
+    int intern(const divans_lit_config& c) {        // under mu
+        for (size_t i = 0; i < cfgs.size(); ++i) if (std::memcmp(cfgs[i].get(), &c, sizeof(c)) == 0) return (int)i;
+        if (cfgs.size() >= kMaxConfigs) return -1;
+        cfgs.emplace_back(new divans_lit_config(c));
+        return (int)cfgs.size() - 1;
+    }
 };
 ParseMemo::ParseMemo() : p_(new Impl()) {}
 ParseMemo::~ParseMemo() { delete p_; }
@@ -1076,10 +1084,10 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
         std::lock_guard<std::mutex> g(memo->p_->mu);
         auto it = memo->p_->map.find(key);
         if (it != memo->p_->map.end()) {
-            const ParseMemo::Impl::Entry& e = *it->second;
+            const ParseMemo::Impl::Entry& e = it->second;
             if (e.total > 0x7fffffffu) return PARSE_UNSUPPORTED;
             if (e.total > most) return PARSE_CORRUPT;
-            ps.cfg = e.cfg;
+            ps.cfg = *memo->p_->cfgs[(size_t)e.cfg_id]; ps.cfg_id = e.cfg_id;
             return finish(e.total);
         }
     }
@@ -1120,10 +1128,9 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
     }
     if (memo) {
         std::lock_guard<std::mutex> g(memo->p_->mu);
-        if (memo->p_->map.size() < ParseMemo::Impl::kMaxEntries && !memo->p_->map.count(key)) {
-            std::unique_ptr<ParseMemo::Impl::Entry> e(new ParseMemo::Impl::Entry{total, ps.cfg});
-            memo->p_->map.emplace(std::move(key), std::move(e));
-        }
+        const int id = memo->p_->intern(ps.cfg);
+        ps.cfg_id = id;
+        if (id >= 0 && memo->p_->map.size() < ParseMemo::Impl::kMaxEntries) memo->p_->map.emplace(std::move(key), ParseMemo::Impl::Entry{total, id});
     }
     return finish(total);
 }

@@ -95,17 +95,19 @@ class StreamDecoder {
 enum ParseStatus { PARSE_OK = 0, PARSE_NEED_MORE = 1, PARSE_CORRUPT = 2, PARSE_UNSUPPORTED = 3, PARSE_GPU_ERROR = 4 };
 struct ParsedStream {
     divans_lit_config cfg; size_t total = 0;
+    int cfg_id = -1;                                         // with a ParseMemo: equal ids (>= 0) of one memo <=> identical `cfg`
     std::vector<uint8_t> lit;                                // the LIT coder's bytes (left empty when parse_container_host is asked for spans)
     std::vector<std::pair<uint32_t, uint32_t>> lit_spans;    // ... or where they lie in the container: (offset, length) of every LIT slice, in order
     size_t lit_size = 0;                                     // their total either way
     void copy_lit(const uint8_t* container, uint8_t* dst) const {   // gathers the spans (the batch interface stages them straight into page-locked memory)
-        for (const auto& sp : lit_spans) { std::memcpy(dst, container + sp.first, sp.second); dst += sp.second; }
+        for (const auto& sp : lit_spans) { std::memcpy(dst, container + sp.first, sp.second); dst += sp.second; }   // <= 64 KiB pieces
     }
 };
 // What a CMD stream decodes to is a function of its bytes alone, and a batch of equal-length literal-only streams coded under the same
 // options carries the same few hundred CMD bytes in every container (PredictionMode + one literal length per ring lap): the memo keeps
 // (CMD bytes -> decoded size, LIT configuration) of the streams parsed so far, so that the 8.2 k nibbles of a PredictionMode are walked
-// once per distinct CMD stream and not once per container (220 us -> 15 us per 64 KiB container on one core).  Thread-safe; bounded.
+// once per distinct CMD stream and not once per container (220 us -> 15 us per 64 KiB container on one core).  Thread-safe; bounded
+// (65 536 CMD streams of ~100 bytes, 64 distinct configurations of 25 KB).
 class ParseMemo {
   public:
     ParseMemo();

@@ -32,6 +32,8 @@ struct LitGeometry {
     uint32_t bt_first, n_btypes;   // context tables exist for literal block types [bt_first, bt_first + n_btypes)
     uint32_t mix_off;              // byte offset of mixing_mask inside the configuration blob
     uint32_t lut1_classes;         // distinct literal_lut1 values of the prediction mode (1 for LSB6 / MSB6: the context is a function of prev alone)
+    uint32_t wrap_check;           // some speed lets a row total leave i16 (divans_gpu_speed_supported is false): streaming kernels without
+                                   // row caches, which keep such a row recognisable and report a stream that codes with one (lit_kernels.hip blend_row)
 };
 
 // One Literal command of a general stream (codec/mod.rs:711-792): `len` literal bytes coded with the literal block type
@@ -72,6 +74,7 @@ struct LitBatch {
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
 constexpr uint32_t LIT_STATUS_BAD_SEGMENT = 4u;   // a segment names a literal block type outside the codec's context tables
+constexpr uint32_t LIT_STATUS_OUTPUT_FULL = 8u;   // divans_gpu_lit_encode_packed: the coded streams did not fit the caller's buffer
 constexpr uint32_t LIT_STATUS_BAD_STREAM = 2u;    // decode: a chunk did not end with both states at 2^31, or the coded words were not consumed exactly
 
 struct RansBatch {
@@ -146,7 +149,7 @@ void lit_decode2_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap)
 uint32_t lit_decode2_effective_caches(uint32_t dm_log2, bool mix, bool seg);   // the caches of dm_log2 a kernel instance exists for
 uint32_t lit_decode2_stream_lds(uint32_t dm_log2);   // LDS bytes one stream takes in lit_decode2_kernel (word ring + row caches)
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
-                       uint64_t* dst_off, uint64_t* total, hipStream_t st);
+                       uint64_t* dst_off, uint64_t* total, hipStream_t st, bool accumulate = false, uint64_t cap = ~0ull, uint32_t* status = nullptr);
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);
 hipError_t launch_selftest_cdf_ops(const uint32_t* d_ops, uint32_t n, int32_t* d_out, hipStream_t st);
 

@@ -95,21 +95,38 @@ struct Table {
     }
 };
 
-// frequentist_cdf.rs:74-85 on one entry per lane (li = lane index in row).  The host rejects speeds with
-// inc + lim + 16 > 0x7fff, so no i16 wrap can occur and plain 32-bit arithmetic is exact.
-// same, when the row's total before the update is already at hand (cdf[15] always takes the increment, so the
-// renormalisation test needs no second broadcast)
-__device__ __forceinline__ int blend_row_known_max(int c, int li, int sym, int inc, int lim, int old_max) {
+// frequentist_cdf.rs:74-85 on one entry per lane (li = lane index in row).  For speeds whose row totals never leave i16
+// (divans_gpu_speed_supported) plain 32-bit arithmetic is the reference's.  For the others (`wc`, LitGeometry::wrap_check) the
+// reference's i16 total wraps negative when it passes 0x7fff: `cdf[15] >= lim` is then false -- no renormalisation -- and the next
+// nibble coded with that row gets a (start, freq) that is no distribution (ans.rs:281-285's debug_asserts; a release build divides by a
+// zero freq or writes a stream its own decoder cannot read).  The lanes keep such a row recognisable instead of wrapping it: no
+// renormalisation, its total stays above 0x7fff (saturating at 0xffff, rows are stored as u16), and wrap_scan() after the stream tells
+// a row that merely ended there (harmless: the reference never looks at it again) from one that was coded with again.
+// `_known_max`: the row's total before the update is already at hand (cdf[15] always takes the increment, so the renormalisation
+// test needs no second broadcast)
+// i16 leaves its range in two places of blend: the increment carries the total past 0x7fff, or -- the total still inside -- the
+// renormalisation's `cdf[15] + 16` does (t = c + i + 1 is largest in entry 15); either way the reference's row is garbage from there on
+__device__ __forceinline__ int blend_wrap_checked(int c, int li, int lim, int renorm, int nt) {
+    c = c > 0xffff ? 0xffff : c;
+    if (nt > 0x7fff) return c;                                   // wrapped by the increment: no renormalisation (the i16 total is negative)
+    if (nt < lim) return c;
+    if (nt + 16 > 0x7fff) return li == 15 ? 0x8000 : c;          // wrapped inside the renormalisation: mark the total
+    return renorm;
+}
+__device__ __forceinline__ int blend_row_known_max(int c, int li, int sym, int inc, int lim, int old_max, bool wc = false) {
     c = (li >= sym) ? c + inc : c;
     int t = c + li + 1;
     int renorm = t - (t >> 2);
-    return old_max + inc >= lim ? renorm : c;
+    const int nt = old_max + inc;
+    if (wc) return blend_wrap_checked(c, li, lim, renorm, nt);
+    return nt >= lim ? renorm : c;
 }
-__device__ __forceinline__ int blend_row(int c, int li, int sym, int inc, int lim) {
+__device__ __forceinline__ int blend_row(int c, int li, int sym, int inc, int lim, bool wc = false) {
     c = (li >= sym) ? c + inc : c;
     int c15 = row_bcast<15>(c);
     int t = c + li + 1;
     int renorm = t - (t >> 2);
+    if (wc) return blend_wrap_checked(c, li, lim, renorm, c15);
     return c15 >= lim ? renorm : c;
 }
 
@@ -147,6 +164,22 @@ __device__ __forceinline__ Table<CACHE> make_table(const LitBatch& b, uint8_t* l
     t.cl.tag_off = base + hi_bytes + b.cache_rows_low * 32u;
     t.cl.set_mask = (b.cache_rows_low >> 1) - 1u;
     return t;
+}
+
+// LitGeometry::wrap_check, after a stream: was a row whose total had left i16 coded with again?  Such a row took at least one more
+// increment after the one that carried it past 0x7fff (blend_row above keeps it there), so its total is above 0x7fff + inc of its
+// table -- stride rows literal_adaptation[0], FirstNibble rows [3], SecondNibble rows [2] (literal.rs:241,320,354).  Lane l of the
+// row looks at entry 15 of rows l, l + 16, ...; needs the uncached table (the host launches these speeds with CACHE == 0).
+template <int CACHE>
+__device__ __forceinline__ bool wrap_scan(const LitGeometry& g, const Table<CACHE>& tb, int li, int rbase) {
+    bool bad = false;
+    const uint32_t base = tb.lane_off - 2u * (uint32_t)li + 30u;     // entry 15 of row 0 of this stream's slab
+    for (uint32_t row = (uint32_t)li; row < g.total_rows; row += 16u) {
+        const int total = (int)__builtin_amdgcn_raw_buffer_load_b16(tb.rsrc, base + (row << 5), 0, 0);
+        const int inc = row < g.cm_base ? g.inc0 : (row < g.cm_base + g.nctx ? g.inc3 : g.inc2);
+        bad |= total > 0x7fff + inc;
+    }
+    return ((__ballot(bad) >> rbase) & 0xffffull) != 0ull;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -187,7 +220,7 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
         int p = average_rows(cm, st, cmax, smax, mix_rate);
         int pmax = row_bcast<15>(p);
         packed = mixed_start_freq(p, cm, st, pmax, cmax, smax, li, rbase, sym, wfreqs);
-        cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
+        cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax, g.wrap_check != 0u);
         tb.store(cref, cm);
     } else {
         int cv = ((MM < 0 || MM == 2) && rs.is_default) ? 4 * (li + 1) : st;
@@ -197,7 +230,7 @@ __device__ __forceinline__ uint32_t model_nibble(const LitGeometry& g, const Lds
         uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
         packed = (uint32_t)row_gather((int)sf, rbase, sym);
     }
-    if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0);   // literal_adaptation[0] for both nibbles, literal.rs:320,354
+    if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0, g.wrap_check != 0u);   // literal_adaptation[0] for both nibbles, literal.rs:320,354
     if (CACHE != 0 || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);   // a cached way must hold its row even when it is not blended
     return packed;
 }
@@ -225,7 +258,7 @@ __device__ __forceinline__ uint32_t model_finish(const LitGeometry& g, const Tab
     const uint32_t sf = (uint32_t)(dprev + 1) | ((uint32_t)((int)d - dprev - 1) << 16);
     const uint32_t packed = (uint32_t)row_gather((int)sf, rbase, sym);
     int st = f.value;
-    if (!f.is_default) st = blend_row_known_max(st, li, sym, g.inc0, g.lim0, mx);   // cv == f.value here, so mx is its total
+    if (!f.is_default) st = blend_row_known_max(st, li, sym, g.inc0, g.lim0, mx, g.wrap_check != 0u);   // cv == f.value here, so mx is its total
     if (CACHE != 0 || !f.is_default) tb.store(f.ref, st);
     return packed;
 }
@@ -315,6 +348,14 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_model_encode_kernel(const Lit
         if (MIX && b.wstate && (li & 7) == 0) {   // lanes 0 and 8 of the row hold the two Weights objects
             int32_t* p = b.wstate + (li ? 3 : 0);
             p[0] = wp.w.w0; p[1] = wp.w.w1; p[2] = wp.w.norm;
+        }
+        if (g.wrap_check) {     // a speed under which a row total can leave i16: say so if one did and was coded with again
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            if (wrap_scan<CACHE>(g, tb, li, rbase) && li == 0) {
+                if (b.status) atomicOr(b.status, LIT_STATUS_BAD_MODEL);
+                if (b.stream_bad) b.stream_bad[s] = 1;
+            }
         }
     }
 }
@@ -439,8 +480,12 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
 // as long as one -- so all that matters is that the one-wave workgroups are spread evenly, and left to itself the dispatcher stacks
 // three on some SIMDs of a CU while others hold one: 65 536 streams = 2048 waves = two per SIMD took 19.0 ms, pinned 14.7
 // (profiles/r03g_rans_wave_placement.txt).  Larger batches simply run in rounds of 2048 waves.
-__global__ __launch_bounds__(RANS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void rans_encode2_kernel(const RansBatch b) {
-    const uint32_t g = blockIdx.x * RANS_THREADS + threadIdx.x;
+#ifndef DIVANS_RANS2_THREADS    // experiment switch (scripts/build_variants.sh rans2)
+#define DIVANS_RANS2_THREADS 256
+#endif
+constexpr int RANS2_THREADS = DIVANS_RANS2_THREADS;
+__global__ __launch_bounds__(RANS2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void rans_encode2_kernel(const RansBatch b) {
+    const uint32_t g = blockIdx.x * RANS2_THREADS + threadIdx.x;
     const uint32_t s = g >> 1, ck = g & 1u;
     const bool live = s < b.n_streams;
     const uint32_t len = live ? (b.in_sizes ? b.in_sizes[s] : b.stream_len) : 0u;
@@ -529,10 +574,10 @@ __device__ __forceinline__ uint32_t decode_nibble(const LitGeometry& g, const Ld
     S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;
     if (MIX) {
         wpmix = freq;
-        cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax);
+        cm = blend_row_known_max(cm, li, sym, HIGH ? g.inc3 : g.inc2, HIGH ? g.lim3 : g.lim2, cmax, g.wrap_check != 0u);
         tb.store(cref, cm);
     }
-    if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0);
+    if (!((MM < 0 || MM == 2) && rs.is_default)) st = blend_row(st, li, sym, g.inc0, g.lim0, g.wrap_check != 0u);
     if (CACHE != 0 || !((MM < 0 || MM == 2) && rs.is_default)) tb.store(sref, st);
     return (uint32_t)sym;
 }
@@ -561,7 +606,7 @@ __device__ __forceinline__ void finish_nibble(const LitGeometry& g, const Table<
     const uint32_t start = packed & 0xffffu, freq = packed >> 16;
     S = (uint64_t)freq * (S >> 15) + (uint64_t)slot - (uint64_t)start;     // helper_advance_sym, ans.rs:238
     int st = f.value;
-    if (!f.is_default) st = blend_row_known_max(st, li, sym, g.inc0, g.lim0, mx);   // cv == f.value here, so mx is its total
+    if (!f.is_default) st = blend_row_known_max(st, li, sym, g.inc0, g.lim0, mx, g.wrap_check != 0u);   // cv == f.value here, so mx is its total
     if (CACHE != 0 || !f.is_default) tb.store(f.ref, st);
 }
 
@@ -661,6 +706,11 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
             int32_t* p = b.wstate + (li ? 3 : 0);
             p[0] = wp.w.w0; p[1] = wp.w.w1; p[2] = wp.w.norm;
         }
+        if (g.wrap_check) {     // the encoder of this stream coded with a row whose i16 total had wrapped: whatever it wrote, it is not these bytes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            corrupt |= wrap_scan<CACHE>(g, tb, li, rbase);
+        }
         if (corrupt && li == 0) {
             if (b.status) atomicOr(b.status, LIT_STATUS_BAD_STREAM);
             if (b.stream_bad) b.stream_bad[s] = 1;
@@ -671,9 +721,12 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode_kernel(const LitBatch 
 // ---------------------------------------------------------------------------------------------
 // pack_streams: exclusive scan of the 4-byte-rounded sizes (single block, 3 phases) + coalesced copy
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void scan_sizes_kernel(const uint32_t* sizes, uint32_t n, uint64_t* offsets, uint64_t* total) {
+// `accumulate`: *total on entry is where this batch starts in the packed buffer (a sub-batch appended behind earlier ones) and takes
+// this batch's bytes on top; otherwise the batch starts at 0 and *total receives its size
+__global__ __launch_bounds__(1024) void scan_sizes_kernel(const uint32_t* sizes, uint32_t n, uint64_t* offsets, uint64_t* total, int accumulate) {
     __shared__ uint64_t partial[1024];
     const uint32_t t = threadIdx.x;
+    const uint64_t base = accumulate ? *total : 0ull;       // read by every thread before thread 1023 overwrites it (barriers below)
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t beg = t * per < n ? t * per : n, end = beg + per < n ? beg + per : n;
     uint64_t sum = 0;
@@ -686,13 +739,13 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(const uint32_t* sizes,
         partial[t] += v;
         __syncthreads();
     }
-    uint64_t run = t ? partial[t - 1] : 0;
+    uint64_t run = base + (t ? partial[t - 1] : 0);
     for (uint32_t i = beg; i < end; ++i) { offsets[i] = run; run += (sizes[i] + 3u) & ~3u; }
-    if (t == 1023u) *total = partial[1023];
+    if (t == 1023u) *total = base + partial[1023];
 }
 
 __global__ __launch_bounds__(256) void pack_copy_kernel(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes,
-                                                        uint32_t n, uint8_t* packed, const uint64_t* dst_off) {
+                                                        uint32_t n, uint8_t* packed, const uint64_t* dst_off, uint64_t cap, uint32_t* status) {
     // one wave per stream, 4 bytes per lane per step (coded streams are whole 32-bit words)
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     const uint32_t nw = (gridDim.x * 256u) >> 6;
@@ -700,6 +753,10 @@ __global__ __launch_bounds__(256) void pack_copy_kernel(const uint8_t* slots, co
         const uint32_t* src = (const uint32_t*)(slots + src_off[s]);
         uint32_t* dst = (uint32_t*)(packed + dst_off[s]);
         const uint32_t words = (sizes[s] + 3u) >> 2;
+        if (dst_off[s] + 4ull * words > cap) {        // the caller's buffer ends here: the stream stays unwritten (offsets and sizes still say what was needed)
+            if (lane == 0 && status) atomicOr(status, LIT_STATUS_OUTPUT_FULL);
+            continue;
+        }
         for (uint32_t i = lane; i < words; i += 64u) dst[i] = src[i];
     }
 }
@@ -818,8 +875,8 @@ hipError_t launch_model_encode(const LitBatch& b_in, bool mix, uint32_t blocks, 
 }
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
     if (b.scratch) {   // one lane per chunk (streams of at most two chunks), then move chunk 0 in front of chunk 1
-        const uint32_t blocks = (2u * b.n_streams + RANS_THREADS - 1) / RANS_THREADS;
-        hipLaunchKernelGGL(rans_encode2_kernel, dim3(blocks), dim3(RANS_THREADS), 0, st, b);
+        const uint32_t blocks = (2u * b.n_streams + RANS2_THREADS - 1) / RANS2_THREADS;
+        hipLaunchKernelGGL(rans_encode2_kernel, dim3(blocks), dim3(RANS2_THREADS), 0, st, b);
         const uint32_t sblocks = (b.n_streams + 3u) / 4u < 8192u ? (b.n_streams + 3u) / 4u : 8192u;
         hipLaunchKernelGGL(rans_stitch_kernel, dim3(sblocks), dim3(256), 0, st, b);
         return hipGetLastError();
@@ -846,11 +903,11 @@ hipError_t launch_decode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStr
     return hipGetLastError();
 }
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
-                       uint64_t* dst_off, uint64_t* total, hipStream_t st) {
-    hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, st, sizes, n, dst_off, total);
+                       uint64_t* dst_off, uint64_t* total, hipStream_t st, bool accumulate, uint64_t cap, uint32_t* status) {
+    hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, st, sizes, n, dst_off, total, accumulate ? 1 : 0);
     uint32_t blocks = (n + 3) / 4;
     blocks = blocks > 2048 ? 2048 : (blocks ? blocks : 1);
-    hipLaunchKernelGGL(pack_copy_kernel, dim3(blocks), dim3(256), 0, st, slots, src_off, sizes, n, packed, dst_off);
+    hipLaunchKernelGGL(pack_copy_kernel, dim3(blocks), dim3(256), 0, st, slots, src_off, sizes, n, packed, dst_off, cap, status);
     return hipGetLastError();
 }
 hipError_t launch_selftest_cdf_ops(const uint32_t* d_ops, uint32_t n, int32_t* d_out, hipStream_t st) {

@@ -168,6 +168,17 @@ int divans_gpu_pack_streams(divans_gpu_codec *c, const uint8_t *d_slots, const u
                             const uint32_t *d_sizes, uint32_t n_streams, uint8_t *d_packed,
                             uint64_t *d_packed_offsets, uint64_t *d_total);
 
+/* Encode n_streams streams and leave them CONTIGUOUS in d_packed, stream after stream (4-byte aligned starts): d_packed_offsets[i],
+ * d_sizes[i], *d_total = bytes used (device u64).  The work is done in sub-batches of `sub_batch` streams (0 = the codec's default,
+ * 32768) whose right-aligned output slots and bucket work arrays the codec owns and reuses, so that a 65 536-stream batch holds the
+ * slots and work arrays of half of it instead of divans_gpu_lit_encode_bound() per stream for all of them.
+ * When the coded streams do not fit `packed_cap` the ones past the end are left out and DIVANS_GPU_STATUS_OUTPUT_FULL is raised
+ * (offsets, sizes and *d_total still say what was needed: call again with that much).  Input conventions as divans_gpu_lit_encode_batch. */
+#define DIVANS_GPU_STATUS_OUTPUT_FULL 8u
+int divans_gpu_lit_encode_packed(divans_gpu_codec *c, const uint8_t *d_in, const uint64_t *d_in_offsets, const uint32_t *d_in_sizes,
+                                 uint32_t stream_len, uint32_t n_streams, uint8_t *d_packed, uint64_t packed_cap,
+                                 uint64_t *d_packed_offsets, uint32_t *d_sizes, uint64_t *d_total, uint32_t sub_batch);
+
 /* Convenience wrappers over host memory (H2D, launch, D2H, synchronous).  out_offsets/out_sizes are host arrays. */
 int divans_gpu_lit_encode_host(divans_gpu_codec *c, const uint8_t *in, uint32_t stream_len, uint32_t n_streams,
                                uint8_t *out_packed, size_t out_cap, uint64_t *out_offsets, uint32_t *out_sizes,
@@ -204,6 +215,7 @@ typedef struct divans_gpu_info {
     uint64_t table_bytes;          /* HBM bytes of the CDF tables */
     uint64_t scratch_bytes;        /* HBM bytes of the encoder's work memory: bucketed-pass work arrays, start/freq spill, rANS chunk scratch */
     float last_model_ms, last_rans_ms, last_decode_ms; /* hipEvent timings of the last batch calls */
+    float last_pack_ms;            /* the pack launches inside the last divans_gpu_lit_encode_packed call */
 } divans_gpu_info;
 int divans_gpu_codec_info(divans_gpu_codec *c, divans_gpu_info *info);
 /* The kernel instance the last decode call launched, spelt as rocprofv3 --kernel-trace reports it
@@ -239,11 +251,18 @@ int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, ui
  * returns the number of mismatches over every (cdf<<15)/max with 1<=max<32768, 0<=cdf<=max. */
 int divans_gpu_selftest_division(divans_gpu_codec *c, uint64_t *mismatches);
 
-/* 1 when divans_gpu_codec_create accepts (inc, lim) as a literal_adaptation speed: inc, lim within the reference's own bounds
- * (src/probability/interface.rs:341-365) and no count of a row ever leaves i16 under it -- FrequentistCDF16::blend
- * (src/probability/frequentist_cdf.rs:74-85) wraps there, after which a row's total is negative and what the reference codes with
- * it is no longer a distribution; the GPU coder refuses such speeds rather than code them differently.  Host-only, needs no device. */
+/* 1 when no count of a row can ever leave i16 under Speed(inc, lim): FrequentistCDF16::blend (src/probability/frequentist_cdf.rs:74-85)
+ * adds inc to a row's total on every update and renormalises once it reached lim, so the total follows one trajectory from 64; such
+ * speeds run on every kernel.  Host-only, needs no device. */
 int divans_gpu_speed_supported(int32_t inc, int32_t lim);
+/* 1 when divans_gpu_codec_create takes (inc, lim) at all: every i16 pair with inc >= 0 -- whatever the f8 pairs of a PredictionMode
+ * command decode to (src/probability/interface.rs:577-585), short of a negative increment.  Under an accepted speed that is not
+ * "supported" the reference's i16 row total wraps negative at some point, and the next nibble coded with that row is not a
+ * distribution any more (src/ans.rs:281-285; its own decoder cannot read such a stream back).  A stream in which no wrapped row is
+ * coded with again -- every short stream -- is coded bit for bit as the reference codes it; one in which that happens raises
+ * DIVANS_GPU_STATUS_BAD_MODEL (encoding) / DIVANS_GPU_STATUS_BAD_STREAM and the per-stream flag (decoding).  These speeds run on the
+ * streaming kernels without row caches: correct, not fast. */
+int divans_gpu_speed_accepted(int32_t inc, int32_t lim);
 
 /* Test entry points: device primitives in isolation, so that the reference's own unit tests can be run against them.
  * cdf_ops: a script of n_ops operations {kind, a, b, c} (4 x u32 each) on two CDF rows and one Weights object, one

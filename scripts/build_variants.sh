@@ -14,6 +14,11 @@ build () {  # name, extra flags
 }
 if [ "$1" = "noperm" ]; then
   build noperm "-DDIVANS_D2_PERM=0" &
+elif [ "$1" = "rans2" ]; then      # workgroup size of the chunk-parallel rANS pass (lit_kernels.hip): one wave per workgroup as in round 3
+  OBJS2=$(ls divans_amd/build/*.o | grep -v lit_kernels)
+  /opt/rocm/bin/hipcc $FLAGS -DDIVANS_RANS2_THREADS=64 -x hip -c divans_amd/csrc/lit_kernels.hip -o gpurun_exp/lit_kernels_rans64.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_exp/libdivans_rans64.so $OBJS2 gpurun_exp/lit_kernels_rans64.o
+  rm gpurun_exp/lit_kernels_rans64.o
 elif [ "$1" = "dm_auto" ]; then    # the batch ABI with and without the per-batch choice of direct-mapped caches (capi.cpp)
   OBJS2=$(ls divans_amd/build/*.o | grep -v capi)
   /opt/rocm/bin/hipcc $FLAGS -DDIVANS_DM_AUTO_DEFAULT=0 -x hip -c divans_amd/csrc/capi.cpp -o gpurun_exp/capi_nodmauto.o

@@ -89,8 +89,9 @@ def test_host_crc32c_paths_agree():
 
 def test_speed_supported_means_no_i16_wrap():
     """divans_gpu_speed_supported (host-only) against the Python restatement's FrequentistCDF16::blend with its i16 wrapping:
-    an accepted speed never takes a count of a row out of i16 -- the kernels' 32-bit arithmetic and the reference's wrapping
-    arithmetic are then the same thing -- and the speeds it refuses are the ones under which the reference wraps."""
+    a supported speed never takes a count of a row out of i16 -- the kernels' 32-bit arithmetic and the reference's wrapping
+    arithmetic are then the same thing -- and the others are the ones under which the reference wraps (they run on the wrap-checked
+    streaming kernels, divans_gpu_speed_accepted; only a negative increment is refused)."""
     import numpy as np
     import divans_amd as da
     import ref_restatement as rr
@@ -114,12 +115,18 @@ def test_speed_supported_means_no_i16_wrap():
         assert da.speed_supported(inc, lim) and not wraps(inc, lim), (inc, lim)
     for inc, lim in [(0x4000, 0x4000), (0x3000, 0x1000), (0x2000, 0x100), (0x4000, 1), (8180, 64), (0x3ff0, 0x4000)]:
         assert not da.speed_supported(inc, lim) and wraps(inc, lim), (inc, lim)
-    for inc, lim in [(-1, 100), (1, 0), (0x4001, 100), (1, 0x4001)]:
-        assert not da.speed_supported(inc, lim)
+    # the reference's debug-only bounds (inc, lim <= 0x4000, probability/interface.rs:341-365) are no part of the rule: only the trajectory is
+    for inc, lim in [(1, 0), (3, -5), (1, 0x4001), (16, 0x6000), (0x30, 0x7000)]:
+        assert da.speed_supported(inc, lim) and da.speed_accepted(inc, lim) and not wraps(inc, lim, steps=40000 if lim > 0x4000 else 400), (inc, lim)
+    for inc, lim in [(0x4001, 100), (1, 0x7fff), (0x7800, 0x7800), (0x5000, 0x7fff)]:
+        assert not da.speed_supported(inc, lim) and da.speed_accepted(inc, lim), (inc, lim)
+    for inc, lim in [(-1, 100), (-0x8000, 0x2000), (0x8000, 5), (5, 0x8000)]:
+        assert not da.speed_supported(inc, lim) and not da.speed_accepted(inc, lim)
     rng = np.random.default_rng(11)
     checked = 0
     for _ in range(300):
-        inc = int(rng.integers(0, 0x4001)) >> int(rng.integers(0, 6)); lim = max(1, int(rng.integers(1, 0x4001)) >> int(rng.integers(0, 6)))
+        inc = int(rng.integers(0, 0x8000)) >> int(rng.integers(0, 8)); lim = (int(rng.integers(0, 0x8000)) >> int(rng.integers(0, 6))) - int(rng.integers(0, 3)) * 40
+        assert da.speed_accepted(inc, lim)
         if da.speed_supported(inc, lim):
             assert not wraps(inc, lim), (inc, lim)
             checked += 1

@@ -238,15 +238,92 @@ def test_brotli_derived_prediction_mode(btype, context_mixing, corpus):
     codec.close()
 
 
-def test_unsupported_speed_is_rejected():
-    # speeds under which the reference's i16 row totals wrap (divans_gpu_speed_supported): (0x3000, 0x1000) climbs towards
-    # 4 * inc although inc + lim is small
+def _encode_ragged(da, codec, blocks, lens):
+    """device entry point with per-stream sizes (no status check of its own) -> (coded bytes, offsets, sizes) on the host"""
+    import torch
+    dev = torch.device("cuda")
+    n, L = blocks.shape
+    d_in = torch.from_numpy(np.concatenate([blocks.reshape(-1), np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.arange(n, dtype=torch.int64, device=dev) * L
+    d_sz = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    outs = codec.alloc_encode_outputs(n, L)
+    codec.encode_batch(d_in, n, L, outs, in_offsets=d_off, in_sizes=d_sz)
+    torch.cuda.synchronize()
+    return outs["out"].cpu().numpy(), outs["offsets"].cpu().numpy(), outs["sizes"].cpu().numpy()
+
+
+def _decode_ragged(da, codec, packed, offs, sizes, lens, L):
+    import torch
+    dev = torch.device("cuda")
+    n = len(lens)
+    d_coded = torch.from_numpy(np.concatenate([np.asarray(packed, np.uint8), np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(np.asarray(offs).astype(np.int64)).to(dev); d_sz = torch.from_numpy(np.asarray(sizes).astype(np.int32)).to(dev)
+    out = torch.zeros(n * L + 64, dtype=torch.uint8, device=dev)
+    o_off = torch.arange(n, dtype=torch.int64, device=dev) * L
+    o_sz = torch.from_numpy(np.asarray(lens).astype(np.int32)).to(dev)
+    codec.decode_batch(d_coded, d_off, d_sz, n, L, out, out_offsets=o_off, out_sizes=o_sz)
+    torch.cuda.synchronize()
+    return out[:n * L].cpu().numpy().reshape(n, L)
+
+
+def test_a_negative_increment_is_rejected():
     import divans_amd as da
-    for inc, lim in [(0x4000, 0x4000), (0x3000, 0x1000), (8180, 64)]:
-        g = da.config_simple()
-        g.literal_adaptation[0].inc = inc; g.literal_adaptation[0].lim = lim
-        with pytest.raises(da.DivansGpuError):
-            da.LiteralCodec(g, 1024)
+    g = da.config_simple()
+    g.literal_adaptation[0].inc = -1; g.literal_adaptation[0].lim = 100
+    with pytest.raises(da.DivansGpuError):
+        da.LiteralCodec(g, 1024)
+
+
+@pytest.mark.parametrize("mixing", [0, 2])
+def test_speeds_under_which_the_references_row_totals_wrap(mixing, corpus):
+    """VERDICT r03 item 5: every speed the wire format can carry is taken.  Where FrequentistCDF16::blend's i16 total can wrap
+    (divans_gpu_speed_supported is false) the reference codes correctly until a wrapped row is coded with again -- from there its own
+    encoder writes what its decoder cannot read (the oracle, which wraps like it, reports the invalid (start, freq)).  The GPU coder agrees
+    on both sides of that line: streams the oracle can code come out bit for bit and decode back with a clean status; streams it cannot
+    raise BAD_MODEL when encoded, and bytes that are no valid stream under such a speed raise BAD_STREAM when decoded."""
+    import divans_amd as da
+    rng = np.random.default_rng(5 + mixing)
+    for speed in [(0x3000, 0x1000), (0x4000, 0x4000), (0x7800, 0x7800), (8180, 64), (0x2800, 0x6000)]:
+        assert not da.speed_supported(*speed) and da.speed_accepted(*speed)
+        speeds = [speed, (0x10, 0x2000), speed, speed] if mixing else [speed] * 4
+        g, o = _random_config(rng, da, mixing, 2, [4], speeds)
+        L = 2048
+        cands = [corpus[7000 + 97 * i:7000 + 97 * i + n].copy() for i, n in enumerate([1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 40, 64, 200, 700, 2048])]
+        cands += [np.arange(n, dtype=np.uint8) * 37 % 251 for n in (5, 9, 30)] + [np.full(n, 0x61, np.uint8) for n in (1, 2, 3, 4, 5, 7)]
+        codec = da.LiteralCodec(g, L)
+        n_clean = n_flagged = 0
+        for i, c in enumerate(cands):
+            try:
+                ref = po.lit_encode(o, c)
+                oracle_ok = bool((po.lit_decode(o, ref, c.size) == c).all())     # with mixing a wrapped row can yield pairs that LOOK valid and still not decode
+            except RuntimeError:
+                ref, oracle_ok = None, False
+            block = np.zeros((1, L), np.uint8); block[0, :c.size] = c
+            lens = np.array([c.size], np.uint32)
+            packed, offs, sizes = _encode_ragged(da, codec, block, lens)
+            st = codec.status()
+            assert st in (0, 1), (speed, i, st)
+            if st == 0:             # no wrapped row was coded with: the reference's arithmetic, bit for bit
+                n_clean += 1
+                assert oracle_ok, (speed, i, c.size, "the GPU coder saw no wrapped row in use, the oracle cannot code the stream")
+                got = packed[int(offs[0]):int(offs[0]) + int(sizes[0])]
+                assert got.size == ref.size and (got == ref).all(), (speed, i, c.size)
+                back = _decode_ragged(da, codec, packed, offs, sizes, lens, L)
+                assert codec.status() == 0 and (back[0, :c.size] == c).all(), (speed, i)
+            else:                   # BAD_MODEL: a row whose i16 total had wrapped was coded with again
+                n_flagged += 1
+                if not mixing:
+                    assert ref is None, (speed, i, c.size, "flagged, but the oracle codes the stream")
+        assert n_clean >= 8 and n_flagged >= 3, (speed, n_clean, n_flagged)      # both sides of the line are exercised
+        # ... and what no encoder wrote: a long stream coded under the default speed, read under this one
+        plain, po_plain = _random_config(rng, da, mixing, 2, [4], [(0x10, 0x2000)] * 4)
+        long_in = corpus[20000:20000 + L].copy()[None, :]
+        pc = da.LiteralCodec(plain, L)
+        pp, poff, psz = pc.encode_host(long_in, L)
+        pc.close()
+        _decode_ragged(da, codec, pp, poff, psz, np.array([L], np.uint32), L)
+        assert codec.status() & 2, (speed, "BAD_STREAM expected")
+        codec.close()
 
 
 @pytest.mark.parametrize("mixing", [0, 2])
@@ -719,4 +796,51 @@ def test_decoder_survives_thousands_of_damaged_streams(cfg_name, corpus):
     for f, back in results[1:]:
         assert (f == results[0][0]).all()                          # the generations agree on what is acceptable
     assert codec._lib.divans_gpu_codec_set_stream_flags(codec._h, None) == 0
+    codec.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_encode_packed_equals_encode_batch_plus_pack(cfg_name, corpus):
+    """divans_gpu_lit_encode_packed (sub-batches through codec-owned slots, packed at running offsets) leaves exactly the bytes
+    divans_gpu_lit_encode_batch + divans_gpu_pack_streams leave, for sub-batch sizes that do and do not divide the batch, ragged streams,
+    and says so when the caller's buffer is too small"""
+    import torch
+    import divans_amd as da
+    dev = torch.device("cuda")
+    cfg = da.config_simple() if cfg_name == "simple" else da.config_context_mixing()
+    n, L = 77, 5000
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, L + 1, n).astype(np.int32); lens[0] = L; lens[5] = 0
+    blocks = np.stack([np.resize(corpus[1000 * i:1000 * i + L], L) for i in range(n)])
+    d_in = torch.from_numpy(np.concatenate([blocks.reshape(-1), np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.arange(n, dtype=torch.int64, device=dev) * L
+    d_sz = torch.from_numpy(lens).to(dev)
+    codec = da.LiteralCodec(cfg, L)
+    outs = codec.alloc_encode_outputs(n, L)
+    codec.encode_batch(d_in, n, L, outs, in_offsets=d_off, in_sizes=d_sz)
+    ref_packed, ref_off, ref_total = codec.pack(outs, n)
+    ref_total = int(ref_total.item())
+    ref_sizes = outs["sizes"].clone()
+    for sub in (0, 16, 77, 10, 1):
+        packed = torch.zeros(ref_total + 256, dtype=torch.uint8, device=dev)
+        poff = torch.zeros(n, dtype=torch.int64, device=dev); sizes = torch.zeros(n, dtype=torch.int32, device=dev); total = torch.zeros(1, dtype=torch.int64, device=dev)
+        codec.encode_packed(d_in, n, L, packed, poff, sizes, total, in_offsets=d_off, in_sizes=d_sz, sub_batch=sub)
+        assert codec.status() == 0
+        assert int(total.item()) == ref_total and torch.equal(sizes, ref_sizes) and torch.equal(poff, ref_off), sub
+        assert torch.equal(packed[:ref_total], ref_packed[:ref_total]), sub
+        back = torch.zeros(n * L + 64, dtype=torch.uint8, device=dev)
+        codec.decode_batch(packed, poff, sizes, n, L, back, out_offsets=d_off, out_sizes=d_sz)
+        assert codec.status() == 0
+        got = back[:n * L].cpu().numpy().reshape(n, L)
+        for i in range(n):
+            assert (got[i, :lens[i]] == blocks[i, :lens[i]]).all(), (sub, i)
+        assert codec.info().last_pack_ms >= 0
+    # a buffer that ends inside the batch: the streams past it stay out, the status word says so, the sizes still tell what is needed
+    small = torch.zeros(ref_total // 2, dtype=torch.uint8, device=dev)
+    poff = torch.zeros(n, dtype=torch.int64, device=dev); sizes = torch.zeros(n, dtype=torch.int32, device=dev); total = torch.zeros(1, dtype=torch.int64, device=dev)
+    codec.encode_packed(d_in, n, L, small, poff, sizes, total, in_offsets=d_off, in_sizes=d_sz, sub_batch=16)
+    assert codec.status() & 8
+    assert int(total.item()) == ref_total and torch.equal(sizes, ref_sizes)
+    fit = int((ref_off + ((ref_sizes.to(torch.int64) + 3) & ~3) <= small.numel()).sum().item())
+    assert 0 < fit < n and torch.equal(small[:int(ref_off[fit].item())], ref_packed[:int(ref_off[fit].item())])
     codec.close()
