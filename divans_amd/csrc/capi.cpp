@@ -239,7 +239,33 @@ static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint
     for (int t = 0; t < 3; ++t) if (t_used[t]) plane[t] = nplanes++;
     g.plane0 = plane[0]; g.plane1 = plane[1]; g.plane2 = plane[2];
     g.low_width = any1 ? 256u : 16u;
-    const uint32_t high_rows = nplanes * 256u * g.nctx;
+    // The high-nibble stride row of code_nibble is [ctx][prev] (literal.rs:205-208 with every mixing value 4), and ctx itself is a
+    // function of (prev, lut1 class of prev_prev): of the nctx x 256 rows only (classes) x 256 can ever be touched.  Where that function
+    // table is laid out [row slot of the class][prev] instead: config 3 (cm[i] = i & 63, UTF8) 16 384 -> 1024 rows, 690 KB -> 199 KB per
+    // resident stream, a third of the table fill per stream.
+#ifndef DIVANS_HS_BY_CLASS
+#define DIVANS_HS_BY_CLASS 1
+#endif
+    g.hs_classes = 0;
+    if (DIVANS_HS_BY_CLASS && g.mm_uniform == 4 && !constant && n_btypes == 1u && nclass <= 4 && (uint32_t)nclass < g.nctx) {
+        // two classes of one prev may select the same context (UTF8: lut0 | lut1 collides for the non-ASCII bytes) and then share a
+        // row: the free half of the fused table ([prev][4 + class], the prediction modes with at most 4 classes) names the row slot
+        // of every class -- the first class with that context
+        uint32_t most = 0;
+        for (int prev = 0; prev < 256; ++prev) {
+            uint32_t used = 0;
+            for (int k = 0; k < nclass; ++k) {
+                uint32_t slot = used;
+                for (int j = 0; j < k; ++j)
+                    if (blob[LIT_BLOB_CTXF + prev * 8 + j] == blob[LIT_BLOB_CTXF + prev * 8 + k]) { slot = blob[LIT_BLOB_CTXF + prev * 8 + 4 + j]; break; }
+                if (slot == used) ++used;
+                blob[LIT_BLOB_CTXF + prev * 8 + 4 + k] = (uint8_t)slot;
+            }
+            most = std::max(most, used);
+        }
+        if (most < g.nctx) g.hs_classes = most;
+    }
+    const uint32_t high_rows = g.hs_classes ? 256u * g.hs_classes : nplanes * 256u * g.nctx;
     const uint32_t low_rows = nplanes * 256u * g.low_width;
     g.low_base = high_rows;
     g.cm_base = high_rows + low_rows;

@@ -246,7 +246,8 @@ struct History {
 
 // codec/literal.rs:176-208, as select_rows of lit_device.h but on a History
 template <bool HIGH, int MM, bool NEED8>
-__device__ __forceinline__ RowSel select_rows2(const LitGeometry& g, const uint8_t* lds_mix, uint32_t ctx, const History<NEED8>& h, uint32_t hi_nib) {
+__device__ __forceinline__ RowSel select_rows2(const LitGeometry& g, const uint8_t* lds_mix, uint32_t ctxk, const History<NEED8>& h, uint32_t hi_nib) {
+    const uint32_t ctx = ctxk & 0xffu;      // ctxk = context | row slot of (prev, class of prev_prev) << 8 (context_of)
     uint32_t mm_opts;
     if (MM >= 0) mm_opts = (uint32_t)MM;
     else mm_opts = lds_mix[ctx | (HIGH ? ((h.p1 >> 4) << 8) : ((hi_nib << 8) | 4096u))];
@@ -257,7 +258,10 @@ __device__ __forceinline__ RowSel select_rows2(const LitGeometry& g, const uint8
     if (mm_opts >= 4) { uint32_t x = mm_opts ^ 4u; stride_offset = (x < 7u ? x : 7u) << 3; }
     const uint32_t sb = (DIVANS_D2_PERM && MM == 4) ? h.pb : h.stride_byte(stride_offset);
     uint32_t b, c, width;
-    if (HIGH) { b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx; }
+    if (HIGH) {
+        b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx;
+        if (MM == 4 && g.hs_classes) { c = ctxk >> 8; width = g.hs_classes; }     // [slot of the class of prev_prev][prev]: the reachable rows only
+    }
     else { b = ((mm & sb) | (~mm & ctx)) & 0xffu; c = (hi_nib & fast_cm) | ((ctx & opt1) << 4); width = g.low_width; }
     const uint32_t t = (mm >> 7) ^ (opt1 >> 2);
     const uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);

@@ -128,8 +128,10 @@ struct RowSel {
 };
 
 // codec/literal.rs:176-208.  All inputs are row-uniform.
+// `ctxk` = context | row slot of (prev, class of prev_prev) << 8, as context_of() returns it
 template <bool HIGH, int MM>
-__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* lds_mix, uint32_t ctx, uint64_t last8, uint32_t hi_nib) {
+__device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_t* lds_mix, uint32_t ctxk, uint64_t last8, uint32_t hi_nib) {
+    const uint32_t ctx = ctxk & 0xffu;
     const uint32_t prev_byte = (uint32_t)(last8 >> 56);
     uint32_t mm_opts;
     if (MM >= 0) mm_opts = (uint32_t)MM;
@@ -141,7 +143,11 @@ __device__ __forceinline__ RowSel select_rows(const LitGeometry& g, const uint8_
     if (mm_opts >= 4) { uint32_t x = mm_opts ^ 4u; stride_offset = (x < 7u ? x : 7u) << 3; }
     const uint32_t sb = (uint32_t)(last8 >> (56 - stride_offset)) & 0xffu;
     uint32_t b, c, width;
-    if (HIGH) { b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx; }
+    if (HIGH) {
+        b = sb & mm & ~opt1 & 0xffu; c = ctx; width = g.nctx;
+        // LitGeometry::hs_classes: only the rows (prev, class of prev_prev) can reach exist, [slot of the class][prev] instead of [ctx][prev]
+        if (MM == 4 && g.hs_classes) { c = ctxk >> 8; width = g.hs_classes; }
+    }
     else { b = ((mm & sb) | (~mm & ctx)) & 0xffu; c = (hi_nib & fast_cm) | ((ctx & opt1) << 4); width = g.low_width; }
     const uint32_t t = (mm >> 7) ^ (opt1 >> 2);
     const uint32_t plane = t == 0 ? g.plane0 : (t == 1 ? g.plane1 : g.plane2);
@@ -181,11 +187,15 @@ __device__ __forceinline__ LdsView load_config_to_lds(uint8_t* lds, const LitBat
 
 // Context of the next byte: literal.rs:87-117 with lut0 / lut1 / context map fused on the host into
 // LIT_BLOB_CTXF[block type][prev][lut1 class of prev_prev]; `ctab` = byte offset of the current block type's table,
-// `k1` (that class) is carried over from the previous byte.
+// `k1` (that class) is carried over from the previous byte.  Where LitGeometry::hs_classes lays the high-nibble stride table out by
+// class, the row slot of (prev, class) comes along in bits 8.. (the host put it into the table's free half; select_rows takes the pair apart).
 template <bool CTXC>
 __device__ __forceinline__ uint32_t context_of(const LitGeometry& g, const uint8_t* lds_ctx, uint32_t ctab, uint32_t prev, uint32_t k1) {
     if (CTXC) return (uint32_t)g.ctx_const;
-    return lds_ctx[ctab + (prev << 3) + k1];
+    const uint32_t at = ctab + (prev << 3) + k1;
+    uint32_t v = lds_ctx[at];
+    if (g.hs_classes) v |= (uint32_t)lds_ctx[at + 4u] << 8;
+    return v;
 }
 
 // Walks a stream's segment list (general streams: one segment per Literal command).  `left` = bytes of the current

@@ -32,6 +32,8 @@ struct LitGeometry {
     uint32_t bt_first, n_btypes;   // context tables exist for literal block types [bt_first, bt_first + n_btypes)
     uint32_t mix_off;              // byte offset of mixing_mask inside the configuration blob
     uint32_t lut1_classes;         // distinct literal_lut1 values of the prediction mode (1 for LSB6 / MSB6: the context is a function of prev alone)
+    uint32_t hs_classes;           // > 0: the high-nibble stride table holds [row slot of the lut1 class of prev_prev][prev] (that many slots) instead of
+                                   // [ctx][prev] -- the rows a stride-1 configuration can reach; the slots are in LIT_BLOB_CTXF[prev][4 + class]
     uint32_t wrap_check;           // some speed lets a row total leave i16 (divans_gpu_speed_supported is false): streaming kernels without
                                    // row caches, which keep such a row recognisable and report a stream that codes with one (lit_kernels.hip blend_row)
 };

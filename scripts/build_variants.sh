@@ -14,6 +14,11 @@ build () {  # name, extra flags
 }
 if [ "$1" = "noperm" ]; then
   build noperm "-DDIVANS_D2_PERM=0" &
+elif [ "$1" = "hs_rows" ]; then    # the high-nibble stride table as [ctx][prev] (round 3) instead of [class][prev] (capi.cpp derive_geometry)
+  OBJS2=$(ls divans_amd/build/*.o | grep -v capi)
+  /opt/rocm/bin/hipcc $FLAGS -DDIVANS_HS_BY_CLASS=0 -x hip -c divans_amd/csrc/capi.cpp -o gpurun_exp/capi_hsctx.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_exp/libdivans_hsctx.so $OBJS2 gpurun_exp/capi_hsctx.o
+  rm gpurun_exp/capi_hsctx.o
 elif [ "$1" = "rans2" ]; then      # workgroup size of the chunk-parallel rANS pass (lit_kernels.hip): one wave per workgroup as in round 3
   OBJS2=$(ls divans_amd/build/*.o | grep -v lit_kernels)
   /opt/rocm/bin/hipcc $FLAGS -DDIVANS_RANS2_THREADS=64 -x hip -c divans_amd/csrc/lit_kernels.hip -o gpurun_exp/lit_kernels_rans64.o
