@@ -5,7 +5,7 @@ import json, re, sys
 tag = sys.argv[1]
 out = {"tag": tag, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB), separate passes, per-dispatch average of the divans kernels; the row "
        "accesses are 2 bytes per lane, for which the guide's x2 FETCH_SIZE correction (calibrated on 16 B/lane streaming reads) does not apply: "
-       "raw counters are reported.  Keys: dominant-kernel names as bench.py uses them.", "configs": {}}
+       "raw counters are reported.  Keys: kernel names as rocprofv3 reports them, without namespace and template arguments.", "configs": {}}
 for spec in sys.argv[2:]:
     config, summary, cmd, streams, block = spec.split(":")
     vals = {}
@@ -14,8 +14,7 @@ for spec in sys.argv[2:]:
         if not m or "divans" not in m.group(1):
             continue
         short = re.sub(r"^void ", "", m.group(1).strip()).split("<")[0].split("(")[0].replace("divans_hip::", "")
-        if short.startswith("lit_decode2_kernel") or short == "lit_decode_kernel":
-            short = "lit_decode_kernel"          # bench.py's name for whichever decode kernel generation ran
+        # bench.py names the decode kernel as rocprofv3 does and falls back to this base name (without template arguments) for the lookup
         vals.setdefault(short, {})[m.group(2)] = float(m.group(3)) * 1024.0      # counters are in KiB
     out["configs"][config] = {"command": open(cmd).read().strip(), "streams": int(streams), "block_bytes": int(block), "config": config,
                               "kernels": {k: {"fetch_bytes": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE"),

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): per BASELINE configuration, the kernel-trace stats of `python bench.py --config X` and the
 # PMC passes that feed roofline.traffic and the instruction census (separate runs; --pmc is never combined with trace domains
-# other than kernel-trace).  Outputs under gpurun_out/prof_<tag>/<config>/.  usage: profile_round3.sh <tag>
+# other than kernel-trace).  Outputs under gpurun_out/prof_<tag>/<config>/.  usage: profile_round.sh <tag>  (rounds 3 and 4)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 mkdir -p /tmp/divans_cache
