@@ -192,7 +192,7 @@ def spawn_ranks(args):
     """`python bench.py --gpus N` from a plain shell: become N ranks (one per GPU) under torch.distributed.run."""
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("DIVANS_BENCH_SHARE_GPU") != "1":
         sys.exit(f"bench: --gpus {args.gpus} needs {args.gpus} GPUs on this node, {have} visible (no CPU fallback, no silent single-rank run)")
     port = 29400 + os.getpid() % 500
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -415,12 +415,20 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DIVANS_BENCH_SHARE_GPU=1: verification of the N > 1 path on a one-GPU box -- every rank on cuda:0, gloo rendezvous (RCCL refuses two
+    # ranks on one device), divans_amd.sharding staging device tensors through the host.  The line says so; its numbers mean nothing.
+    share_gpu = world > 1 and os.environ.get("DIVANS_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench: rank {rank} needs GPU {local_rank}; {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -518,9 +526,9 @@ def main():
             step_s = elapsed / K
             m = dict(mg)
             m.update({"gather_ms": round(gather_s * 1e3, 3), "gathered_bytes": int(coded_all), "gather_checked_on_rank0": bool(g_ok == world),
-                      "rccl_world_size": world,
+                      "rccl_world_size": world, "transport": "gloo, all ranks on one GPU (DIVANS_BENCH_SHARE_GPU: path verification only)" if share_gpu else "rccl",
                       "scatter_gather_inclusive_MBps": round(total_streams * L / 1e6 / (step_s + mg["scatter_ms"] / 1e3 + gather_s), 2)})
-            t = torch.zeros((3, world), dtype=torch.float64, device=dev)
+            t = torch.zeros((3, world), dtype=torch.float64, device="cpu" if share_gpu else dev)
             t[0, rank] = res["elapsed"] / K * 1e3; t[1, rank] = res["roofline"]["frac"]; t[2, rank] = res["roofline"]["achieved"]
             dist.all_reduce(t)
             m["code_ms"] = round(step_s * 1e3, 3)               # encode + pack + decode of every rank's shard, max over ranks (= ms_per_step)
