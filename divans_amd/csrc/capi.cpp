@@ -112,6 +112,7 @@ struct divans_gpu_codec {
     uint32_t blocks2 = 0;                 // persistent grid of lit_decode2_kernel
     bool user_geometry = false;           // set_geometry / set_split_cache / set_decoder were called: set_block_types keeps their choices
     char last_decode_kernel[128] = "";    // divans_gpu_codec_last_decode_kernel
+    uint32_t last_decode_grid = 0;
     uint8_t* d_stream_flags = nullptr;    // caller-owned per-stream failure flags of the decode entry points (divans_gpu_codec_set_stream_flags)
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
@@ -911,11 +912,33 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         // A batch that is resident all at once runs at the latency of a stream's dependency chain, and the direct-mapped lookup is
         // the shorter chain (16 384 streams: 60.3 vs 63.5 ms, mixing 138 vs 142); only a batch that keeps the grid busy for several
         // rounds gains from the 2-way sets' fewer misses (profiles/r03c_small_batch_geometry.txt)
-        if (c->dm_auto && n_streams <= c->blocks2 * groups_per_block(c)) b.dm_shift &= 0x7fffffffu;
+        uint32_t grid = c->blocks2;
+        if (c->dm_auto && n_streams <= c->blocks2 * groups_per_block(c)) {
+            b.dm_shift &= 0x7fffffffu;
+            // ... and such a batch leaves LDS unused that shortens the chain further: the largest high-row caches under which every
+            // stream is still resident at once (profiles/r04c_small_batch_caches.txt: 16 384 streams 60.1 -> 54.2 ms with 64 instead of
+            // 32 high rows, 8192: 44.5 -> 40.4; mixing 20 480 streams 162.8 -> 152.5 ms with 32 + 16, 16 384: 134.4 -> 123.4 with 32 + 32;
+            // low-row caches do not pay even there)
+            if (!d_segs && c->geom.total_rows < 0x7fffu) {
+                const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
+                const uint32_t fixed = 256u + (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
+                const uint32_t mix_cands[2] = {6u | (6u << 8), 6u | (5u << 8)};      // (log2 rows + 1) per table: high stride | FirstNibble << 8
+                const uint32_t plain_cands[1] = {7u};
+                const uint32_t* cands = c->mix ? mix_cands : plain_cands;
+                for (uint32_t i = 0; i < (c->mix ? 2u : 1u); ++i) {
+                    const uint32_t lg = lit_decode2_effective_caches(cands[i], c->mix, false);
+                    const uint32_t per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(lg) + fixed;
+                    const uint32_t fit = std::min(8u, (160u * 1024u) / per_wg);
+                    if (lg == cands[i] && (uint64_t)n_streams <= (uint64_t)c->num_cus * fit * groups_per_block(c)) { b.dm_log2 = lg; break; }
+                }
+            }
+            grid = std::min(grid, (n_streams + groups_per_block(c) - 1u) / groups_per_block(c));
+        }
         b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
+        c->last_decode_grid = grid;
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    if (use_decode2(c)) { lit_decode2_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode2(b, c->mix, c->blocks2, c->stream)); }
+    if (use_decode2(c)) { lit_decode2_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode2(b, c->mix, c->last_decode_grid, c->stream)); }
     else { lit_decode_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream)); }
     HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     c->timing_pending_dec = true;
