@@ -191,7 +191,7 @@ def exported_symbols():
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_encode_packed", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
         "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
-        "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
+        "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_status_async", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
         "divans_gpu_lit_encode_host_pipelined", "divans_gpu_lit_decode_host_pipelined", "divans_gpu_host_alloc", "divans_gpu_host_free",
@@ -673,6 +673,7 @@ def batch_compress(inputs, options=None):
 
 
 def batch_decompress(containers, total_out, options=None):
+    """list of complete containers -> (list of payloads, timing dict)"""
     L = load_library()
     options = options or batch_options()
     return _batch_call(L.divans_batch_decompress, "divans_batch_decompress", options, containers, int(total_out) + 64)

@@ -231,7 +231,7 @@ struct Lane {
     std::map<CodecKey, Entry> codecs;     // at most kCodecsPerLane: a long-running process that sees many PredictionModes / length classes
     uint64_t tick = 0;                    // would otherwise pile up tables and scratch until hipMalloc fails
     static constexpr size_t kCodecsPerLane = 6;
-    PinnedBuf h_in, h_off, h_sz, h_ooff, h_osz, h_out, h_chunks, h_total, h_flags;
+    PinnedBuf h_in, h_off, h_sz, h_ooff, h_osz, h_out, h_chunks, h_total, h_flags, h_status;
     DeviceBuf d_in, d_off, d_sz, d_slots, d_ooff, d_osz, d_packed, d_poff, d_total, d_chunks, d_out, d_flags;
     long slice = -1;                 // slice in flight on this lane
     ~Lane() {
@@ -407,6 +407,8 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         r = divans_gpu_pack_streams(codec, L.d_slots.as<uint8_t>(), L.d_ooff.as<uint64_t>(), L.d_osz.as<uint32_t>(), (uint32_t)m,
                                     L.d_packed.as<uint8_t>(), L.d_poff.as<uint64_t>(), L.d_total.as<uint64_t>());
         if (r) return r;
+        HIP_OR_FAIL(L.h_status.reserve(64));
+        r = divans_gpu_codec_status_async(codec, L.h_status.as<uint32_t>()); if (r) return r;     // read in complete(), behind the lane's event
         // the packed streams are at most slot * m bytes, in practice about half the input: copy what a stream can be at most only
         // when the slice is tiny, otherwise the first bytes that can hold the whole slice at the input's size (checked on completion)
         HIP_OR_FAIL(hipMemcpyAsync(L.h_ooff.p, L.d_poff.p, 8 * m, hipMemcpyDeviceToHost, L.stream));
@@ -443,8 +445,7 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         ov.in_flight -= 1; ov.gpu_last = now_ms();
         divans_gpu_codec* codec = nullptr;
         int r = L.codec_for(probe.cfg, s.bound, opt->device, m, &codec); if (r) return r;
-        uint32_t status = 0;
-        if (divans_gpu_codec_status(codec, &status) || status) return set_last_error(DIVANS_GPU_EINVAL, "the literal coder reported an invalid model state");
+        if (L.h_status.as<uint32_t>()[0]) return set_last_error(DIVANS_GPU_EINVAL, "the literal coder reported an invalid model state");
         if (!plans_done) make_plans();
         if (plan_rc) return set_last_error(plan_rc, "a stream's command stream cannot be coded");
         // framing: Mux replay, EOF marker, CRC trailer per stream
@@ -561,27 +562,31 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             g->members.push_back(i); g->in_bytes += parsed[i].lit_size; g->out_bytes += parsed[i].total;
         }
         if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
-        size_t in_total = 0, out_total = 0, m_total = 0;
+        // the slice's decoded bytes sit in d_out exactly as they will in `out` (stream order, back to back): one copy brings them home
+        const size_t slice_out_base = out_offsets[b];
+        size_t in_total = 0, m_total = 0;
+        const size_t out_total = pos - slice_out_base;
         for (auto& g : groups) {
-            g.in_base = in_total; g.out_base = out_total; g.idx_base = m_total;
-            in_total += (g.in_bytes + 127) & ~(size_t)63; out_total += (g.out_bytes + 63) & ~(size_t)63; m_total += g.members.size();
+            g.in_base = in_total; g.out_base = 0; g.idx_base = m_total;
+            in_total += (g.in_bytes + 127) & ~(size_t)63; m_total += g.members.size();
         }
         HIP_OR_FAIL(L.h_in.reserve(in_total + 128)); HIP_OR_FAIL(L.h_off.reserve(8 * m_total)); HIP_OR_FAIL(L.h_sz.reserve(4 * m_total));
-        HIP_OR_FAIL(L.h_ooff.reserve(8 * m_total)); HIP_OR_FAIL(L.h_osz.reserve(4 * m_total)); HIP_OR_FAIL(L.h_out.reserve(out_total + 64));
-        HIP_OR_FAIL(L.h_flags.reserve(m_total + 64));
+        HIP_OR_FAIL(L.h_ooff.reserve(8 * m_total)); HIP_OR_FAIL(L.h_osz.reserve(4 * m_total));
+        HIP_OR_FAIL(L.h_out.reserve(out_total + 64));
+        HIP_OR_FAIL(L.h_flags.reserve(m_total + 64)); HIP_OR_FAIL(L.h_status.reserve(4 * groups.size() + 64));
         HIP_OR_FAIL(L.d_in.reserve(in_total + 128)); HIP_OR_FAIL(L.d_off.reserve(8 * m_total)); HIP_OR_FAIL(L.d_sz.reserve(4 * m_total));
         HIP_OR_FAIL(L.d_ooff.reserve(8 * m_total)); HIP_OR_FAIL(L.d_osz.reserve(4 * m_total)); HIP_OR_FAIL(L.d_out.reserve(out_total + 64));
         HIP_OR_FAIL(L.d_flags.reserve(m_total + 64));
         std::memset(L.h_in.p, 0, in_total + 128);     // the kernels read whole words past a stream's last byte
         for (auto& g : groups) {
-            uint64_t ip = 0, op = 0;
+            uint64_t ip = 0;
             std::vector<uint64_t> ioff(g.members.size());
             for (size_t j = 0; j < g.members.size(); ++j) {
                 const divans_host::ParsedStream& ps = parsed[g.members[j]];
                 ioff[j] = ip;
                 L.h_off.as<uint64_t>()[g.idx_base + j] = ip; L.h_sz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.lit_size;
-                L.h_ooff.as<uint64_t>()[g.idx_base + j] = op; L.h_osz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.total;
-                ip += ps.lit_size; op += ps.total;
+                L.h_ooff.as<uint64_t>()[g.idx_base + j] = out_offsets[g.members[j]] - slice_out_base; L.h_osz.as<uint32_t>()[g.idx_base + j] = (uint32_t)ps.total;
+                ip += ps.lit_size;
             }
             parallel_for(g.members.size(), opt->host_threads, [&](size_t j) {
                 const divans_host::ParsedStream& ps = parsed[g.members[j]];
@@ -605,8 +610,11 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
                                             (uint32_t)g.members.size(), L.d_out.as<uint8_t>() + g.out_base, L.d_ooff.as<uint64_t>() + g.idx_base,
                                             L.d_osz.as<uint32_t>() + g.idx_base, g.bound);
             if (r) return r;
+            r = divans_gpu_codec_status_async(codec, L.h_status.as<uint32_t>() + (&g - groups.data())); if (r) return r;
         }
-        HIP_OR_FAIL(hipMemcpyAsync(L.h_out.p, L.d_out.p, out_total, hipMemcpyDeviceToHost, L.stream));
+        // (copying straight into a caller's page-locked buffer instead was measured and is no faster: 186 vs 140 ms for 16 384 x 64 KiB,
+        // profiles/r04d_batch_container_rate_summary.txt -- the host copy below runs at 54 GB/s under the GPU work of the later slices)
+        if (out_total) HIP_OR_FAIL(hipMemcpyAsync(L.h_out.p, L.d_out.p, out_total, hipMemcpyDeviceToHost, L.stream));
         HIP_OR_FAIL(hipMemcpyAsync(L.h_flags.p, L.d_flags.p, m_total, hipMemcpyDeviceToHost, L.stream));
         HIP_OR_FAIL(hipEventRecord(L.done, L.stream));
         const double t1 = now_ms();
@@ -626,10 +634,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
         const double t0 = now_ms();
         std::vector<Group>& groups = slice_groups[k];
         for (auto& g : groups) {
-            divans_gpu_codec* codec = nullptr;
-            int r = L.codec_for(g.cfg, g.bound, opt->device, g.members.size(), &codec); if (r) return r;
-            uint32_t st = 0;
-            if (divans_gpu_codec_status(codec, &st)) return DIVANS_GPU_EHIP;
+            const uint32_t st = L.h_status.as<uint32_t>()[&g - groups.data()];     // copied behind the group's launch, in page-locked memory by now
             // the per-stream flags are the kernels' own record (the status word is the codec's, and a codec may have been rebuilt)
             bool flagged = false;
             for (size_t j = 0; j < g.members.size() && !flagged; ++j) flagged = L.h_flags.as<uint8_t>()[g.idx_base + j] != 0;
@@ -638,9 +643,12 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
                 for (size_t j = 0; j < g.members.size(); ++j) if (L.h_flags.as<uint8_t>()[g.idx_base + j]) { first = g.members[j]; out_sizes[first] = (size_t)-1; break; }
                 return set_last_error(DIVANS_GPU_ECORRUPT, "the LIT stream of container " + std::to_string(first) + " failed the decoder's integrity check");
             }
-            parallel_for(g.members.size(), opt->host_threads, [&](size_t j) {
-                const size_t i = g.members[j];
-                stream_copy(out + out_offsets[i], L.h_out.as<uint8_t>() + g.out_base + L.h_ooff.as<uint64_t>()[g.idx_base + j], parsed[i].total);
+        }
+        if (e > b) {      // the host threads bring the slice home, 256 KiB at a time
+            const size_t slice_out_base = out_offsets[b], bytes = out_offsets[e - 1] + parsed[e - 1].total - slice_out_base;
+            const size_t piece = (size_t)256 << 10, pieces = (bytes + piece - 1) / piece;
+            parallel_for(pieces, opt->host_threads, [&](size_t q) {
+                stream_copy(out + slice_out_base + q * piece, L.h_out.as<uint8_t>() + q * piece, std::min(piece, bytes - q * piece));
             });
         }
         for (size_t i = b; i < e; ++i) { std::vector<uint8_t>().swap(parsed[i].lit); std::vector<std::pair<uint32_t, uint32_t>>().swap(parsed[i].lit_spans); }

@@ -1022,6 +1022,13 @@ extern "C" int divans_gpu_codec_status(divans_gpu_codec* c, uint32_t* status) {
     return 0;
 }
 
+extern "C" int divans_gpu_codec_status_async(divans_gpu_codec* c, uint32_t* h_pinned_status) {
+    if (!c || !h_pinned_status) return fail(DIVANS_GPU_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(h_pinned_status, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
 extern "C" int divans_gpu_codec_last_decode_kernel(divans_gpu_codec* c, char* buf, size_t cap) {
     if (!c || !buf || !cap) return fail(DIVANS_GPU_EINVAL, "null argument");
     snprintf(buf, cap, "%s", c->last_decode_kernel);

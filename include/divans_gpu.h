@@ -158,6 +158,10 @@ int divans_gpu_codec_status(divans_gpu_codec *c, uint32_t *status);
 /* Clears the word without waiting (stream-ordered, before the launches that follow): for callers that keep a codec across calls
  * and may have abandoned a launch sequence without reading its status. */
 int divans_gpu_codec_clear_status(divans_gpu_codec *c);
+/* Enqueues a copy of the word into PAGE-LOCKED host memory behind the launches enqueued so far (no wait, no clear): read it once an
+ * event recorded after this call has completed.  (divans_gpu_codec_status copies into pageable memory and synchronises the stream, which
+ * costs ~10 ms per call while other streams keep the device busy.) */
+int divans_gpu_codec_status_async(divans_gpu_codec *c, uint32_t *h_pinned_status);
 /* Which stream: `d_flags` (device memory, >= n_streams bytes, zeroed by the caller; NULL = off) receives a 1 for every stream
  * of the following decode calls that fails that integrity check. */
 int divans_gpu_codec_set_stream_flags(divans_gpu_codec *c, uint8_t *d_flags);

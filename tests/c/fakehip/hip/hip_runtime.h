@@ -33,4 +33,5 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->recorded
 static inline hipError_t hipEventSynchronize(hipEvent_t e) { return e->recorded ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memcpy(dst, src, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { if (n) std::memset(dst, v, n); return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
 #endif

@@ -159,6 +159,11 @@ extern "C" int divans_gpu_codec_status(divans_gpu_codec* c, uint32_t* status) {
     *status = c->status; c->status = 0;
     return 0;
 }
+extern "C" int divans_gpu_codec_status_async(divans_gpu_codec* c, uint32_t* h) {
+    if (!c || !h) return fail(DIVANS_GPU_EINVAL, "null argument");
+    *h = c->status;
+    return 0;
+}
 extern "C" int divans_gpu_codec_clear_status(divans_gpu_codec* c) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     c->status = 0;

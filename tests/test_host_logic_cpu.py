@@ -351,3 +351,4 @@ def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, tmp_path,
     corpus.tofile(src)
     r = _run([exe, str(src), "9", str(rounds), str(largest)], timeout=1500, env=SAN_ENV)
     assert r.returncode == 0 and "all equal to the oracle's and back" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
