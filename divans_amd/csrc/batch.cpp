@@ -227,7 +227,7 @@ struct CodecKey {
 
 struct Lane {
     hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-    struct Entry { divans_gpu_codec* c; uint32_t full_grid; uint64_t used; };   // full_grid: the persistent grid the codec chose for a full GPU
+    struct Entry { divans_gpu_codec* c; uint32_t full_grid, cur_grid; uint64_t used; };   // full_grid: the persistent grid the codec chose for a full GPU; cur_grid: what it is set to
     std::map<CodecKey, Entry> codecs;     // at most kCodecsPerLane: a long-running process that sees many PredictionModes / length classes
     uint64_t tick = 0;                    // would otherwise pile up tables and scratch until hipMalloc fails
     static constexpr size_t kCodecsPerLane = 6;
@@ -261,14 +261,13 @@ struct Lane {
             if (rc) return rc;
             divans_gpu_info info;
             if (divans_gpu_codec_info(c, &info)) { divans_gpu_codec_destroy(c); return DIVANS_GPU_EHIP; }
-            it = codecs.emplace(key, Entry{c, info.blocks, 0}).first;
+            it = codecs.emplace(key, Entry{c, info.blocks, info.blocks, 0}).first;
         }
         it->second.used = ++tick;
         // a small slice does not need the full persistent grid's worth of CDF tables; a later, larger one gets the grid back
         const uint32_t want = (uint32_t)std::max<size_t>(1, std::min<size_t>(it->second.full_grid, (n_streams + 15) / 16));
-        divans_gpu_info info;
-        if (divans_gpu_codec_info(it->second.c, &info) == 0 && info.blocks != want)
-            (void)divans_gpu_codec_set_geometry(it->second.c, want, 0xffffffffu);
+        // (the grid is remembered here: asking the codec -- divans_gpu_codec_info -- waits for the events of its last launches)
+        if (it->second.cur_grid != want && divans_gpu_codec_set_geometry(it->second.c, want, 0xffffffffu) == 0) it->second.cur_grid = want;
         *out = it->second.c;
         return 0;
     }

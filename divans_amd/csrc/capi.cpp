@@ -587,9 +587,8 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
     if (fit == 0u) return fail(DIVANS_GPU_EINVAL, "these caches do not fit the 160 KB of LDS");
     uint32_t nb = blocks ? blocks : c->blocks2;
     nb = std::min(nb, c->num_cus * std::min(8u, fit));
-    if (generation == 2u && nb > c->blocks2 && c->d_tables) {   // more resident streams than the tables were sized for
-        HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0;
-    }
+    // (a larger grid than the tables were sized for: ensure_tables grows them at the next launch; they never shrink, so a codec
+    // that alternates between small and large batches -- the lanes of divans_batch_* do -- does not free and reallocate gigabytes)
     if (generation == 2u) c->blocks2 = std::max(1u, nb);
     c->decode_gen = generation;
     return 0;
