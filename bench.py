@@ -282,6 +282,8 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     if args.split_cache:
         hi_rows, lo_rows = (int(x) for x in args.split_cache.split(","))
         codec.set_split_cache(hi_rows, lo_rows)
+    if args.table_candidates > 1:
+        codec.tune_tables(args.table_candidates)      # acts on the first decode below (verification or warm-up), never inside the timed region
     outs = alloc_packed_outputs(torch, N, L, dev)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
     ok, checked = True, 0
@@ -342,6 +344,8 @@ def run_decode_only(torch, da, po, args, dev, copies=4096):
     d_out_sz = torch.tensor([b.size for b in blocks], dtype=torch.int32, device=dev).repeat(copies).contiguous()
     d_out = torch.zeros(copies * data.size, dtype=torch.uint8, device=dev)
     codec = da.LiteralCodec(da.config_context_mixing(), L, device=dev.index)
+    if args.table_candidates > 1:
+        codec.tune_tables(args.table_candidates)
     orig = torch.from_numpy(data).to(dev)
 
     def decode():
@@ -387,6 +391,8 @@ def main():
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
     ap.add_argument("--decoder-generation", type=int, default=0, help="decode kernel: 1 = lit_kernels.hip, 2 / 3 = lit_decode2.hip direct-mapped / 2-way caches (tuning; 0 = the codec's default)")
+    ap.add_argument("--table-candidates", type=int, default=4, help="placements of the CDF tables the first (untimed) decode of a codec tries before it keeps "
+                    "the fastest (divans_gpu_codec_tune_tables; 1 = take the first allocation as it comes)")
     ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
     ap.add_argument("--bucket-batch", type=int, default=0, help="streams per launch sequence of the two-model bucketed pass (tuning; default 32768)")
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
@@ -570,6 +576,7 @@ def main():
                 "encode_MBps": rec["encode_MBps"], "decode_MBps": rec["decode_MBps"],
                 "kernel_ms": rec["kernel_ms"], "roofline": rec["roofline"],
                 "encoder_work_bytes_per_input_byte": rec["encoder_work_bytes_per_input_byte"], "table_bytes": rec["table_bytes"],
+                "table_placement_candidates": max(1, args.table_candidates),
             }
             if "multi_gpu" in rec:
                 line["multi_gpu"] = rec["multi_gpu"]

@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -91,6 +93,9 @@ static void make_luts(uint8_t mode, uint8_t* lut0, uint8_t* lut1) {
     }
 }
 
+// the CDF tables' memory: a hipMalloc block (chunks empty) or an address range with physical chunks mapped into it (table_alloc)
+struct TableMem { int16_t* p = nullptr; size_t bytes = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk_bytes = 0, va_bytes = 0; int device = 0; };
+
 struct divans_gpu_codec {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -110,12 +115,15 @@ struct divans_gpu_codec {
     bool dm_auto = DIVANS_DM_AUTO_DEFAULT != 0;          // nobody chose between direct-mapped and 2-way caches (divans_gpu_codec_set_decoder): pick per batch
     uint32_t dm_log2 = 0, dm_shift = 0;   // LitBatch::dm_log2 / dm_shift
     uint32_t blocks2 = 0;                 // persistent grid of lit_decode2_kernel
+    uint32_t blocks_t = 0, t_log2 = 0, t_shift = 0;   // generation 4 (lit_decode_t.hip, one lane per stream): grid of 64-stream workgroups, cache rows / shifts
     bool user_geometry = false;           // set_geometry / set_split_cache / set_decoder were called: set_block_types keeps their choices
     char last_decode_kernel[128] = "";    // divans_gpu_codec_last_decode_kernel
     uint32_t last_decode_grid = 0;
     uint8_t* d_stream_flags = nullptr;    // caller-owned per-stream failure flags of the decode entry points (divans_gpu_codec_set_stream_flags)
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
+    TableMem tm;                          // what d_tables points into (table_alloc)
+    uint32_t table_candidates = 1; bool tables_tuned = false;   // divans_gpu_codec_tune_tables
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
     uint32_t* d_status = nullptr;
     // bucketed encoder model pass (lit_bucket.hip)
@@ -272,6 +280,10 @@ static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint
     g.cm_base = high_rows + low_rows;
     const bool mix = cfg.context_mixing > 1;  // Weights::should_mix, weights.rs:44-46
     g.total_rows = g.cm_base + (mix ? 17u * g.nctx : 0u);
+    if (const char* e = getenv("DIVANS_SLAB_ROWS_MOD")) {      // experiment: pad a stream's slab to r rows mod m ("m:r")
+        unsigned m = 0, r = 0;
+        if (sscanf(e, "%u:%u", &m, &r) == 2 && m > 1 && r < m) while (g.total_rows % m != r) ++g.total_rows;
+    }
     g.inc0 = cfg.literal_adaptation[0].inc; g.lim0 = cfg.literal_adaptation[0].lim;
     g.inc1 = cfg.literal_adaptation[1].inc; g.lim1 = cfg.literal_adaptation[1].lim;
     g.inc2 = cfg.literal_adaptation[2].inc; g.lim2 = cfg.literal_adaptation[2].lim;
@@ -297,7 +309,131 @@ static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
 
 static uint32_t groups_per_block(const divans_gpu_codec*) { return LIT_THREADS / 16; }
 static bool use_decode2(const divans_gpu_codec* c) { return c->decode_gen == 2u && c->blocks2 != 0u && !c->geom.wrap_check; }
-static uint32_t resident_groups(const divans_gpu_codec* c) { return std::max(c->blocks, use_decode2(c) ? c->blocks2 : 0u) * groups_per_block(c); }
+static bool use_decode_t(const divans_gpu_codec* c) { return c->decode_gen == 4u && c->blocks_t != 0u && !c->geom.wrap_check; }
+// streams that own a table slab at once
+static uint32_t resident_groups(const divans_gpu_codec* c) {
+    return std::max(std::max(c->blocks, use_decode2(c) ? c->blocks2 : 0u) * groups_per_block(c), use_decode_t(c) ? c->blocks_t * 64u : 0u);
+}
+
+// The CDF tables' memory.  How it is mapped changes the decode time by 10-20 % (profiles/r04e_table_placement.txt): one physically
+// contiguous block (hipDeviceMallocContiguous: large translation fragments) is the slowest, hipMalloc lands anywhere between that
+// and 10 % better from one allocation -- and one box -- to the next, 2 MiB chunks created one by one and mapped side by side into a
+// reserved address range (hipMemCreate / hipMemMap) are consistently the fastest.  That is what the tables use.
+// One rule comes with it: an address range is NEVER handed back (hipMemAddressFree).  On ROCm 7.2 a range that is unmapped, freed,
+// reserved again and mapped to new chunks reads and writes through stale translations -- scripts/probes/vmm_remap_probe.hip shows it
+// with nothing but the runtime API, and the decode kernels returned wrong bytes that way.  So a range a codec is done with stays
+// mapped and waits in a small per-process pool for the next codec that fits; a range the pool gives up is unmapped and its chunks
+// released, but its addresses stay reserved for the life of the process (address space, not memory).
+// DIVANS_TABLES_ALLOC = "hipmalloc" / "contiguous" / "scattered:<chunk MiB>[:noshuffle]" are measurement switches.
+static std::mutex g_table_pool_mu;
+static std::vector<TableMem> g_table_pool;            // mapped ranges no codec uses, oldest first
+constexpr size_t kTablePoolRanges = 2;
+
+static void table_release_chunks(TableMem& t) {        // unmap and give the memory back; the address range stays reserved (see above)
+    for (size_t i = 0; i < t.chunks.size(); ++i) (void)hipMemUnmap((uint8_t*)t.p + i * t.chunk_bytes, t.chunk_bytes);
+    for (auto h : t.chunks) (void)hipMemRelease(h);
+    t.chunks.clear();
+    t.p = nullptr; t.bytes = 0;
+}
+
+static void table_free(TableMem& t) {
+    if (!t.p) return;
+    if (t.chunks.empty()) { (void)hipFree(t.p); t.p = nullptr; t.bytes = 0; return; }
+    std::lock_guard<std::mutex> lock(g_table_pool_mu);
+    g_table_pool.push_back(std::move(t));
+    t = TableMem();
+    while (g_table_pool.size() > kTablePoolRanges) { table_release_chunks(g_table_pool.front()); g_table_pool.erase(g_table_pool.begin()); }
+}
+
+static void table_pool_drop(int device) {
+    std::lock_guard<std::mutex> lock(g_table_pool_mu);
+    for (size_t i = 0; i < g_table_pool.size();) {
+        if (g_table_pool[i].device == device) { table_release_chunks(g_table_pool[i]); g_table_pool.erase(g_table_pool.begin() + i); } else ++i;
+    }
+}
+
+static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, bool shuffle, TableMem& t) {
+    hipMemAllocationProp prop;
+    std::memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess || gran == 0) return e != hipSuccess ? e : hipErrorUnknown;
+    size_t chunk = std::max<size_t>(gran, chunk_mib << 20);
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (need + chunk - 1) / chunk;
+    void* va = nullptr;
+    e = hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0);
+    if (e != hipSuccess) return e;
+    std::vector<hipMemGenericAllocationHandle_t> hs;
+    for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, chunk, &prop, 0);
+        if (e == hipSuccess) hs.push_back(h);
+    }
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    if (shuffle) { uint64_t x = 0x9e3779b97f4a7c15ull; for (size_t i = n; i > 1; --i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(order[i - 1], order[x % i]); } }
+    size_t mapped = 0;
+    for (; mapped < n && e == hipSuccess; ++mapped) {
+        e = hipMemMap((uint8_t*)va + mapped * chunk, chunk, 0, hs[order[mapped]], 0);
+        if (e != hipSuccess) break;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc desc;
+        std::memset(&desc, 0, sizeof(desc));
+        desc.location.type = hipMemLocationTypeDevice; desc.location.id = device; desc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, n * chunk, &desc, 1);
+    }
+    if (e != hipSuccess) {       // (the range stays reserved here too)
+        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((uint8_t*)va + i * chunk, chunk);
+        for (auto h : hs) (void)hipMemRelease(h);
+        (void)hipGetLastError();
+        return e;
+    }
+    t.chunks.resize(n);
+    for (size_t i = 0; i < n; ++i) t.chunks[i] = hs[order[i]];      // in mapping order: table_release_chunks walks them
+    t.chunk_bytes = chunk; t.va_bytes = n * chunk;
+    t.p = (int16_t*)va; t.bytes = need; t.device = device;
+    return hipSuccess;
+}
+
+// fresh = never from the pool (divans_gpu_codec_tune_tables compares placements: it must not be handed the range it just put aside)
+// plain = one hipMalloc block whatever the mode (the tuning tries both kinds: which is faster differs from box to box)
+static hipError_t table_alloc(int device, size_t need, TableMem& t, bool fresh = false, bool plain = false) {
+    const char* mode = getenv("DIVANS_TABLES_ALLOC");
+    hipError_t e = hipErrorUnknown;
+    if (plain) {
+    } else if (!mode || mode[0] == 's') {
+        unsigned mib = 2; char tail[32] = "";
+        if (mode) (void)sscanf(mode, "scattered:%u:%31s", &mib, tail);
+        if (!fresh) {
+            std::lock_guard<std::mutex> lock(g_table_pool_mu);
+            size_t pick = g_table_pool.size();
+            for (size_t i = 0; i < g_table_pool.size(); ++i) {
+                const TableMem& m = g_table_pool[i];
+                if (m.device == device && m.va_bytes >= need && m.va_bytes <= need + need / 2 + (64u << 20) && m.chunk_bytes == std::max<size_t>(2u << 20, (size_t)mib << 20) &&
+                    (pick == g_table_pool.size() || m.va_bytes < g_table_pool[pick].va_bytes)) pick = i;
+            }
+            if (pick < g_table_pool.size()) {
+                t = std::move(g_table_pool[pick]);
+                g_table_pool.erase(g_table_pool.begin() + pick);
+                t.bytes = need;
+                return hipSuccess;
+            }
+        }
+        e = table_alloc_chunks(device, need, mib ? mib : 2, std::strcmp(tail, "noshuffle") != 0, t);
+        if (e != hipSuccess) { table_pool_drop(device); e = table_alloc_chunks(device, need, mib ? mib : 2, std::strcmp(tail, "noshuffle") != 0, t); }   // out of memory: the idle ranges first
+    } else if (mode[0] == 'c') {
+        e = hipExtMallocWithFlags((void**)&t.p, need, hipDeviceMallocContiguous);
+        if (e != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; }
+    }
+    if (e != hipSuccess) { e = hipMalloc((void**)&t.p, need); if (e != hipSuccess) t.p = nullptr; else { t.chunks.clear(); t.device = device; } }
+    if (e == hipSuccess) t.bytes = need;
+    return e;
+}
+
+static void free_tables(divans_gpu_codec* c) { table_free(c->tm); c->d_tables = nullptr; c->tables_bytes = 0; c->tables_tuned = false; }
 
 static int ensure_tables(divans_gpu_codec* c) {
     // big geometries (many context columns / planes) shrink the persistent grid instead of asking for hundreds of GB:
@@ -308,11 +444,14 @@ static int ensure_tables(divans_gpu_codec* c) {
         const size_t budget = std::max<size_t>(free_b / 4, per_block);
         if ((size_t)c->blocks * per_block > budget) c->blocks = (uint32_t)std::max<size_t>(1, budget / per_block);
         if ((size_t)c->blocks2 * per_block > budget) c->blocks2 = (uint32_t)std::max<size_t>(1, budget / per_block);
+        if ((size_t)c->blocks_t * 4u * per_block > budget) c->blocks_t = (uint32_t)std::max<size_t>(1, budget / (4u * per_block));
     }
     const size_t need = (size_t)resident_groups(c) * c->geom.total_rows * 32u;
     if (need <= c->tables_bytes) return 0;
-    if (c->d_tables) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }
-    if (hipMalloc(&c->d_tables, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(CDF tables) failed");
+    if (c->d_tables) { HIP_TRY(hipStreamSynchronize(c->stream)); free_tables(c); }
+    if (table_alloc(c->device, need, c->tm) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(CDF tables) failed");
+    c->d_tables = c->tm.p;
+    if (getenv("DIVANS_DEBUG_ALLOC")) fprintf(stderr, "[divans] tables %p + %zu in %zu chunks\n", (void*)c->d_tables, need, c->tm.chunks.size());
     c->tables_bytes = need;
     return 0;
 }
@@ -351,7 +490,10 @@ static void configure_from_geometry(divans_gpu_codec* c) {
         if (c->mix) { c->dm_log2 = 5u | (5u << 8); c->dm_shift = 5u | (5u << 8); }
         else { c->dm_log2 = 6u; c->dm_shift = c->geom.ctx_const >= 0 ? 31u : 5u; }
     }
-    c->dm_shift |= 0x80000000u;   // 2-way organisation (generation 3): fewer misses than direct mapped at the same time per byte
+    // organisation: 2-way sets (generation 3) without mixing -- fewer misses at the same time per byte --, direct mapped (generation 2) with:
+    // since the high stride rows are laid out [class slot][prev] (hs_classes) the direct-mapped lookup is 5-8 % ahead there on tables
+    // placed alike (profiles/r04e_table_placement.txt: 433-442 vs 467-480 ms for 65 536 streams)
+    if (!c->mix) c->dm_shift |= 0x80000000u;
     {
         const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
         const uint32_t lds_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(c->dm_log2) + 256u /* byte ranks */ +
@@ -404,7 +546,7 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->d_blob) (void)hipFree(c->d_blob);
-    if (c->d_tables) (void)hipFree(c->d_tables);
+    free_tables(c);
     if (c->d_sf) (void)hipFree(c->d_sf);
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_slots) (void)hipFree(c->d_slots);
@@ -509,7 +651,7 @@ extern "C" int divans_gpu_codec_set_block_types(divans_gpu_codec* c, uint32_t n_
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(c->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     c->geom = g;
-    if (c->d_tables) { HIP_TRY(hipFree(c->d_tables)); c->d_tables = nullptr; c->tables_bytes = 0; }
+    free_tables(c);
     // the block types change the LDS the context tables take, not what the caller chose before: keep an explicitly set
     // grid / cache organisation / decoder generation, clamped to what still fits the LDS (and to caches the new row count allows)
     const uint32_t blocks = c->blocks, blocks2 = c->blocks2, ch = c->cache_high, cl = c->cache_low, gen = c->decode_gen, lg = c->dm_log2, sh = c->dm_shift;
@@ -559,8 +701,37 @@ extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t genera
 static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks, bool by_user) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (by_user) c->user_geometry = true;
-    if (generation < 1u || generation > 3u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches) or 3 (second generation, 2-way caches)");
+    if (generation < 1u || generation > 4u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches), 3 (second generation, 2-way caches) or 4 (one lane per stream)");
     HIP_TRY(hipSetDevice(c->device));
+    if (generation == 4u) {
+        // lit_decode_t.hip: rows[i] slots of the four direct-mapped per-stream caches (0 = one slot, the staging buffer the kernel needs anyway)
+        if (c->geom.wrap_check) return fail(DIVANS_GPU_EINVAL, "generation 4 does not run speeds whose row totals leave i16");
+        if (c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "generation 4 needs fewer than 32767 rows per stream");
+        uint32_t lg2 = c->t_log2, sh = c->t_shift;
+        if (rows && shifts) {
+            lg2 = 0; sh = 0;
+            for (int i = 0; i < 4; ++i) {
+                if (rows[i]) {
+                    if (rows[i] > 256u || (rows[i] & (rows[i] - 1u))) return fail(DIVANS_GPU_EINVAL, "cache rows must be 0 or a power of two up to 256");
+                    uint32_t l = 0; while ((1u << l) < rows[i]) ++l;
+                    lg2 |= (l + 1u) << (8 * i);
+                }
+                if (shifts[i] > 31u) return fail(DIVANS_GPU_EINVAL, "hash shift must be below 32");
+                sh |= shifts[i] << (8 * i);
+            }
+        }
+        const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
+        const uint32_t per_wg = 64u * lit_decode_t_stream_lds(lg2, c->mix) + 256u +
+                                (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
+        const uint32_t fit = (160u * 1024u) / per_wg;
+        if (fit == 0u) return fail(DIVANS_GPU_EINVAL, "these caches do not fit the 160 KB of LDS");
+        uint32_t nb = blocks ? blocks : (c->blocks_t ? c->blocks_t : c->num_cus * 4u);      // default: one wave per SIMD
+        nb = std::min(nb, c->num_cus * std::min(32u, fit));
+        c->t_log2 = lg2; c->t_shift = sh; c->blocks_t = std::max(1u, nb);
+        c->decode_gen = 4u;
+        if (by_user) c->dm_auto = false;
+        return 0;
+    }
     const bool two_way = generation == 3u;
     if (by_user) c->dm_auto = false;
     if (generation == 3u) generation = 2u;
@@ -591,6 +762,14 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
     // that alternates between small and large batches -- the lanes of divans_batch_* do -- does not free and reallocate gigabytes)
     if (generation == 2u) c->blocks2 = std::max(1u, nb);
     c->decode_gen = generation;
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t candidates) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (candidates == 0u || candidates > 8u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [1, 8]");
+    c->table_candidates = candidates;
+    c->tables_tuned = false;
     return 0;
 }
 
@@ -906,7 +1085,12 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
     if (d_segs && !use_decode2(c) && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
-    if (use_decode2(c)) {
+    const bool transposed = use_decode_t(c) && !d_segs;      // (segment lists: the first generation's kernel)
+    if (transposed) {
+        b.dm_log2 = c->t_log2; b.dm_shift = c->t_shift;
+        b.cache_bytes_per_wg = 64u * lit_decode_t_stream_lds(c->t_log2, c->mix);
+        c->last_decode_grid = std::min(c->blocks_t, (n_streams + 63u) / 64u);
+    } else if (use_decode2(c)) {
         b.dm_log2 = lit_decode2_effective_caches(c->dm_log2, c->mix, d_segs != nullptr); b.dm_shift = c->dm_shift;
         // A batch that is resident all at once runs at the latency of a stream's dependency chain, and the direct-mapped lookup is
         // the shorter chain (16 384 streams: 60.3 vs 63.5 ms, mixing 138 vs 142); only a batch that keeps the grid busy for several
@@ -936,10 +1120,42 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
         c->last_decode_grid = grid;
     }
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    if (use_decode2(c)) { lit_decode2_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode2(b, c->mix, c->last_decode_grid, c->stream)); }
-    else { lit_decode_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream)); }
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    auto launch = [&]() -> int {
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        if (transposed) { lit_decode_t_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode_t(b, c->mix, c->last_decode_grid, c->stream)); }
+        else if (use_decode2(c)) { lit_decode2_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode2(b, c->mix, c->last_decode_grid, c->stream)); }
+        else { lit_decode_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream)); }
+        HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+        return 0;
+    };
+    rc = launch(); if (rc) return rc;
+    // divans_gpu_codec_tune_tables: the first batch that fills at least half the grid is decoded once per candidate placement of the tables (the same
+    // bytes come out every time) and the fastest placement stays
+    if (c->table_candidates > 1u && !c->tables_tuned && 2u * (uint64_t)n_streams >= resident_groups(c)) {
+        float best = 0.f;
+        HIP_TRY(hipEventSynchronize(c->ev[4]));
+        HIP_TRY(hipEventElapsedTime(&best, c->ev[3], c->ev[4]));
+        std::vector<TableMem> aside;
+        for (uint32_t k = 1; k < c->table_candidates; ++k) {
+            TableMem cand;
+            if (table_alloc(c->device, c->tm.bytes, cand, true, (k & 1u) != 0u) != hipSuccess) { (void)hipGetLastError(); break; }     // no room for a second copy: keep what we have
+            std::swap(c->tm, cand);
+            c->d_tables = c->tm.p; b.tables = c->d_tables;
+            rc = launch();
+            float t = 0.f;
+            if (!rc && (hipEventSynchronize(c->ev[4]) != hipSuccess || hipEventElapsedTime(&t, c->ev[3], c->ev[4]) != hipSuccess)) rc = fail(DIVANS_GPU_EHIP, "timing a candidate table placement failed");
+            if (getenv("DIVANS_DEBUG_ALLOC")) fprintf(stderr, "[divans] table placement %u (%s): %.2f ms (best so far %.2f)\n", k, c->tm.chunks.empty() ? "one block" : "chunks", t, best);
+            if (rc || t >= best) { std::swap(c->tm, cand); c->d_tables = c->tm.p; b.tables = c->d_tables; }    // the earlier one stays
+            else best = t;
+            aside.push_back(std::move(cand));
+            if (rc) break;
+        }
+        for (auto& m : aside) table_free(m);
+        if (rc) return rc;
+        c->last_decode_ms = best; c->timing_pending_dec = false;
+        c->tables_tuned = true;
+        return 0;       // (the events hold the last candidate's time; last_decode_ms the kept one's)
+    }
     c->timing_pending_dec = true;
     return 0;
 }

@@ -55,23 +55,7 @@ __device__ __forceinline__ uint32_t lds_read8(uint32_t a) { return *(const lds_u
 __device__ __forceinline__ uint32_t lds_read32(uint32_t a) { return *(const lds_u32*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_write32(uint32_t a, uint32_t v) { *(lds_u32*)(uintptr_t)a = v; }
 
-// Which 128-byte line of a stream's table a row shares with three others is free to choose (the table is private to the launch,
-// any bijection of the row index decodes the same bytes), and it decides how many of the stream's row accesses the L2 can serve:
-// with 28 672 resident streams a stream owns about 1 KB of it, eight lines.  The stride-1 tables are indexed by the previous
-// byte; its four neighbours in a line are the next byte values in THIS order instead of numeric order -- lower-case letters by
-// their usual English frequency first, then the separators, capitals, digits, everything else numerically -- so that the bytes
-// text keeps coming back to sit together (an LRU model of 1 KB per stream misses 51 % instead of 67 % of the low-row accesses
-// of the benchmark text; for data without such a skew the order is as good as any other).
-struct BytePerm {
-    uint8_t rank[256];
-    constexpr BytePerm() : rank{} {
-        const char order[] = " etaoinshrdlcumwfgypbvkjxqz\n,.;'\"-!?:()TAISOWHBCMNEPDLFRGYUVKJQXZ0123456789";
-        bool used[256] = {};
-        uint32_t n = 0;
-        for (uint32_t i = 0; i + 1u < sizeof(order); ++i) { const uint8_t b = (uint8_t)order[i]; if (!used[b]) { used[b] = true; rank[b] = (uint8_t)n++; } }
-        for (uint32_t b = 0; b < 256u; ++b) if (!used[b]) rank[b] = (uint8_t)n++;
-    }
-};
+// BytePerm (lit_device.h): the order in which the stride-1 tables lay the previous byte's rows out
 __device__ const BytePerm kBytePerm{};
 
 constexpr uint32_t kRingWords = 32u;

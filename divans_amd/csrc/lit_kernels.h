@@ -150,6 +150,10 @@ void lit_decode_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);
 void lit_decode2_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);
 uint32_t lit_decode2_effective_caches(uint32_t dm_log2, bool mix, bool seg);   // the caches of dm_log2 a kernel instance exists for
 uint32_t lit_decode2_stream_lds(uint32_t dm_log2);   // LDS bytes one stream takes in lit_decode2_kernel (word ring + row caches)
+// lit_decode_t.hip: one lane per stream (decoder generation 4); 64 streams per workgroup
+hipError_t launch_decode_t(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
+void lit_decode_t_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);
+uint32_t lit_decode_t_stream_lds(uint32_t dm_log2, bool mix);   // LDS bytes one stream takes there
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
                        uint64_t* dst_off, uint64_t* total, hipStream_t st, bool accumulate = false, uint64_t cap = ~0ull, uint32_t* status = nullptr);
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);

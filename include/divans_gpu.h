@@ -248,6 +248,14 @@ int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
 int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4],
                                  uint32_t blocks);
 
+/* Where the CDF tables' pages lie in device memory moves the decode time by several percent from one allocation to the next
+ * (DESIGN.md section 5).  A long-lived codec can ask for the placement to be tuned: the next divans_gpu_lit_decode_batch call whose
+ * batch fills at least half the persistent grid runs its launch `candidates` times (1..8; 1 = off, the default), each time on a freshly allocated
+ * copy of the tables -- alternately 2 MiB chunks mapped side by side (what the tables use by default) and one hipMalloc block; which
+ * kind is faster differs from box to box --, the same bytes come out every time; it synchronises and keeps the fastest.  The copies
+ * exist side by side while it runs.  Tuned again after the tables had to be re-allocated. */
+int divans_gpu_codec_tune_tables(divans_gpu_codec *c, uint32_t candidates);
+
 /* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */
 int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, uint32_t low_rows);
 

@@ -2,7 +2,9 @@
 """Tuning aid: decode time of the second-generation decoder (lit_decode2.hip) over cache geometries and persistent grids, next
 to the first generation's default, one process, data built once.
 
-    python scripts/decode2_sweep.py [--streams 65536] [--config simple|mixing] [--geoms hs:hc:ls:lc:sh_hs:sh_hc:sh_ls:sh_lc:wg,...]
+    python scripts/decode2_sweep.py [--streams 65536] [--config simple|mixing] [--geoms hs:hc:ls:lc:sh_hs:sh_hc:sh_ls:sh_lc:wg[:gen],...]
+
+gen 4 = lit_decode_t.hip (one lane per stream): wg = 64-stream workgroups per CU.
 """
 import argparse
 import os
@@ -58,6 +60,7 @@ def main():
     run("gen1 default", lambda c: c.set_decoder(1))
     run("gen2 default (direct mapped)", lambda c: c.set_decoder(2))
     run("gen3 default (2-way)", lambda c: c.set_decoder(3))
+    run("gen4 default (one lane per stream, no caches, one wave per SIMD)", lambda c: c.set_decoder(4))
     if args.geoms:
         geoms = [tuple(int(x) for x in g.split(":")) for g in args.geoms.split(",")]
     elif args.config == "simple":

@@ -200,6 +200,12 @@ def test_generic_mixing_mask_and_context_maps(mixing, mode, corpus, random_then_
             got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
             assert got.size == ref.size and (got == ref).all(), (vs, i)
         assert (codec.decode_host(packed, offs, sizes, L) == blocks).all()
+        try:
+            codec.set_decoder(4, (8, 4, 0, 2), (3, 5, 5, 1))      # one lane per stream (lit_decode_t.hip), table-driven instances
+        except da.DivansGpuError as e:
+            assert "32767 rows" in str(e)                         # (its 15-bit cache tags; the value sets with three planes exceed them)
+        else:
+            assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), "generation 4"
         codec.close()
 
 
@@ -218,6 +224,8 @@ def test_uniform_mm0_specialisation(corpus):
     for i in range(6):
         assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == po.lit_encode(o, blocks[i])).all()
     assert (codec.decode_host(packed, offs, sizes, 9000) == blocks).all()
+    codec.set_decoder(4)
+    assert (codec.decode_host(packed, offs, sizes, 9000) == blocks).all(), "generation 4"
     codec.close()
 
 
@@ -347,7 +355,7 @@ def test_speeds_whose_total_stays_above_lim(mixing, encode_path, corpus, random_
             ref = po.lit_encode(o, blocks[i])
             got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
             assert got.size == ref.size and (got == ref).all(), (speeds, i)
-        for gen in (1, 3):
+        for gen in (1, 3, 4):
             codec.set_decoder(gen)
             assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), gen
         codec.close()
@@ -710,17 +718,102 @@ def test_decoder2_cache_geometries(cfg_name, generation, geom, corpus, shuffle38
     codec.close()
 
 
+# ---- generation 4 (lit_decode_t.hip): one lane per stream, direct-mapped caches laid out by lane ----
+_T_GEOMETRIES = [
+    ((0, 0, 0, 0), (5, 5, 5, 5)),        # no caches: one staging slot per table
+    ((4, 4, 4, 4), (0, 1, 2, 3)),        # evictions on almost every access, four different hashes
+    ((16, 16, 0, 0), (5, 5, 5, 5)),
+    ((8, 2, 1, 16), (8, 31, 4, 5)),
+    ((32, 0, 16, 0), (31, 5, 7, 5)),
+]
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+@pytest.mark.parametrize("geom", range(len(_T_GEOMETRIES)))
+def test_lane_per_stream_decoder_geometries(cfg_name, geom, corpus, shuffle384, random_then_unicode):
+    """ragged streams (a wave's lanes finish at different times, three rounds of a one-workgroup grid with live and idle lanes), lengths
+    across the 32 KiB chunk boundary, unaligned output offsets"""
+    import torch
+    rows, shifts = _T_GEOMETRIES[geom]
+    L = 40000
+    n = 150
+    rng = np.random.default_rng(geom)
+    lens = [int(x) for x in rng.integers(1, 3000, n)]
+    lens[0] = L; lens[1] = 32768; lens[2] = 32769; lens[3] = 17; lens[70] = 33000; lens[149] = 1
+    srcs = [corpus, random_then_unicode, np.resize(shuffle384, 200000), np.resize(np.frombuffer(b"abracadabra ", dtype=np.uint8), 200000)]
+    parts = [srcs[i % 4][1000 * i:1000 * i + lens[i]] for i in range(n)]
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    flat = np.concatenate(parts)
+    dev = torch.device("cuda", 0)
+    da, codec = _codec(cfg_name, L)
+    codec.set_decoder(4, rows, shifts, blocks=1)
+    d_in = torch.from_numpy(np.concatenate([flat, np.zeros(64, np.uint8)])).to(dev)
+    outs = codec.alloc_encode_outputs(n)
+    d_off = torch.tensor(starts, dtype=torch.int64, device=dev); d_sz = torch.tensor(lens, dtype=torch.int32, device=dev)
+    codec.encode_batch(d_in, n, L, outs, in_offsets=d_off, in_sizes=d_sz)
+    d_back = torch.zeros(sum(lens) + 64, dtype=torch.uint8, device=dev)
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, L, d_back, out_offsets=d_off, out_sizes=d_sz)
+    torch.cuda.synchronize()
+    assert "lit_decode_t_kernel" in codec.last_decode_kernel()
+    back = d_back.cpu().numpy()
+    assert (back[:sum(lens)] == flat).all(), (cfg_name, rows, int(np.argmax(back[:sum(lens)] != flat)))
+    assert (back[sum(lens):] == 0).all()
+    assert codec.status() == 0
+    offs = outs["offsets"].cpu().numpy(); szs = outs["sizes"].cpu().numpy(); blob = outs["out"].cpu().numpy()
+    ocfg = _oracle_cfg(cfg_name)
+    for i in (0, 2, 3, 70, 149):
+        ref = po.lit_encode(ocfg, flat[starts[i]:starts[i] + lens[i]])
+        assert szs[i] == ref.size and (blob[offs[i]:offs[i] + szs[i]] == ref).all(), i
+    codec.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_table_placement_tuning_changes_no_byte(cfg_name, corpus):
+    """divans_gpu_codec_tune_tables: the decode that tunes (three copies of the tables, the launch repeated on each) and the ones after it
+    return what an untuned codec returns; a batch too small to time tunes nothing; bad arguments are refused"""
+    import torch
+    da, codec = _codec(cfg_name, 2048)
+    resident = codec.info().resident_groups
+    n = resident // 2 + 16
+    blocks = workload.make_blocks(corpus, 3, n, block_len=2048)
+    d_in = torch.from_numpy(blocks).cuda()
+    outs = codec.alloc_encode_outputs(n, 2048)
+    codec.encode_batch(d_in, n, 2048, outs)
+    plain = torch.zeros((n, 2048), dtype=torch.uint8, device="cuda")
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, plain)
+    assert torch.equal(plain, d_in) and codec.status() == 0
+    with pytest.raises(da.DivansGpuError):
+        codec.tune_tables(0)
+    with pytest.raises(da.DivansGpuError):
+        codec.tune_tables(9)
+    codec.tune_tables(3)
+    few = torch.zeros((40, 2048), dtype=torch.uint8, device="cuda")
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], 40, 2048, few)          # below half the grid: not the batch to time
+    assert torch.equal(few, d_in[:40])
+    for _ in range(3):                                                                      # the first of these tunes
+        back = torch.zeros((n, 2048), dtype=torch.uint8, device="cuda")
+        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
+        assert torch.equal(back, d_in) and codec.status() == 0
+        assert codec.info().last_decode_ms > 0
+    # a damaged stream is still reported by a tuning decode
+    codec.tune_tables(2)
+    coded = outs["out"].clone(); coded[int(outs["offsets"][5]) + 30] ^= 0x40
+    codec.decode_batch(coded, outs["offsets"], outs["sizes"], n, 2048, back)
+    assert codec.status() & 2
+    codec.close()
+
+
 @pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
 def test_both_decoder_generations_agree(cfg_name, corpus):
     blocks = workload.make_blocks(corpus, 40, 300, block_len=3000)
     da, codec = _codec(cfg_name, 3000)
     packed, offs, sizes = codec.encode_host(blocks, 3000)
-    for gen in (1, 2, 3):
+    for gen in (1, 2, 3, 4):
         codec.set_decoder(gen)
         assert (codec.decode_host(packed, offs, sizes, 3000) == blocks).all(), gen
     # a damaged stream fails the integrity check of either generation
     bad = packed.copy(); bad[int(offs[7]) + 40] ^= 0x10
-    for gen in (1, 2, 3):
+    for gen in (1, 2, 3, 4):
         codec.set_decoder(gen)
         with pytest.raises(da.DivansGpuError):
             codec.decode_host(bad, offs, sizes, 3000)
@@ -776,7 +869,7 @@ def test_decoder_survives_thousands_of_damaged_streams(cfg_name, corpus):
     flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
     assert codec._lib.divans_gpu_codec_set_stream_flags(codec._h, ctypes.c_void_p(flags.data_ptr())) == 0
     results = []
-    for gen in (1, 2, 3):
+    for gen in (1, 2, 3, 4):
         codec.set_decoder(gen)
         flags.zero_()
         d_back = torch.full((n, L), 0xEE, dtype=torch.uint8, device="cuda")
