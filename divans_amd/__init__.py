@@ -130,6 +130,7 @@ def load_library():
     L.divans_gpu_codec_set_geometry.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_tune_tables.argtypes = [vp, u32]
+    L.divans_gpu_trim.argtypes = []; L.divans_gpu_trim.restype = None
     L.divans_gpu_codec_set_decoder.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]
     L.divans_gpu_codec_set_decoder.restype = ctypes.c_int
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
@@ -191,7 +192,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_encode_packed", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_status_async", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
@@ -294,6 +295,11 @@ def config_context_mixing():
 def speed_supported(inc, lim):
     """True when (inc, lim) is a literal_adaptation speed the GPU coder accepts (no row count ever leaves i16 under it)."""
     return bool(load_library().divans_gpu_speed_supported(int(inc), int(lim)))
+
+
+def trim():
+    """give the memory of the idle table ranges back (divans_gpu_trim)"""
+    load_library().divans_gpu_trim()
 
 
 def speed_accepted(inc, lim):

@@ -345,10 +345,10 @@ static void table_free(TableMem& t) {
     while (g_table_pool.size() > kTablePoolRanges) { table_release_chunks(g_table_pool.front()); g_table_pool.erase(g_table_pool.begin()); }
 }
 
-static void table_pool_drop(int device) {
+static void table_pool_drop(int device) {      // device < 0: every device
     std::lock_guard<std::mutex> lock(g_table_pool_mu);
     for (size_t i = 0; i < g_table_pool.size();) {
-        if (g_table_pool[i].device == device) { table_release_chunks(g_table_pool[i]); g_table_pool.erase(g_table_pool.begin() + i); } else ++i;
+        if (device < 0 || g_table_pool[i].device == device) { table_release_chunks(g_table_pool[i]); g_table_pool.erase(g_table_pool.begin() + i); } else ++i;
     }
 }
 
@@ -764,6 +764,8 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
     c->decode_gen = generation;
     return 0;
 }
+
+extern "C" void divans_gpu_trim(void) { table_pool_drop(-1); }
 
 extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t candidates) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");

@@ -255,6 +255,9 @@ int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const
  * kind is faster differs from box to box --, the same bytes come out every time; it synchronises and keeps the fastest.  The copies
  * exist side by side while it runs.  Tuned again after the tables had to be re-allocated. */
 int divans_gpu_codec_tune_tables(divans_gpu_codec *c, uint32_t candidates);
+/* A destroyed codec's tables stay mapped (at most two ranges per process) for the next codec that fits -- their address ranges are never
+ * handed back to the driver, see DESIGN.md section 5.  This gives the MEMORY of the idle ranges back now. */
+void divans_gpu_trim(void);
 
 /* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */
 int divans_gpu_codec_set_split_cache(divans_gpu_codec *c, uint32_t high_rows, uint32_t low_rows);

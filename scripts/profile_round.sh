@@ -10,7 +10,9 @@ mkdir -p /tmp/divans_cache
 run_config () {
   local CFG=$1; shift
   local FULL=$1; shift
-  local ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --host-data --input-cache /tmp/divans_cache --check-streams 64"
+  # --table-candidates 1: the averages are over the timed launches only, on the placement the first allocation got
+  local ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --host-data --input-cache /tmp/divans_cache --check-streams 64 --table-candidates 1"
+  [ -n "${PROFILE_FULL:-}" ] && FULL=$PROFILE_FULL      # PROFILE_FULL=0: kernel stats + FETCH_SIZE / WRITE_SIZE only, for every configuration
   local OUT=$REPO/gpurun_out/prof_$TAG/$CFG
   mkdir -p $OUT
   echo "python bench.py $ARGS" > $OUT/cmd.txt

@@ -800,7 +800,18 @@ def test_table_placement_tuning_changes_no_byte(cfg_name, corpus):
     coded = outs["out"].clone(); coded[int(outs["offsets"][5]) + 30] ^= 0x40
     codec.decode_batch(coded, outs["offsets"], outs["sizes"], n, 2048, back)
     assert codec.status() & 2
+    tables = codec.info().table_bytes
     codec.close()
+    # the tables of a closed codec wait (mapped) for the next one; divans_gpu_trim gives their memory back
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    da.trim()
+    assert torch.cuda.mem_get_info()[0] >= before + tables // 2
+    da.trim()                                       # nothing left: a no-op
+    da2, codec2 = _codec(cfg_name, 2048)            # and a codec made afterwards maps a new range
+    codec2.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
+    assert torch.equal(back, d_in) and codec2.status() == 0
+    codec2.close()
 
 
 @pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
