@@ -769,7 +769,7 @@ extern "C" void divans_gpu_trim(void) { table_pool_drop(-1); }
 
 extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t candidates) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    if (candidates == 0u || candidates > 8u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [1, 8]");
+    if (candidates == 0u || candidates > 16u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [1, 16]");
     c->table_candidates = candidates;
     c->tables_tuned = false;
     return 0;
