@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--config", default="simple")
     ap.add_argument("--streams", type=int, default=65536)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--codecs", type=int, default=1, help="this many codecs alive at once (each with its own tables), decoding in turn")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -44,14 +45,18 @@ def main():
     outs = codec.alloc_encode_outputs(N, L)
     codec.encode_batch(d_in, N, L, outs)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
-    ms = []
-    for _ in range(args.reps):
-        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
-        torch.cuda.synchronize()
-        ms.append(codec.info().last_decode_ms)
-    ok = codec.status() == 0 and bytes(d_back[N // 3, 1000:1100].cpu().numpy()) == bytes(d_in[N // 3, 1000:1100].cpu().numpy())
-    print(f"{args.config} {N} streams, tables {os.environ.get('DIVANS_TABLES_ALLOC', 'chunks')}: decode {' '.join('%.2f' % m for m in ms)} ms  ok={ok}", flush=True)
-    codec.close()
+    codecs = [codec] + [da.LiteralCodec(cfg, L) for _ in range(args.codecs - 1)]
+    for k, c in enumerate(codecs):
+        c.set_decoder(2)
+        ms = []
+        for _ in range(args.reps):
+            c.decode_batch(outs["out"], outs["offsets"], outs["sizes"], N, L, d_back)
+            torch.cuda.synchronize()
+            ms.append(c.info().last_decode_ms)
+        ok = c.status() == 0 and bytes(d_back[N // 3, 1000:1100].cpu().numpy()) == bytes(d_in[N // 3, 1000:1100].cpu().numpy())
+        print(f"codec {k}: {args.config} {N} streams, tables {os.environ.get('DIVANS_TABLES_ALLOC', 'chunks')}: decode {' '.join('%.2f' % m for m in ms)} ms  ok={ok}", flush=True)
+    for c in codecs:
+        c.close()
 
 
 if __name__ == "__main__":
