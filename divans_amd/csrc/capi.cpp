@@ -403,16 +403,20 @@ static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, 
 static hipError_t table_alloc(int device, size_t need, TableMem& t, bool fresh = false, bool plain = false) {
     const char* mode = getenv("DIVANS_TABLES_ALLOC");
     hipError_t e = hipErrorUnknown;
-    if (plain) {
+    // Every mapped chunk is a buffer object of its own, and a process that holds thousands of them pays for it in every other runtime call:
+    // with 2 MiB chunks under the tables of the eight lanes of divans_batch_* the many-containers ABI fell from 8.0 / 8.0 to 6.7 / 4.9 GB/s
+    // (profiles/r04f_batch_container_rate_ab.txt).  So: 32 MiB chunks (as fast as 2 MiB ones, profiles/r04e_table_placement.txt), and only for
+    // tables of 2 GiB and more -- the persistent grids of whole-GPU batches, where the placement is worth 10-20 %; smaller tables are one block.
+    if (plain || (!mode && need < ((size_t)2 << 30))) {
     } else if (!mode || mode[0] == 's') {
-        unsigned mib = 2; char tail[32] = "";
+        unsigned mib = 32; char tail[32] = "";
         if (mode) (void)sscanf(mode, "scattered:%u:%31s", &mib, tail);
         if (!fresh) {
             std::lock_guard<std::mutex> lock(g_table_pool_mu);
             size_t pick = g_table_pool.size();
             for (size_t i = 0; i < g_table_pool.size(); ++i) {
                 const TableMem& m = g_table_pool[i];
-                if (m.device == device && m.va_bytes >= need && m.va_bytes <= need + need / 2 + (64u << 20) && m.chunk_bytes == std::max<size_t>(2u << 20, (size_t)mib << 20) &&
+                if (m.device == device && m.va_bytes >= need && m.va_bytes <= need + need / 2 + (64u << 20) && m.chunk_bytes == ((size_t)mib << 20) &&
                     (pick == g_table_pool.size() || m.va_bytes < g_table_pool[pick].va_bytes)) pick = i;
             }
             if (pick < g_table_pool.size()) {
@@ -422,8 +426,8 @@ static hipError_t table_alloc(int device, size_t need, TableMem& t, bool fresh =
                 return hipSuccess;
             }
         }
-        e = table_alloc_chunks(device, need, mib ? mib : 2, std::strcmp(tail, "noshuffle") != 0, t);
-        if (e != hipSuccess) { table_pool_drop(device); e = table_alloc_chunks(device, need, mib ? mib : 2, std::strcmp(tail, "noshuffle") != 0, t); }   // out of memory: the idle ranges first
+        e = table_alloc_chunks(device, need, mib ? mib : 32, std::strcmp(tail, "noshuffle") != 0, t);
+        if (e != hipSuccess) { table_pool_drop(device); e = table_alloc_chunks(device, need, mib ? mib : 32, std::strcmp(tail, "noshuffle") != 0, t); }   // out of memory: the idle ranges first
     } else if (mode[0] == 'c') {
         e = hipExtMallocWithFlags((void**)&t.p, need, hipDeviceMallocContiguous);
         if (e != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; }

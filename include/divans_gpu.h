@@ -251,7 +251,7 @@ int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const
 /* Where the CDF tables' pages lie in device memory moves the decode time by several percent from one allocation to the next
  * (DESIGN.md section 5).  A long-lived codec can ask for the placement to be tuned: the next divans_gpu_lit_decode_batch call whose
  * batch fills at least half the persistent grid runs its launch `candidates` times (1..16; 1 = off, the default; about one placement in six is a fast one, profiles/r04e_table_placement.txt), each time on a freshly allocated
- * copy of the tables -- alternately 2 MiB chunks mapped side by side (what the tables use by default) and one hipMalloc block; which
+ * copy of the tables -- alternately 32 MiB chunks mapped side by side (what tables of 2 GiB and more use by default) and one hipMalloc block; which
  * kind is faster differs from box to box --, the same bytes come out every time; it synchronises and keeps the fastest.  The copies
  * exist side by side while it runs.  Tuned again after the tables had to be re-allocated. */
 int divans_gpu_codec_tune_tables(divans_gpu_codec *c, uint32_t candidates);
