@@ -315,12 +315,13 @@ static uint32_t resident_groups(const divans_gpu_codec* c) {
     return std::max(std::max(c->blocks, use_decode2(c) ? c->blocks2 : 0u) * groups_per_block(c), use_decode_t(c) ? c->blocks_t * 64u : 0u);
 }
 
-// The CDF tables' memory.  How it is mapped changes the decode time by 10-20 % (profiles/r04e_table_placement.txt): one physically
-// contiguous block (hipDeviceMallocContiguous: large translation fragments) is the slowest, hipMalloc lands anywhere between that
-// and 10 % better from one allocation -- and one box -- to the next, 2 MiB chunks created one by one and mapped side by side into a
-// reserved address range (hipMemCreate / hipMemMap) are consistently the fastest.  That is what the tables use.
-// One rule comes with it: an address range is NEVER handed back (hipMemAddressFree).  On ROCm 7.2 a range that is unmapped, freed,
-// reserved again and mapped to new chunks reads and writes through stale translations -- scripts/probes/vmm_remap_probe.hip shows it
+// The CDF tables' memory.  How the driver places and maps it changes the decode time by 10-20 % (profiles/r04e_table_placement.txt): one
+// physically contiguous block (hipDeviceMallocContiguous) is always the slowest (the L2 loses two thirds of its hits), a hipMalloc block lands
+// anywhere in a 10 % band from one allocation -- and one box -- to the next (on some boxes always at the slow end), physical chunks created one
+// by one and mapped side by side into a reserved address range (hipMemCreate / hipMemMap) have the better worst case.  Big tables use the
+// latter (table_alloc), and divans_gpu_codec_tune_tables measures several placements of both kinds and keeps the fastest.
+// One rule comes with the mapping calls: an address range is NEVER handed back (hipMemAddressFree).  On ROCm 7.2 a range that is unmapped,
+// freed, reserved again and mapped to new chunks reads and writes through stale translations -- scripts/probes/vmm_remap_probe.hip shows it
 // with nothing but the runtime API, and the decode kernels returned wrong bytes that way.  So a range a codec is done with stays
 // mapped and waits in a small per-process pool for the next codec that fits; a range the pool gives up is unmapped and its chunks
 // released, but its addresses stay reserved for the life of the process (address space, not memory).
@@ -350,6 +351,18 @@ static void table_pool_drop(int device) {      // device < 0: every device
     for (size_t i = 0; i < g_table_pool.size();) {
         if (device < 0 || g_table_pool[i].device == device) { table_release_chunks(g_table_pool[i]); g_table_pool.erase(g_table_pool.begin() + i); } else ++i;
     }
+}
+
+// hipMalloc for the codec's other big arrays: before it fails for lack of memory, the idle table ranges of the pool are given back
+static hipError_t device_alloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess) table_pool_drop(dev);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
 }
 
 static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, bool shuffle, TableMem& t) {
@@ -432,7 +445,7 @@ static hipError_t table_alloc(int device, size_t need, TableMem& t, bool fresh =
         e = hipExtMallocWithFlags((void**)&t.p, need, hipDeviceMallocContiguous);
         if (e != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; }
     }
-    if (e != hipSuccess) { e = hipMalloc((void**)&t.p, need); if (e != hipSuccess) t.p = nullptr; else { t.chunks.clear(); t.device = device; } }
+    if (e != hipSuccess) { e = device_alloc((void**)&t.p, need); if (e != hipSuccess) t.p = nullptr; else { t.chunks.clear(); t.device = device; } }
     if (e == hipSuccess) t.bytes = need;
     return e;
 }
@@ -464,7 +477,7 @@ static int ensure_sf(divans_gpu_codec* c, uint32_t n_streams) {
     const size_t need = (size_t)n_streams * 2u * c->max_stream_len * sizeof(uint32_t);
     if (need <= c->sf_bytes) return 0;
     if (c->d_sf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_sf)); c->d_sf = nullptr; c->sf_bytes = 0; }
-    if (hipMalloc(&c->d_sf, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(start/freq spill) failed");
+    if (device_alloc((void**)&c->d_sf, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(start/freq spill) failed");
     c->sf_bytes = need;
     return 0;
 }
@@ -587,7 +600,7 @@ static int ensure_bucket(divans_gpu_codec* c, uint32_t n_streams, BucketBatch& b
     const size_t need = sz_sfs + sz_desc + sz_tasks + sz_inv + sz_sorted + 256u;
     if (need > c->bk_bytes) {
         if (c->d_bk) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_bk)); c->d_bk = nullptr; c->bk_bytes = 0; }
-        if (hipMalloc(&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed encoder work arrays) failed");
+        if (device_alloc((void**)&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed encoder work arrays) failed");
         c->bk_bytes = need;
     }
     uint8_t* p = c->d_bk;
@@ -607,7 +620,7 @@ static int ensure_bucket_mix(divans_gpu_codec* c, uint32_t n_streams, MixBucketB
     const size_t need = 256u + 2u * (sz_xs + sz_max) + sz_desc + sz_tasks + sz_inv + sz_sorted;
     if (need > c->bk_bytes) {
         if (c->d_bk) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_bk)); c->d_bk = nullptr; c->bk_bytes = 0; }
-        if (hipMalloc(&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed two-model encoder work arrays) failed");
+        if (device_alloc((void**)&c->d_bk, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(bucketed two-model encoder work arrays) failed");
         c->bk_bytes = need;
     }
     uint8_t* p = c->d_bk;
@@ -634,7 +647,7 @@ static int ensure_rans_scratch(divans_gpu_codec* c, uint32_t n_streams, const Sf
     if (!base) {
         if (need > c->rs_bytes) {
             if (c->d_rs) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_rs)); c->d_rs = nullptr; c->rs_bytes = 0; }
-            if (hipMalloc(&c->d_rs, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(rANS chunk scratch) failed");
+            if (device_alloc((void**)&c->d_rs, need) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(rANS chunk scratch) failed");
             c->rs_bytes = need;
         }
         base = c->d_rs;
@@ -984,7 +997,7 @@ extern "C" int divans_gpu_lit_encode_packed(divans_gpu_codec* c, const uint8_t* 
     while ((uint64_t)sub * slot > ((uint64_t)1 << 36) && sub > 1024u) sub = (sub + 1u) / 2u;      // at most 64 GiB of slots
     if ((size_t)sub * slot > c->slots_bytes) {
         if (c->d_slots) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_slots)); c->d_slots = nullptr; c->slots_bytes = 0; }
-        if (hipMalloc(&c->d_slots, (size_t)sub * slot) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(output slots of a sub-batch) failed");
+        if (device_alloc((void**)&c->d_slots, (size_t)sub * slot) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(output slots of a sub-batch) failed");
         c->slots_bytes = (size_t)sub * slot;
     }
     if (sub > c->slot_off_cap) {
@@ -1344,7 +1357,7 @@ template <typename T>
 static int host_scratch(divans_gpu_codec* c, int which, size_t bytes, T** out) {
     if (bytes > c->host_scratch_cap[which]) {
         if (c->host_scratch[which]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->host_scratch[which])); c->host_scratch[which] = nullptr; c->host_scratch_cap[which] = 0; }
-        if (hipMalloc(&c->host_scratch[which], bytes) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(host-buffer staging) failed");
+        if (device_alloc((void**)&c->host_scratch[which], bytes) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(host-buffer staging) failed");
         c->host_scratch_cap[which] = bytes;
     }
     *out = (T*)c->host_scratch[which];
