@@ -133,6 +133,7 @@ def load_library():
     L.divans_gpu_trim.argtypes = []; L.divans_gpu_trim.restype = None
     L.divans_gpu_codec_set_decoder.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]
     L.divans_gpu_codec_set_decoder.restype = ctypes.c_int
+    L.divans_gpu_experimental_decoders.argtypes = []; L.divans_gpu_experimental_decoders.restype = ctypes.c_int
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
     L.divans_gpu_codec_set_bucket_batch.argtypes = [vp, u32]
     L.divans_gpu_lit_encode_host_pipelined.argtypes = [vp, vp, u32, u32, vp, ctypes.c_size_t, vp, vp, ctypes.POINTER(ctypes.c_size_t), u32]
@@ -185,6 +186,16 @@ def load_library():
     return L
 
 
+def experimental_decoders():
+    """True if the loaded library was built with the decoders that lost their measurements (generations 1-with-caches and 4)."""
+    return bool(load_library().divans_gpu_experimental_decoders())
+
+
+def decoder_generations():
+    """The decoder generations divans_gpu_codec_set_decoder accepts in this build."""
+    return (1, 2, 3, 4) if experimental_decoders() else (2, 3)
+
+
 def exported_symbols():
     """Entry points include/divans_gpu.h declares (used by the CPU-side ABI test)."""
     return [
@@ -192,7 +203,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_encode_packed", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_experimental_decoders", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_status_async", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
@@ -367,8 +378,9 @@ class LiteralCodec:
         _check(self._lib.divans_gpu_codec_set_bucket_batch(self._h, int(streams)), "set_bucket_batch")
 
     def set_decoder(self, generation=2, rows=None, shifts=None, blocks=0):
-        """Decode kernel generation (2 = lit_decode2.hip, 1 = lit_kernels.hip) and, for generation 2, the rows / hash shifts of its
-        four direct-mapped caches (high stride, high context-map, low stride, low context-map rows) and its persistent grid."""
+        """Decode kernel generation (2 / 3 = lit_decode2.hip direct mapped / 2-way; 1 = lit_kernels.hip and 4 = lit_decode_t.hip only in a
+        library built with DIVANS_WITH_EXPERIMENTAL_DECODERS=1) and, for generation 2 / 3, the rows / hash shifts of its
+        four caches (high stride, high context-map, low stride, low context-map rows) and its persistent grid."""
         u32x4 = ctypes.c_uint32 * 4
         r = u32x4(*[int(x) for x in rows]) if rows is not None else None
         sh = u32x4(*[int(x) for x in (shifts if shifts is not None else (5, 5, 5, 5))]) if rows is not None else None

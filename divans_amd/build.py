@@ -12,9 +12,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdivans_hip.so")
-SOURCES = ["lit_kernels.hip", "lit_decode2.hip", "lit_decode_t.hip", "lit_bucket.hip", "lit_bucket_mix.hip", "capi.cpp", "host_stream.cpp",
+SOURCES = ["lit_kernels.hip", "lit_decode2.hip", "lit_bucket.hip", "lit_bucket_mix.hip", "capi.cpp", "host_stream.cpp",
            "ffi.cpp", "ir.cpp", "batch.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# The decoders that lost their measurements (generation 4 = lit_decode_t.hip, generation 1 with unified / split caches; lit_kernels.h)
+# are compiled only on request: DIVANS_WITH_EXPERIMENTAL_DECODERS=1 python divans_amd/build.py --force
+EXPERIMENTAL = os.environ.get("DIVANS_WITH_EXPERIMENTAL_DECODERS", "0") not in ("", "0")
+if EXPERIMENTAL:
+    SOURCES.insert(2, "lit_decode_t.hip")
+    FLAGS.append("-DDIVANS_WITH_EXPERIMENTAL_DECODERS=1")
 
 
 def hipcc():
@@ -79,6 +85,21 @@ def build(force=False, verbose=False):
     with open(flags_tag, "w") as f:
         f.write(flags_now)
     return LIB
+
+
+def check_experimental():
+    """Compile check of the sources only experiment builds link (lit_decode_t.hip): object only, kept under build/."""
+    if EXPERIMENTAL:
+        return
+    os.makedirs(OBJ, exist_ok=True)
+    path = os.path.join(CSRC, "lit_decode_t.hip")
+    obj = os.path.join(OBJ, "lit_decode_t.hip.check.o")
+    if not _stale(obj, [path] + _headers()):
+        return
+    res = subprocess.run([hipcc()] + FLAGS + ["-DDIVANS_WITH_EXPERIMENTAL_DECODERS=1", "-x", "hip", "-c", path, "-o", obj], capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed compiling lit_decode_t.hip (experiment-only source)")
 
 
 if __name__ == "__main__":

@@ -309,7 +309,12 @@ static void set_cache_fields(const divans_gpu_codec* c, LitBatch& b) {
 
 static uint32_t groups_per_block(const divans_gpu_codec*) { return LIT_THREADS / 16; }
 static bool use_decode2(const divans_gpu_codec* c) { return c->decode_gen == 2u && c->blocks2 != 0u && !c->geom.wrap_check; }
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
 static bool use_decode_t(const divans_gpu_codec* c) { return c->decode_gen == 4u && c->blocks_t != 0u && !c->geom.wrap_check; }
+#else
+static bool use_decode_t(const divans_gpu_codec*) { return false; }
+#endif
+extern "C" int divans_gpu_experimental_decoders(void) { return DIVANS_WITH_EXPERIMENTAL_DECODERS; }
 // streams that own a table slab at once
 static uint32_t resident_groups(const divans_gpu_codec* c) {
     return std::max(std::max(c->blocks, use_decode2(c) ? c->blocks2 : 0u) * groups_per_block(c), use_decode_t(c) ? c->blocks_t * 64u : 0u);
@@ -720,6 +725,12 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
     if (by_user) c->user_geometry = true;
     if (generation < 1u || generation > 4u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches), 3 (second generation, 2-way caches) or 4 (one lane per stream)");
     HIP_TRY(hipSetDevice(c->device));
+#if !DIVANS_WITH_EXPERIMENTAL_DECODERS
+    // generations 1 and 4 lost their measurements (lit_kernels.h); this build keeps generation 1 only as the decoder of wrap-checked
+    // speeds and of the call-by-call interface, where the library selects it by itself
+    if (generation == 4u || (generation == 1u && by_user))
+        return fail(DIVANS_GPU_EINVAL, "decoder generations 1 and 4 are experiment builds (DIVANS_WITH_EXPERIMENTAL_DECODERS=1 python divans_amd/build.py --force)");
+#else
     if (generation == 4u) {
         // lit_decode_t.hip: rows[i] slots of the four direct-mapped per-stream caches (0 = one slot, the staging buffer the kernel needs anyway)
         if (c->geom.wrap_check) return fail(DIVANS_GPU_EINVAL, "generation 4 does not run speeds whose row totals leave i16");
@@ -749,6 +760,7 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
         if (by_user) c->dm_auto = false;
         return 0;
     }
+#endif
     const bool two_way = generation == 3u;
     if (by_user) c->dm_auto = false;
     if (generation == 3u) generation = 2u;
@@ -801,7 +813,9 @@ extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t block
         if (!valid_cache_rows(cache_rows)) return fail(DIVANS_GPU_EINVAL, "cache_rows must be 0 or a power of two in [16, 256]");
         if (cache_rows && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
         c->cache_high = cache_rows; c->cache_low = 0; c->cache_unified = cache_rows != 0;
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
         c->decode_gen = 1;   // these are the caches of the first-generation decoder (and of the streaming model kernel)
+#endif                       // (default build: of the streaming model kernel only; the decoder stays generation 2 / 3)
     }
     if (blocks) {
         c->blocks = blocks;
@@ -820,7 +834,10 @@ extern "C" int divans_gpu_codec_set_split_cache(divans_gpu_codec* c, uint32_t hi
     if (high_rows == 0 && low_rows != 0) return fail(DIVANS_GPU_EINVAL, "a low-nibble cache needs a high-nibble cache");
     if ((high_rows || low_rows) && c->geom.total_rows >= 0x7fffu) return fail(DIVANS_GPU_EINVAL, "row cache needs fewer than 32767 rows per stream");
     c->cache_high = high_rows; c->cache_low = low_rows; c->cache_unified = false;
-    c->decode_gen = 1; c->user_geometry = true;
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
+    c->decode_gen = 1;
+#endif
+    c->user_geometry = true;
     return 0;
 }
 
@@ -1103,13 +1120,22 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.stream_bad = c->d_stream_flags;
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
     set_cache_fields(c, b);
+#if !DIVANS_WITH_EXPERIMENTAL_DECODERS
+    if (!use_decode2(c) && (b.cache_mode == 1u || b.cache_mode == 3u)) {     // the generation-1 fallback of this build knows the high-row cache or none
+        b.cache_mode = 2u; b.cache_rows_low = 0u;
+        b.cache_bytes_per_wg = (LIT_THREADS / 16) * b.cache_rows_high * 34u;
+    }
+#endif
     if (d_segs && !use_decode2(c) && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
     const bool transposed = use_decode_t(c) && !d_segs;      // (segment lists: the first generation's kernel)
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
     if (transposed) {
         b.dm_log2 = c->t_log2; b.dm_shift = c->t_shift;
         b.cache_bytes_per_wg = 64u * lit_decode_t_stream_lds(c->t_log2, c->mix);
         c->last_decode_grid = std::min(c->blocks_t, (n_streams + 63u) / 64u);
-    } else if (use_decode2(c)) {
+    } else
+#endif
+    if (use_decode2(c)) {
         b.dm_log2 = lit_decode2_effective_caches(c->dm_log2, c->mix, d_segs != nullptr); b.dm_shift = c->dm_shift;
         // A batch that is resident all at once runs at the latency of a stream's dependency chain, and the direct-mapped lookup is
         // the shorter chain (16 384 streams: 60.3 vs 63.5 ms, mixing 138 vs 142); only a batch that keeps the grid busy for several
@@ -1141,8 +1167,11 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     }
     auto launch = [&]() -> int {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
         if (transposed) { lit_decode_t_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode_t(b, c->mix, c->last_decode_grid, c->stream)); }
-        else if (use_decode2(c)) { lit_decode2_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode2(b, c->mix, c->last_decode_grid, c->stream)); }
+        else
+#endif
+        if (use_decode2(c)) { lit_decode2_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode2(b, c->mix, c->last_decode_grid, c->stream)); }
         else { lit_decode_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode(b, c->mix, c->blocks, c->stream)); }
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
         return 0;

@@ -150,10 +150,20 @@ void lit_decode_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);
 void lit_decode2_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);
 uint32_t lit_decode2_effective_caches(uint32_t dm_log2, bool mix, bool seg);   // the caches of dm_log2 a kernel instance exists for
 uint32_t lit_decode2_stream_lds(uint32_t dm_log2);   // LDS bytes one stream takes in lit_decode2_kernel (word ring + row caches)
+// Decoders that lost their measurement and are NOT part of the default library (build with DIVANS_WITH_EXPERIMENTAL_DECODERS=1 in the
+// environment of divans_amd/build.py to have them): generation 4 = lit_decode_t.hip, one lane per stream, 30-45 % slower everywhere
+// (profiles/r04e_lane_per_stream_decoder.txt), and the instances of generation 1's lit_decode_kernel no product path needs (the unified and
+// split cache organisations; 3-8 % behind generation 3, profiles/r03b_bench_decoder_generations_same_box.txt).  Generation 1 without a
+// cache / with the high-row cache stays: it decodes under speeds whose row totals leave i16 (wrap-checked) and call by call (resumable).
+#ifndef DIVANS_WITH_EXPERIMENTAL_DECODERS
+#define DIVANS_WITH_EXPERIMENTAL_DECODERS 0
+#endif
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
 // lit_decode_t.hip: one lane per stream (decoder generation 4); 64 streams per workgroup
 hipError_t launch_decode_t(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 void lit_decode_t_kernel_name(const LitBatch& b, bool mix, char* buf, size_t cap);
 uint32_t lit_decode_t_stream_lds(uint32_t dm_log2, bool mix);   // LDS bytes one stream takes there
+#endif
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
                        uint64_t* dst_off, uint64_t* total, hipStream_t st, bool accumulate = false, uint64_t cap = ~0ull, uint32_t* status = nullptr);
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);

@@ -851,7 +851,29 @@ typedef void (*LitKernel)(const LitBatch);
         }                                                                                                    \
     }
 LIT_PICK(lit_model_encode_kernel)
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
 LIT_PICK(lit_decode_kernel)
+#else
+// The default library keeps generation 1's decoder only where no later generation runs: without a cache (wrap-checked speeds) and with
+// the high-nibble-row cache (the resumable call-by-call decoder); the unified / split cache instances are experiment builds (lit_kernels.h)
+template <int CACHE, bool SEG>
+static LitKernel pick_lit_decode_kernel(int mm, bool ctxc, bool mix) {
+    const int key = (mm == 4 ? 2 : (mm == 0 ? 1 : 0)) * 4 + (ctxc ? 2 : 0) + (mix ? 1 : 0);
+    switch (key) {
+    case 0: return lit_decode_kernel<-1, false, false, CACHE, SEG>; case 1: return lit_decode_kernel<-1, false, true, CACHE, SEG>;
+    case 2: return lit_decode_kernel<-1, true, false, CACHE, SEG>;  case 3: return lit_decode_kernel<-1, true, true, CACHE, SEG>;
+    case 4: return lit_decode_kernel<0, false, false, CACHE, SEG>;  case 5: return lit_decode_kernel<0, false, true, CACHE, SEG>;
+    case 6: return lit_decode_kernel<0, true, false, CACHE, SEG>;   case 7: return lit_decode_kernel<0, true, true, CACHE, SEG>;
+    case 8: return lit_decode_kernel<4, false, false, CACHE, SEG>;  case 9: return lit_decode_kernel<4, false, true, CACHE, SEG>;
+    case 10: return lit_decode_kernel<4, true, false, CACHE, SEG>;  default: return lit_decode_kernel<4, true, true, CACHE, SEG>;
+    }
+}
+static LitKernel pick_mode_lit_decode_kernel(int cache_mode, bool seg, int mm, bool ctxc, bool mix) {
+    if (seg) return cache_mode == 2 ? pick_lit_decode_kernel<2, true>(mm, ctxc, mix) : pick_lit_decode_kernel<0, true>(mm, ctxc, mix);
+    if (cache_mode == 2) return pick_lit_decode_kernel<2, false>(mm, ctxc, mix);
+    return cache_mode == 0 ? pick_lit_decode_kernel<0, false>(mm, ctxc, mix) : nullptr;
+}
+#endif
 
 // specialisation that will actually run: only 0 and 4 have dedicated MM instances
 static int effective_mm(int mm) { return (mm == 0 || mm == 4) ? mm : -1; }
@@ -897,6 +919,7 @@ hipError_t launch_decode(const LitBatch& b_in, bool mix, uint32_t blocks, hipStr
     const int mm = effective_mm(b.geom.mm_uniform);
     if (b.segs && b.cache_mode != 2u && b.cache_mode != 0u) return hipErrorInvalidValue;
     LitKernel k = pick_mode_lit_decode_kernel((int)b.cache_mode, b.segs != nullptr, mm, b.geom.ctx_const >= 0, mix);
+    if (!k) return hipErrorInvalidValue;     // a cache organisation this build holds no generation-1 decoder for
     const uint32_t lds = lit_lds_bytes(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);

@@ -244,9 +244,15 @@ int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
  * or 2-way (3), coded words through an LDS ring) or 1 (lit_kernels.hip) -- and for generations 2 / 3 the rows of the four per-stream caches
  * {high stride rows, high context-map rows, low stride rows, low context-map rows} (0 = not cached, else a power of two in
  * [4, 256]), their hash shifts (set = (row ^ (row >> shift)) & (rows - 1)) and the persistent grid (0 = keep; clamped to
- * what the LDS holds).  rows / shifts may be NULL to keep the current ones.  Both generations produce the same bytes. */
+ * what the LDS holds).  rows / shifts may be NULL to keep the current ones.  Both generations produce the same bytes.
+ * Generations 1 and 4 (one lane per stream, lit_decode_t.hip) measured 3-8 % and 30-45 % slower than 2 / 3 and are selectable only in
+ * a library built with DIVANS_WITH_EXPERIMENTAL_DECODERS=1 (divans_gpu_experimental_decoders() != 0); the default library answers
+ * DIVANS_GPU_EINVAL.  It still uses generation 1 by itself where no later generation runs (speeds whose row totals leave i16, the
+ * call-by-call stream decoder); there divans_gpu_codec_set_geometry / _set_split_cache only shape the streaming encoder pass. */
 int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4],
                                  uint32_t blocks);
+/* 1 if this library was built with the decoders that lost their measurements (generation 4; generation 1 with unified / split caches) */
+int divans_gpu_experimental_decoders(void);
 
 /* Where the CDF tables' pages lie in device memory moves the decode time by several percent from one allocation to the next
  * (DESIGN.md section 5).  A long-lived codec can ask for the placement to be tuned: the next divans_gpu_lit_decode_batch call whose

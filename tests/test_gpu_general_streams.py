@@ -120,7 +120,7 @@ def test_segment_block_type_outside_the_tables_is_reported(corpus):
     codec.encode_segments_batch(d_lit, d_off, d_sz, 1, longest, d_sb, d_segs, outs)
     assert codec.status() & 4
     back = torch.zeros(4000 + 64, dtype=torch.uint8, device=d_lit.device)
-    for gen in (1, 2, 3):
+    for gen in (g for g in (1, 2, 3) if g in da.decoder_generations()):
         codec.set_decoder(gen)
         codec.decode_segments_batch(outs["out"], outs["offsets"], outs["sizes"], 1, longest, d_sb, d_segs, back, d_off, d_sz)
         assert codec.status() & 4, gen

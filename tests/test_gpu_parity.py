@@ -200,12 +200,13 @@ def test_generic_mixing_mask_and_context_maps(mixing, mode, corpus, random_then_
             got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
             assert got.size == ref.size and (got == ref).all(), (vs, i)
         assert (codec.decode_host(packed, offs, sizes, L) == blocks).all()
-        try:
-            codec.set_decoder(4, (8, 4, 0, 2), (3, 5, 5, 1))      # one lane per stream (lit_decode_t.hip), table-driven instances
-        except da.DivansGpuError as e:
-            assert "32767 rows" in str(e)                         # (its 15-bit cache tags; the value sets with three planes exceed them)
-        else:
-            assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), "generation 4"
+        if da.experimental_decoders():
+            try:
+                codec.set_decoder(4, (8, 4, 0, 2), (3, 5, 5, 1))      # one lane per stream (lit_decode_t.hip), table-driven instances
+            except da.DivansGpuError as e:
+                assert "32767 rows" in str(e)                         # (its 15-bit cache tags; the value sets with three planes exceed them)
+            else:
+                assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), "generation 4"
         codec.close()
 
 
@@ -224,8 +225,9 @@ def test_uniform_mm0_specialisation(corpus):
     for i in range(6):
         assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == po.lit_encode(o, blocks[i])).all()
     assert (codec.decode_host(packed, offs, sizes, 9000) == blocks).all()
-    codec.set_decoder(4)
-    assert (codec.decode_host(packed, offs, sizes, 9000) == blocks).all(), "generation 4"
+    if da.experimental_decoders():
+        codec.set_decoder(4)
+        assert (codec.decode_host(packed, offs, sizes, 9000) == blocks).all(), "generation 4"
     codec.close()
 
 
@@ -355,7 +357,7 @@ def test_speeds_whose_total_stays_above_lim(mixing, encode_path, corpus, random_
             ref = po.lit_encode(o, blocks[i])
             got = packed[int(offs[i]):int(offs[i]) + int(sizes[i])]
             assert got.size == ref.size and (got == ref).all(), (speeds, i)
-        for gen in (1, 3, 4):
+        for gen in (g for g in (1, 3, 4) if g in da.decoder_generations()):
             codec.set_decoder(gen)
             assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), gen
         codec.close()
@@ -734,6 +736,9 @@ def test_lane_per_stream_decoder_geometries(cfg_name, geom, corpus, shuffle384, 
     """ragged streams (a wave's lanes finish at different times, three rounds of a one-workgroup grid with live and idle lanes), lengths
     across the 32 KiB chunk boundary, unaligned output offsets"""
     import torch
+    import divans_amd
+    if not divans_amd.experimental_decoders():
+        pytest.skip("generation 4 is an experiment build: DIVANS_WITH_EXPERIMENTAL_DECODERS=1 python divans_amd/build.py --force")
     rows, shifts = _T_GEOMETRIES[geom]
     L = 40000
     n = 150
@@ -814,17 +819,33 @@ def test_table_placement_tuning_changes_no_byte(cfg_name, corpus):
     codec2.close()
 
 
+def test_default_build_does_not_offer_the_decoders_that_lost():
+    """generation 4 (one lane per stream, 30-45 % slower) and a user-selected generation 1 exist only in a library built
+    with DIVANS_WITH_EXPERIMENTAL_DECODERS=1; the default one answers EINVAL and keeps decoding with what it had"""
+    da, codec = _codec("simple", 256)
+    if da.experimental_decoders():
+        pytest.skip("experiment build")
+    for gen in (1, 4):
+        with pytest.raises(da.DivansGpuError, match="experiment builds"):
+            codec.set_decoder(gen)
+    blocks = np.arange(8 * 256, dtype=np.uint32).astype(np.uint8).reshape(8, 256)
+    packed, offs, sizes = codec.encode_host(blocks, 256)
+    assert (codec.decode_host(packed, offs, sizes, 256) == blocks).all()
+    assert "lit_decode2_kernel" in codec.last_decode_kernel()
+    codec.close()
+
+
 @pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
 def test_both_decoder_generations_agree(cfg_name, corpus):
     blocks = workload.make_blocks(corpus, 40, 300, block_len=3000)
     da, codec = _codec(cfg_name, 3000)
     packed, offs, sizes = codec.encode_host(blocks, 3000)
-    for gen in (1, 2, 3, 4):
+    for gen in da.decoder_generations():
         codec.set_decoder(gen)
         assert (codec.decode_host(packed, offs, sizes, 3000) == blocks).all(), gen
     # a damaged stream fails the integrity check of either generation
     bad = packed.copy(); bad[int(offs[7]) + 40] ^= 0x10
-    for gen in (1, 2, 3, 4):
+    for gen in da.decoder_generations():
         codec.set_decoder(gen)
         with pytest.raises(da.DivansGpuError):
             codec.decode_host(bad, offs, sizes, 3000)
@@ -880,7 +901,7 @@ def test_decoder_survives_thousands_of_damaged_streams(cfg_name, corpus):
     flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
     assert codec._lib.divans_gpu_codec_set_stream_flags(codec._h, ctypes.c_void_p(flags.data_ptr())) == 0
     results = []
-    for gen in (1, 2, 3, 4):
+    for gen in da.decoder_generations():
         codec.set_decoder(gen)
         flags.zero_()
         d_back = torch.full((n, L), 0xEE, dtype=torch.uint8, device="cuda")
