@@ -263,7 +263,7 @@ def verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, n_check)
     return ok and bad == 0, len(picks)
 
 
-def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note="", traffic_name=None):
+def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note="", traffic_name=None, byte_order=0):
     """encode+decode config (simple or mixing): verify, time, report."""
     cfg = da.config_simple() if name == "simple" else da.config_context_mixing()
     ocfg = po.config_simple() if name == "simple" else po.config_context_mixing()
@@ -282,17 +282,19 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     if args.split_cache:
         hi_rows, lo_rows = (int(x) for x in args.split_cache.split(","))
         codec.set_split_cache(hi_rows, lo_rows)
-    if args.table_candidates > 1:
-        codec.tune_tables(args.table_candidates)      # acts on the first decode below (verification or warm-up), never inside the timed region
+    if byte_order:
+        codec.set_byte_order(byte_order)
+    if args.table_candidates:
+        codec.tune_tables(args.table_candidates)      # 0 = what a plain divans_gpu_codec_create caller gets (the library's policy); acts on the first
+                                                      # decode below (verification or warm-up), never inside the timed region
     outs = alloc_packed_outputs(torch, N, L, dev)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
     ok, checked = True, 0
     if not args.no_verify:
         ok, checked = verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, args.check_streams)
         first_sizes = outs["sizes"].clone(); d_back.zero_()
-    steps = args.steps if name == "simple" else max(1, min(args.steps, 2))
-    warm = args.warmup if name == "simple" else min(args.warmup, 1)
-    if args.no_verify and args.table_candidates > 1:
+    steps, warm = args.steps, args.warmup
+    if args.no_verify and args.table_candidates != 1:
         warm = max(warm, 1)          # the decode that tries the table placements is never a timed one
     elapsed, rec = timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, warm, barrier)
     if not args.no_verify:   # the timed passes must have produced the same thing
@@ -315,6 +317,7 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
         # HBM the codec holds besides the caller's buffers: the encoder's work arrays (+ the decoder's CDF tables)
         "encoder_work_bytes_per_input_byte": round(codec.info().scratch_bytes / raw, 2),
         "table_bytes": int(codec.info().table_bytes),
+        "table_placement": codec.table_placement(),
     }
     return res, codec, outs
 
@@ -347,7 +350,7 @@ def run_decode_only(torch, da, po, args, dev, copies=4096):
     d_out_sz = torch.tensor([b.size for b in blocks], dtype=torch.int32, device=dev).repeat(copies).contiguous()
     d_out = torch.zeros(copies * data.size, dtype=torch.uint8, device=dev)
     codec = da.LiteralCodec(da.config_context_mixing(), L, device=dev.index)
-    if args.table_candidates > 1:
+    if args.table_candidates:
         codec.tune_tables(args.table_candidates)
     orig = torch.from_numpy(data).to(dev)
 
@@ -368,12 +371,13 @@ def run_decode_only(torch, da, po, args, dev, copies=4096):
     dk = codec.last_decode_kernel() or "lit_decode_kernel"
     kern = {dk: sum(kms) / len(kms)}
     res = {
-        "workload": f"testdata/random_then_unicode ({data.size} B) as {nb} independent streams (4 x 65536 + {blocks[-1].size} B), coded once by the "
+        "workload": f"BASELINE configs[3]: testdata/random_then_unicode ({data.size} B) as {nb} independent streams (4 x 65536 + {blocks[-1].size} B), coded once by the "
                     f"oracle under TestContextMixing options, x{copies} copies = {N} streams resident in HBM, decode only, every copy compared",
         "bit_exact": ok, "streams": N, "steps": steps, "ms_per_step": round(sum(ms) / len(ms), 3),
         "value": round(raw / 1e6 / (sum(ms) / len(ms) / 1e3), 2), "unit": "MB/s decode",
         "compressed_ratio": round(ctot / raw, 4), "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
         "roofline": roofline_of(kern, {dk: raw + ctot}, load_traffic("decode_only", N, L)),
+        "table_placement": codec.table_placement(),
     }
     codec.close()
     return res
@@ -394,8 +398,9 @@ def main():
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
     ap.add_argument("--decoder-generation", type=int, default=0, help="decode kernel: 1 = lit_kernels.hip, 2 / 3 = lit_decode2.hip direct-mapped / 2-way caches (tuning; 0 = the codec's default)")
-    ap.add_argument("--table-candidates", type=int, default=12, help="placements of the CDF tables the first (untimed) decode of a codec tries before it keeps "
-                    "the fastest (divans_gpu_codec_tune_tables; 1 = take the first allocation as it comes)")
+    ap.add_argument("--table-candidates", type=int, default=0, help="placements of the CDF tables the first (untimed) decode of a codec tries before it keeps "
+                    "the fastest: 0 = the library's own policy, i.e. what every divans_gpu_codec_create caller gets (tables of 2 GiB and more: up to 12, "
+                    "stopping at the first fast one); 1 = take the first allocation as it comes; k = exactly k (divans_gpu_codec_tune_tables)")
     ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
     ap.add_argument("--bucket-batch", type=int, default=0, help="streams per launch sequence of the two-model bucketed pass (tuning; default 32768)")
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
@@ -506,10 +511,10 @@ def main():
     shard_text = (f"{total_streams} independent {L} B streams in total, split into contiguous ranges over the GPUs ({N} on this rank)" if strong
                   else f"{N} independent {L} B streams per GPU")
 
-    def pair_record(name, d_in=d_in, traffic_name=None):
+    def pair_record(name, d_in=d_in, traffic_name=None, byte_order=0):
         """One encode+decode configuration on every rank: verify, time (max over ranks), at world > 1 gather the coded streams
         to rank 0 and check them there.  Returns (record for rank 0, bit-exact on all ranks)."""
-        res, codec, outs = run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, traffic_name=traffic_name)
+        res, codec, outs = run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, traffic_name=traffic_name, byte_order=byte_order)
         elapsed = sharding.max_over_ranks(res["elapsed"], dev)
         coded_all, ok_count = sharding.sum_over_ranks([res["coded_total"], int(res["ok"])], dev)
         ok_all = ok_count == world
@@ -535,7 +540,8 @@ def main():
             step_s = elapsed / K
             m = dict(mg)
             m.update({"gather_ms": round(gather_s * 1e3, 3), "gathered_bytes": int(coded_all), "gather_checked_on_rank0": bool(g_ok == world),
-                      "rccl_world_size": world, "transport": "gloo, all ranks on one GPU (DIVANS_BENCH_SHARE_GPU: path verification only)" if share_gpu else "rccl",
+                      "rccl_world_size": world, "transport": ("gloo, all ranks on one GPU (DIVANS_BENCH_SHARE_GPU: path verification only; the RCCL branch of this file has never executed on hardware -- "
+                                    "every lease of rounds 1-5 was one GPU)") if share_gpu else "rccl",
                       "scatter_gather_inclusive_MBps": round(total_streams * L / 1e6 / (step_s + mg["scatter_ms"] / 1e3 + gather_s), 2)})
             t = torch.zeros((3, world), dtype=torch.float64, device="cpu" if share_gpu else dev)
             t[0, rank] = res["elapsed"] / K * 1e3; t[1, rank] = res["roofline"]["frac"]; t[2, rank] = res["roofline"]["achieved"]
@@ -553,7 +559,8 @@ def main():
         rec = {"value": round(total_bytes / 1e6 / (elapsed / K), 2), "steps": K, "ms_per_step": round(elapsed * 1e3 / K, 3),
                "bit_exact": bool(ok_all), "checked_vs_oracle": res["checked_vs_oracle"], "compressed_ratio": round(coded_all / float(total_bytes), 4),
                "encode_MBps": res["encode_MBps"], "decode_MBps": res["decode_MBps"], "kernel_ms": res["kernel_ms"], "roofline": res["roofline"],
-               "encoder_work_bytes_per_input_byte": res["encoder_work_bytes_per_input_byte"], "table_bytes": res["table_bytes"]}
+               "encoder_work_bytes_per_input_byte": res["encoder_work_bytes_per_input_byte"], "table_bytes": res["table_bytes"],
+               "table_placement": res["table_placement"]}
         if m:
             rec["multi_gpu"] = m
         return rec, ok_all
@@ -563,23 +570,28 @@ def main():
     if head_name:
         rec, ok_all = pair_record(head_name)
         if rank == 0:
-            cfg_text = ("TestSimple: stride 1, context map off (BASELINE configs[1])" if head_name == "simple"
-                        else "TestContextMixing: context map + dynamic_context_mixing=2 (BASELINE configs[2])")
+            cfg_tag = "BASELINE configs[1]" if head_name == "simple" else "BASELINE configs[2]"
+            if strong:
+                cfg_tag = "BASELINE configs[4] share, options of " + cfg_tag
+            cfg_text = ("TestSimple: stride 1, context map off" if head_name == "simple"
+                        else "TestContextMixing: context map + dynamic_context_mixing=2")
             line = {
                 "metric": "MB/s encode+decode per GPU, 64 KiB metablocks; bit-exact vs CPU",
                 "value": rec["value"], "unit": "MB/s", "n_gpus": world, "steps": rec["steps"], "warmup": args.warmup,
                 "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                 "dtype": "u16/u64 integer", "data": "synthetic",
-                "config": {"workload": f"{shard_text} cut from alice29||asyoulik (stride 4099, 1% xorshift64* perturbation); {cfg_text}",
+                "config": {"workload": f"{cfg_tag}: {cfg_text}; {shard_text} cut from alice29||asyoulik (stride 4099, 1% xorshift64* perturbation)",
                            "streams_per_gpu": N, "total_streams": total_streams, "block_bytes": L,
                            "sharding": "contiguous stream ranges per rank; no collective inside the timed region"},
-                "bit_exact": rec["bit_exact"], "bit_exact_against": f"in-repo C oracle (restatement of the reference CPU path, pinned on the reference tree's own compressed vector wasm/wasm.html:98-107, tests/test_reference_vectors.py): "
-                                                                f"coded bytes of {rec['checked_vs_oracle']} streams per rank + exact round trip of all",
+                "bit_exact": rec["bit_exact"], "bit_exact_against": "in-repo C oracle (restatement of the reference CPU path; its framing, CRC, CMD and LIT coders are pinned on the one compressed "
+                                     "vector the reference tree holds, wasm/wasm.html:98-107, under that older build's wire variant; context maps, mixing, the "
+                                     "65 536-symbol chunk seam and HEAD's two PredictionMode prior rows have NO reference-built bytes behind them -- "
+                                     f"tests/golden/make_reference_vectors.rs needs cargo): coded bytes of {rec['checked_vs_oracle']} streams per rank + exact round trip of all",
                 "compressed_ratio": rec["compressed_ratio"],
                 "encode_MBps": rec["encode_MBps"], "decode_MBps": rec["decode_MBps"],
                 "kernel_ms": rec["kernel_ms"], "roofline": rec["roofline"],
                 "encoder_work_bytes_per_input_byte": rec["encoder_work_bytes_per_input_byte"], "table_bytes": rec["table_bytes"],
-                "table_placement_candidates": max(1, args.table_candidates),
+                "table_placement": rec["table_placement"],
             }
             if "multi_gpu" in rec:
                 line["multi_gpu"] = rec["multi_gpu"]
@@ -594,23 +606,23 @@ def main():
             # configs[2] on the same streams; at world > 1 this is configs[4]'s second option set, with its own scatter/gather record
             r2, ok2 = pair_record("mixing")
             r2 = dict(r2)
-            r2.update({"workload": "same streams, TestContextMixing: context map cm[i]=i&63, utf8, block type 1, dynamic_context_mixing=2 (BASELINE configs[2])",
+            r2.update({"workload": "BASELINE configs[2]: same streams, TestContextMixing: context map cm[i]=i&63, utf8, block type 1, dynamic_context_mixing=2 (BASELINE configs[2])",
                        "unit": "MB/s encode+decode"})
             sub["mixing"] = r2
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 sub["mixing"]["cpu_baseline"] = cpu_baseline("mixing", workload, corpus, L)
         if world == 1 and args.config == "all" and args.diag_data == "corpus":
             # configs[1]'s options on input that is not English text: the same cut (stride 4099, 1 % perturbation) out of testdata/
-            # random_then_unicode (random bytes, then UTF-8 in several scripts).  The stride-1 decoder lays its tables out by a text-frequency
-            # rank of the previous byte (BytePerm, lit_decode2.hip), which buys nothing here: this record shows what the headline owes to it.
+            # random_then_unicode (random bytes, then UTF-8 in several scripts), decoded with the tables in numeric byte order
+            # (divans_gpu_codec_set_byte_order: the text-frequency rank that is the default buys nothing on such input).
             import lzma
             with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
                 rtu_t = torch.from_numpy(np.frombuffer(f.read(), dtype=np.uint8).copy()).to(dev)
             d_bin = device_blocks(torch, rtu_t, first, N, L)
-            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary")
+            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", byte_order=1)
             rb = dict(rb)
-            rb.update({"workload": f"{N} x {L} B streams cut from testdata/random_then_unicode (stride 4099, 1% perturbation: random bytes and multi-script "
-                                   "UTF-8), TestSimple options as the headline", "unit": "MB/s encode+decode"})
+            rb.update({"workload": f"BASELINE configs[1] options on non-text input: {N} x {L} B streams cut from testdata/random_then_unicode (stride 4099, 1% perturbation: random bytes and multi-script "
+                                   "UTF-8), TestSimple options as the headline, decoder tables in numeric byte order (divans_gpu_codec_set_byte_order 1)", "unit": "MB/s encode+decode"})
             sub["simple_binary"] = rb
             del d_bin
             torch.cuda.empty_cache()

@@ -80,6 +80,22 @@ class BatchTiming(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_double), ("gpu_ms", ctypes.c_double), ("host_overlapped_ms", ctypes.c_double), ("host_serial_ms", ctypes.c_double)]
 
 
+class TablePlacement(ctypes.Structure):
+    _fields_ = [("policy_candidates", ctypes.c_uint32), ("tried", ctypes.c_uint32), ("first_ms", ctypes.c_float), ("best_ms", ctypes.c_float),
+                ("worst_ms", ctypes.c_float), ("kept_chunks", ctypes.c_uint32)]
+
+
+class TableMemoryInfo(ctypes.Structure):
+    _fields_ = [("va_reserved_bytes", ctypes.c_uint64), ("va_cap_bytes", ctypes.c_uint64), ("idle_bytes", ctypes.c_uint64), ("idle_ranges", ctypes.c_uint32)]
+
+
+def table_memory():
+    """divans_gpu_table_memory: address space reserved for tables and never returned, its cap, idle mapped ranges"""
+    t = TableMemoryInfo()
+    _check(load_library().divans_gpu_table_memory(ctypes.byref(t)), "table_memory")
+    return {"va_reserved_bytes": t.va_reserved_bytes, "va_cap_bytes": t.va_cap_bytes, "idle_bytes": t.idle_bytes, "idle_ranges": t.idle_ranges}
+
+
 class GpuInfo(ctypes.Structure):
     _fields_ = [
         ("rows_per_stream", ctypes.c_uint32), ("resident_groups", ctypes.c_uint32),
@@ -131,8 +147,12 @@ def load_library():
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_tune_tables.argtypes = [vp, u32]
     L.divans_gpu_trim.argtypes = []; L.divans_gpu_trim.restype = None
+    L.divans_gpu_codec_table_placement.argtypes = [vp, ctypes.POINTER(TablePlacement)]
+    L.divans_gpu_table_memory.argtypes = [ctypes.POINTER(TableMemoryInfo)]
+    L.divans_gpu_set_table_va_cap.argtypes = [u64]; L.divans_gpu_set_table_va_cap.restype = None
     L.divans_gpu_codec_set_decoder.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]
     L.divans_gpu_codec_set_decoder.restype = ctypes.c_int
+    L.divans_gpu_codec_set_byte_order.argtypes = [vp, u32]
     L.divans_gpu_experimental_decoders.argtypes = []; L.divans_gpu_experimental_decoders.restype = ctypes.c_int
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
     L.divans_gpu_codec_set_bucket_batch.argtypes = [vp, u32]
@@ -203,7 +223,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_encode_packed", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_experimental_decoders", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_codec_table_placement", "divans_gpu_table_memory", "divans_gpu_set_table_va_cap", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_experimental_decoders", "divans_gpu_codec_set_byte_order", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_status_async", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
@@ -215,7 +235,7 @@ def exported_symbols():
 
 def exported_batch_symbols():
     """Entry points include/divans_batch.h declares."""
-    return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress", "divans_batch_release",
+    return ["divans_batch_options_default", "divans_batch_compress_bound", "divans_batch_compress", "divans_batch_decompress", "divans_batch_release", "divans_batch_release_device",
             "divans_probe_container", "divans_batch_last_phases"]
 
 
@@ -386,10 +406,21 @@ class LiteralCodec:
         sh = u32x4(*[int(x) for x in (shifts if shifts is not None else (5, 5, 5, 5))]) if rows is not None else None
         _check(self._lib.divans_gpu_codec_set_decoder(self._h, int(generation), r, sh, int(blocks)), "set_decoder")
 
+    def set_byte_order(self, order):
+        """0 = the stride-1 tables lay the previous byte's rows out by a text-frequency rank (default), 1 = numerically (non-text input)"""
+        _check(self._lib.divans_gpu_codec_set_byte_order(self._h, int(order)), "set_byte_order")
+
     def tune_tables(self, candidates=3):
-        """The next decode_batch call that fills the persistent grid runs `candidates` times on differently placed copies of the CDF
-        tables and keeps the fastest placement (divans_gpu_codec_tune_tables)."""
+        """The next decode_batch call that fills the persistent grid runs on up to `candidates` differently placed copies of the CDF
+        tables and keeps the fastest placement (divans_gpu_codec_tune_tables; 0 = the library's policy, 1 = off)."""
         _check(self._lib.divans_gpu_codec_tune_tables(self._h, int(candidates)), "tune_tables")
+
+    def table_placement(self):
+        """what the placement tuning saw: dict(policy_candidates, tried, first_ms, best_ms, worst_ms, kept_chunks)"""
+        t = TablePlacement()
+        _check(self._lib.divans_gpu_codec_table_placement(self._h, ctypes.byref(t)), "table_placement")
+        return {"policy_candidates": t.policy_candidates, "tried": t.tried, "first_ms": round(t.first_ms, 3), "best_ms": round(t.best_ms, 3),
+                "worst_ms": round(t.worst_ms, 3), "kept": "chunks" if t.kept_chunks else "one block"}
 
     def set_split_cache(self, high_rows, low_rows):
         _check(self._lib.divans_gpu_codec_set_split_cache(self._h, int(high_rows), int(low_rows)), "set_split_cache")

@@ -79,10 +79,12 @@ public:
     }
     int workers() const { return (int)threads_.size(); }
     // body(i) for i in [0, n) on at most `width` threads (the caller is one of them); returns when all are done
+    // Calls on different devices share the pool (it is the process's cores, not a device's): their sections take turns.
     void run(size_t n, int width, const std::function<void(size_t)>& body) {
         if (n == 0) return;
         const int helpers = (int)std::min<size_t>((size_t)std::max(0, std::min(width, workers() + 1) - 1), n - 1);
         if (helpers == 0) { for (size_t i = 0; i < n; ++i) body(i); return; }
+        std::lock_guard<std::mutex> turn(run_mu_);
         std::unique_lock<std::mutex> l(mu_);
         body_ = &body; n_ = n; next_.store(0); wanted_ = helpers; active_ = 0; epoch_ += 1;
         l.unlock();
@@ -110,6 +112,7 @@ private:
         }
     }
     std::vector<std::thread> threads_;
+    std::mutex run_mu_;        // one parallel section at a time
     std::mutex mu_; std::condition_variable cv_, done_cv_;
     const std::function<void(size_t)>* body_ = nullptr; size_t n_ = 0; std::atomic<size_t> next_{0};
     int wanted_ = 0, active_ = 0; unsigned long epoch_ = 0; bool stop_ = false;
@@ -274,26 +277,47 @@ struct Lane {
 };
 
 // The lanes live from call to call (streams, codecs with their tables and scratch, page-locked staging buffers are expensive to
-// create): one pool per process, handed to one call at a time; divans_batch_release() returns everything.
+// create): ONE POOL PER DEVICE, each handed to one call at a time.  Calls on different devices run concurrently -- the reference's
+// states are independent of each other (src/ffi/interface.rs:49-50, src/parallel_decompressor.rs:55-141), and so are a process's
+// GPUs: eight host threads drive eight devices through this interface without waiting for each other's device work (they share
+// the host thread pool).  Nothing is torn down when a call names another device; divans_batch_release_device / divans_batch_release
+// return a device's / every device's lanes.
 struct LanePool {
-    std::mutex mu;
+    std::mutex mu;                       // held for the whole of a call on this device
     int device = -1;
     std::unique_ptr<Lane[]> lanes;
-    int acquire(int dev, Lane** out) {
-        if (!lanes || device != dev) {
-            lanes.reset();
+    int acquire(Lane** out) {
+        if (!lanes) {
             std::unique_ptr<Lane[]> fresh(new Lane[kLanes]);
             for (int i = 0; i < kLanes; ++i) { const int rc = fresh[i].init(); if (rc) return rc; }
-            lanes = std::move(fresh); device = dev;
+            lanes = std::move(fresh);
         }
         *out = lanes.get();
         return 0;
     }
 };
-LanePool& pool() { static LanePool p; return p; }
+struct PoolRegistry {
+    std::mutex mu;                       // guards the map only; never held while a pool's own mutex is waited for by a call
+    std::map<int, std::unique_ptr<LanePool>> by_device;
+    LanePool& of(int device) {
+        std::lock_guard<std::mutex> l(mu);
+        std::unique_ptr<LanePool>& p = by_device[device];
+        if (!p) { p.reset(new LanePool); p->device = device; }
+        return *p;                       // pools are never erased: the reference stays valid for the life of the process
+    }
+    void release(int device) {           // device < 0: all
+        std::vector<LanePool*> pools;
+        { std::lock_guard<std::mutex> l(mu); for (auto& kv : by_device) if (device < 0 || kv.first == device) pools.push_back(kv.second.get()); }
+        for (LanePool* p : pools) {
+            std::lock_guard<std::mutex> l(p->mu);       // waits for a call that is running on that device
+            if (p->lanes) { (void)hipSetDevice(p->device); p->lanes.reset(); }
+        }
+    }
+};
+PoolRegistry& registry() { static PoolRegistry r; return r; }
 
-// Where the host's time went in the last call (divans_batch_last_phases): a diagnostic, overwritten by every call
-double g_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Where the calling thread's time went in its last call (divans_batch_last_phases): a diagnostic, per thread, overwritten by every call
+thread_local double g_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 enum { PH_PARSE_OR_PLAN = 0, PH_STAGE = 1, PH_WAIT = 2, PH_FINISH = 3, PH_GATHER = 4 };
 
 // wall-clock bookkeeping of the overlap: host work counts as overlapped while at least one slice is in flight on the GPU
@@ -345,9 +369,10 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bound_of[a] < bound_of[b]; });
     std::vector<Slice> slices;
     make_slices(order, bound_of, sizes, device_budget(), slices);
-    std::lock_guard<std::mutex> pool_lock(pool().mu);
+    LanePool& lane_pool = registry().of(opt->device);
+    std::lock_guard<std::mutex> pool_lock(lane_pool.mu);
     Lane* lanes = nullptr;
-    rc = pool().acquire(opt->device, &lanes); if (rc) return rc;
+    rc = lane_pool.acquire(&lanes); if (rc) return rc;
     struct Drain { Lane* l; ~Drain() { for (int i = 0; i < kLanes; ++i) if (l[i].stream) (void)hipStreamSynchronize(l[i].stream); } } drain{lanes};   // no early return with copies in flight
     Overlap ov;
 
@@ -491,9 +516,10 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     if (n_streams == 0) return 0;
     const double t_begin = now_ms();
     HIP_OR_FAIL(hipSetDevice(opt->device));
-    std::lock_guard<std::mutex> pool_lock(pool().mu);
+    LanePool& lane_pool = registry().of(opt->device);
+    std::lock_guard<std::mutex> pool_lock(lane_pool.mu);
     Lane* lanes = nullptr;
-    int rc = pool().acquire(opt->device, &lanes); if (rc) return rc;
+    int rc = lane_pool.acquire(&lanes); if (rc) return rc;
     struct Drain { Lane* l; ~Drain() { for (int i = 0; i < kLanes; ++i) if (l[i].stream) (void)hipStreamSynchronize(l[i].stream); } } drain{lanes};   // no early return with copies in flight
     Overlap ov;
     for (double& v : g_phases) v = 0;
@@ -673,16 +699,14 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     return 0;
 }
 
-// Frees what the batch calls keep between calls (HIP streams, codecs, device scratch, page-locked staging buffers).
-void divans_batch_release(void) {
-    std::lock_guard<std::mutex> pool_lock(pool().mu);
-    pool().lanes.reset();
-    pool().device = -1;
-}
+// Frees what the batch calls keep between calls (HIP streams, codecs, device scratch, page-locked staging buffers): of every device /
+// of one.  Waits for a call that is running on a device it releases.
+void divans_batch_release(void) { registry().release(-1); }
+void divans_batch_release_device(int device) { if (device >= 0) registry().release(device); }
 
 // Where the calling thread's time went in the last batch call (milliseconds): [0] CMD coders -- plans (compress) / container parsing
 // (decompress), [1] staging into page-locked memory + enqueueing, [2] waiting for the GPU, [3] container assembly (compress) / copy-out
-// (decompress), [4] final gather of the containers (compress).  A diagnostic: overwritten by every call, not thread-safe across calls.
+// (decompress), [4] final gather of the containers (compress).  A diagnostic: per calling thread, overwritten by that thread's next call.
 void divans_batch_last_phases(double* out, int n) {
     for (int i = 0; i < n && i < 8; ++i) out[i] = g_phases[i];
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +29,21 @@ static int fail(int code, const std::string& msg) { g_last_error = msg; return c
 
 extern "C" const char* divans_gpu_last_error(void) { return g_last_error.c_str(); }
 namespace divans_host { int set_last_error(int code, const std::string& msg) { return fail(code, msg); } }
+
+// Measurement switches read from the environment exist only in experiment builds (-DDIVANS_EXPERIMENT_SWITCHES=1, scripts/build_variants.sh):
+// a shipped library's behaviour does not depend on variables a caller's process happens to carry.
+#ifndef DIVANS_EXPERIMENT_SWITCHES
+#define DIVANS_EXPERIMENT_SWITCHES 0
+#endif
+static const char* exp_env(const char* name) {
+#if DIVANS_EXPERIMENT_SWITCHES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 
 // ---- configuration helpers -------------------------------------------------------------------
 static const divans_speed kSpeedMud = {0x10, 0x2000};  // probability/interface.rs:323 / codec/interface.rs:188-190
@@ -123,7 +139,9 @@ struct divans_gpu_codec {
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     TableMem tm;                          // what d_tables points into (table_alloc)
-    uint32_t table_candidates = 1; bool tables_tuned = false;   // divans_gpu_codec_tune_tables
+    uint32_t byte_order = 0;       // divans_gpu_codec_set_byte_order
+    uint32_t table_candidates = 0; bool tables_tuned = false;   // divans_gpu_codec_tune_tables: 0 = the library's policy (table_candidates_of)
+    divans_gpu_table_placement placement = {0u, 0u, 0.f, 0.f, 0.f, 0u};   // what the tuning saw (divans_gpu_codec_table_placement)
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
     uint32_t* d_status = nullptr;
     // bucketed encoder model pass (lit_bucket.hip)
@@ -280,7 +298,7 @@ static int derive_geometry(const divans_lit_config& cfg, uint32_t bt_first, uint
     g.cm_base = high_rows + low_rows;
     const bool mix = cfg.context_mixing > 1;  // Weights::should_mix, weights.rs:44-46
     g.total_rows = g.cm_base + (mix ? 17u * g.nctx : 0u);
-    if (const char* e = getenv("DIVANS_SLAB_ROWS_MOD")) {      // experiment: pad a stream's slab to r rows mod m ("m:r")
+    if (const char* e = exp_env("DIVANS_SLAB_ROWS_MOD")) {      // experiment builds only: pad a stream's slab to r rows mod m ("m:r")
         unsigned m = 0, r = 0;
         if (sscanf(e, "%u:%u", &m, &r) == 2 && m > 1 && r < m) while (g.total_rows % m != r) ++g.total_rows;
     }
@@ -330,10 +348,16 @@ static uint32_t resident_groups(const divans_gpu_codec* c) {
 // with nothing but the runtime API, and the decode kernels returned wrong bytes that way.  So a range a codec is done with stays
 // mapped and waits in a small per-process pool for the next codec that fits; a range the pool gives up is unmapped and its chunks
 // released, but its addresses stay reserved for the life of the process (address space, not memory).
-// DIVANS_TABLES_ALLOC = "hipmalloc" / "contiguous" / "scattered:<chunk MiB>[:noshuffle]" are measurement switches.
+// DIVANS_TABLES_ALLOC = "hipmalloc" / "contiguous" / "scattered:<chunk MiB>[:noshuffle]" are measurement switches of experiment builds (exp_env).
+//
+// Address space is accounted for (g_va_reserved): past kTableVaCap of reserved-and-never-returned ranges new tables are plain hipMalloc blocks,
+// which hipFree does give back, so a process that cycles big codecs for days ends on the allocator's ordinary behaviour instead of running the
+// device's address space down (divans_gpu_table_memory reports both numbers; the defect's description for the vendor: scripts/probes/README.md).
 static std::mutex g_table_pool_mu;
 static std::vector<TableMem> g_table_pool;            // mapped ranges no codec uses, oldest first
 constexpr size_t kTablePoolRanges = 2;
+static std::atomic<uint64_t> g_va_reserved{0};        // bytes of address ranges reserved for tables and never handed back (the rule above)
+static std::atomic<uint64_t> g_va_cap{(uint64_t)256 << 30};   // kTableVaCap: 256 GiB = 64 four-GiB tables' worth; divans_gpu_set_table_va_cap
 
 static void table_release_chunks(TableMem& t) {        // unmap and give the memory back; the address range stays reserved (see above)
     for (size_t i = 0; i < t.chunks.size(); ++i) (void)hipMemUnmap((uint8_t*)t.p + i * t.chunk_bytes, t.chunk_bytes);
@@ -342,9 +366,10 @@ static void table_release_chunks(TableMem& t) {        // unmap and give the mem
     t.p = nullptr; t.bytes = 0;
 }
 
-static void table_free(TableMem& t) {
+static void table_free(TableMem& t, bool keep_mapped = true) {
     if (!t.p) return;
     if (t.chunks.empty()) { (void)hipFree(t.p); t.p = nullptr; t.bytes = 0; return; }
+    if (!keep_mapped) { table_release_chunks(t); t = TableMem(); return; }      // (the tuning loop: memory back now, nothing kept for a later codec)
     std::lock_guard<std::mutex> lock(g_table_pool_mu);
     g_table_pool.push_back(std::move(t));
     t = TableMem();
@@ -380,9 +405,11 @@ static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, 
     size_t chunk = std::max<size_t>(gran, chunk_mib << 20);
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t n = (need + chunk - 1) / chunk;
+    if (g_va_reserved.load() + n * chunk > g_va_cap.load()) return hipErrorOutOfMemory;     // the caller falls back to one hipMalloc block
     void* va = nullptr;
     e = hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0);
     if (e != hipSuccess) return e;
+    g_va_reserved += n * chunk;      // from here on the range is never returned, whether the mapping below succeeds or not
     std::vector<hipMemGenericAllocationHandle_t> hs;
     for (size_t i = 0; i < n && e == hipSuccess; ++i) {
         hipMemGenericAllocationHandle_t h;
@@ -419,7 +446,7 @@ static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, 
 // fresh = never from the pool (divans_gpu_codec_tune_tables compares placements: it must not be handed the range it just put aside)
 // plain = one hipMalloc block whatever the mode (the tuning tries both kinds: which is faster differs from box to box)
 static hipError_t table_alloc(int device, size_t need, TableMem& t, bool fresh = false, bool plain = false) {
-    const char* mode = getenv("DIVANS_TABLES_ALLOC");
+    const char* mode = exp_env("DIVANS_TABLES_ALLOC");      // experiment builds only (see exp_env)
     hipError_t e = hipErrorUnknown;
     // Every mapped chunk is a buffer object of its own, and a process that holds thousands of them pays for it in every other runtime call:
     // with 2 MiB chunks under the tables of the eight lanes of divans_batch_* the many-containers ABI fell from 8.0 / 8.0 to 6.7 / 4.9 GB/s
@@ -473,7 +500,7 @@ static int ensure_tables(divans_gpu_codec* c) {
     if (c->d_tables) { HIP_TRY(hipStreamSynchronize(c->stream)); free_tables(c); }
     if (table_alloc(c->device, need, c->tm) != hipSuccess) return fail(DIVANS_GPU_ENOMEM, "hipMalloc(CDF tables) failed");
     c->d_tables = c->tm.p;
-    if (getenv("DIVANS_DEBUG_ALLOC")) fprintf(stderr, "[divans] tables %p + %zu in %zu chunks\n", (void*)c->d_tables, need, c->tm.chunks.size());
+    if (exp_env("DIVANS_DEBUG_ALLOC")) fprintf(stderr, "[divans] tables %p + %zu in %zu chunks\n", (void*)c->d_tables, need, c->tm.chunks.size());
     c->tables_bytes = need;
     return 0;
 }
@@ -796,13 +823,46 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
 
 extern "C" void divans_gpu_trim(void) { table_pool_drop(-1); }
 
+extern "C" int divans_gpu_codec_set_byte_order(divans_gpu_codec* c, uint32_t order) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (order > 1u) return fail(DIVANS_GPU_EINVAL, "byte order must be 0 (text-frequency rank) or 1 (numeric)");
+    c->byte_order = order;
+    return 0;
+}
+
 extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t candidates) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    if (candidates == 0u || candidates > 16u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [1, 16]");
+    if (candidates > 16u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [0, 16] (0 = the library's policy, 1 = off)");
     c->table_candidates = candidates;
     c->tables_tuned = false;
     return 0;
 }
+
+// The one placement policy: tables of 2 GiB and more -- the persistent grids of whole-GPU batches, where a slow placement
+// costs 10-20 % of every later decode -- are tried on up to kDefaultTableCandidates placements by the first decode that fills half the grid;
+// smaller tables (the lanes of divans_batch_*, tests) are not tuned.  bench.py measures what this gives a plain divans_gpu_codec_create caller.
+constexpr uint32_t kDefaultTableCandidates = 12u;
+static uint32_t table_candidates_of(const divans_gpu_codec* c) {
+    if (c->table_candidates) return c->table_candidates;
+    return c->tm.bytes >= ((size_t)2 << 30) ? kDefaultTableCandidates : 1u;
+}
+
+extern "C" int divans_gpu_codec_table_placement(divans_gpu_codec* c, divans_gpu_table_placement* out) {
+    if (!c || !out) return fail(DIVANS_GPU_EINVAL, "null argument");
+    *out = c->placement;
+    out->policy_candidates = table_candidates_of(c);
+    return 0;
+}
+
+extern "C" int divans_gpu_table_memory(divans_gpu_table_memory_info* out) {
+    if (!out) return fail(DIVANS_GPU_EINVAL, "null argument");
+    out->va_reserved_bytes = g_va_reserved.load(); out->va_cap_bytes = g_va_cap.load();
+    std::lock_guard<std::mutex> lock(g_table_pool_mu);
+    out->idle_ranges = (uint32_t)g_table_pool.size(); out->idle_bytes = 0;
+    for (const TableMem& m : g_table_pool) out->idle_bytes += m.va_bytes;
+    return 0;
+}
+extern "C" void divans_gpu_set_table_va_cap(uint64_t bytes) { g_va_cap.store(bytes); }
 
 static bool valid_cache_rows(uint32_t r) { return r == 0 || (r >= 16 && r <= 256 && (r & (r - 1)) == 0); }
 
@@ -1077,7 +1137,7 @@ extern "C" int divans_gpu_lit_model_batch(divans_gpu_codec* c, const uint8_t* d_
     });
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    c->rans_pairs = 0;
+    c->rans_pairs = 0; c->enc_spans = 0; c->last_pack_ms = 0.f;      // (not the spans of an earlier divans_gpu_lit_encode_packed call)
     c->timing_pending_enc = true;
     return 0;
 }
@@ -1119,6 +1179,7 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes; b.status = c->d_status;
     b.stream_bad = c->d_stream_flags;
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
+    b.byte_order = c->byte_order;
     set_cache_fields(c, b);
 #if !DIVANS_WITH_EXPERIMENTAL_DECODERS
     if (!use_decode2(c) && (b.cache_mode == 1u || b.cache_mode == 3u)) {     // the generation-1 fallback of this build knows the high-row cache or none
@@ -1127,7 +1188,9 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     }
 #endif
     if (d_segs && !use_decode2(c) && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
+#if DIVANS_WITH_EXPERIMENTAL_DECODERS
     const bool transposed = use_decode_t(c) && !d_segs;      // (segment lists: the first generation's kernel)
+#endif
 #if DIVANS_WITH_EXPERIMENTAL_DECODERS
     if (transposed) {
         b.dm_log2 = c->t_log2; b.dm_shift = c->t_shift;
@@ -1177,14 +1240,19 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         return 0;
     };
     rc = launch(); if (rc) return rc;
-    // divans_gpu_codec_tune_tables: the first batch that fills at least half the grid is decoded once per candidate placement of the tables (the same
-    // bytes come out every time) and the fastest placement stays
-    if (c->table_candidates > 1u && !c->tables_tuned && 2u * (uint64_t)n_streams >= resident_groups(c)) {
+    // divans_gpu_codec_tune_tables / the library's policy: the first batch that fills at least half the grid is decoded once per candidate placement
+    // of the tables (the same bytes come out every time) and the fastest placement stays.  Two copies of the tables are alive at most -- the best so
+    // far and the candidate under test; a rejected one gives its memory back before the next is allocated -- and the loop stops early once it holds
+    // a placement of the fast population (>= 5 % ahead of the slowest seen; the two populations lie ~9 % apart, profiles/r04e_table_placement.txt).
+    // This path synchronises the stream (the call is otherwise asynchronous); it runs once per codec.
+    const uint32_t want = table_candidates_of(c);
+    if (want > 1u && !c->tables_tuned && 2u * (uint64_t)n_streams >= resident_groups(c)) {
         float best = 0.f;
         HIP_TRY(hipEventSynchronize(c->ev[4]));
         HIP_TRY(hipEventElapsedTime(&best, c->ev[3], c->ev[4]));
-        std::vector<TableMem> aside;
-        for (uint32_t k = 1; k < c->table_candidates; ++k) {
+        float worst = best;
+        c->placement.first_ms = best; c->placement.tried = 1u;
+        for (uint32_t k = 1; k < want && !(c->table_candidates == 0u && best <= 0.95f * worst); ++k) {
             TableMem cand;
             if (table_alloc(c->device, c->tm.bytes, cand, true, (k & 1u) != 0u) != hipSuccess) { (void)hipGetLastError(); break; }     // no room for a second copy: keep what we have
             std::swap(c->tm, cand);
@@ -1192,14 +1260,15 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
             rc = launch();
             float t = 0.f;
             if (!rc && (hipEventSynchronize(c->ev[4]) != hipSuccess || hipEventElapsedTime(&t, c->ev[3], c->ev[4]) != hipSuccess)) rc = fail(DIVANS_GPU_EHIP, "timing a candidate table placement failed");
-            if (getenv("DIVANS_DEBUG_ALLOC")) fprintf(stderr, "[divans] table placement %u (%s): %.2f ms (best so far %.2f)\n", k, c->tm.chunks.empty() ? "one block" : "chunks", t, best);
+            if (exp_env("DIVANS_DEBUG_ALLOC")) fprintf(stderr, "[divans] table placement %u (%s): %.2f ms (best so far %.2f)\n", k, c->tm.chunks.empty() ? "one block" : "chunks", t, best);
             if (rc || t >= best) { std::swap(c->tm, cand); c->d_tables = c->tm.p; b.tables = c->d_tables; }    // the earlier one stays
             else best = t;
-            aside.push_back(std::move(cand));
+            if (!rc) { worst = std::max(worst, t); ++c->placement.tried; }
+            table_free(cand, false);      // the loser's memory goes back now (its address range stays reserved: the remap defect)
             if (rc) break;
         }
-        for (auto& m : aside) table_free(m);
         if (rc) return rc;
+        c->placement.best_ms = best; c->placement.worst_ms = worst; c->placement.kept_chunks = c->tm.chunks.empty() ? 0u : 1u;
         c->last_decode_ms = best; c->timing_pending_dec = false;
         c->tables_tuned = true;
         return 0;       // (the events hold the last candidate's time; last_decode_ms the kept one's)

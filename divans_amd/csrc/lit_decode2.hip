@@ -435,8 +435,8 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
     constexpr bool PERM = DIVANS_D2_PERM && MM == 4;
     const uint32_t perm_off = lds_base + (uint32_t)(lv.mix - lv.base);   // behind the configuration tables (lit_lds_bytes2; MM >= 0: no mixing mask there)
-    if (PERM) {
-        if (threadIdx.x < 64u) lds_write32(perm_off + 4u * threadIdx.x, ((const uint32_t*)kBytePerm.rank)[threadIdx.x]);
+    if (PERM) {     // LitBatch::byte_order: BytePerm's text-frequency ranks, or the bytes themselves
+        if (threadIdx.x < 64u) lds_write32(perm_off + 4u * threadIdx.x, b.byte_order ? 0x03020100u + 0x04040404u * threadIdx.x : ((const uint32_t*)kBytePerm.rank)[threadIdx.x]);
         __syncthreads();
     }
     const uint32_t stream_base = lds_base + (threadIdx.x >> 4) * (b.cache_bytes_per_wg / (LIT_THREADS / 16));

@@ -73,6 +73,9 @@ struct LitBatch {
     // else carries over); `consumed` (optional, [n_streams]) receives the coded words a stream read, and with it set the words
     // offered may outnumber the words read (the caller passes what has arrived so far)
     uint32_t* consumed;
+    // lit_decode2.hip, stride-1 instances: the order in which a table lays out the rows of the 256 previous-byte values -- 0 = by a
+    // text-frequency rank (BytePerm, lit_device.h), 1 = numeric.  A private layout of the launch: any order decodes the same bytes.
+    uint32_t byte_order;
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
 constexpr uint32_t LIT_STATUS_BAD_SEGMENT = 4u;   // a segment names a literal block type outside the codec's context tables

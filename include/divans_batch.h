@@ -69,13 +69,17 @@ int divans_batch_decompress(const divans_batch_options *opt, const uint8_t *cons
                             uint8_t *out, size_t out_cap, size_t *out_offsets, size_t *out_sizes, divans_batch_timing *timing);
 
 /* The batch calls keep their eight lanes (HIP streams, codecs with their tables and scratch, page-locked staging buffers) alive
- * between calls -- creating them costs more than coding a few thousand streams -- and run one call at a time per process.
- * This returns everything; the next call builds the lanes again. */
+ * between calls -- creating them costs more than coding a few thousand streams.  There is one set of lanes PER DEVICE: calls that
+ * name different devices (divans_batch_options::device) run concurrently from different host threads -- one process drives all of a
+ * node's GPUs this way, like independent states of the reference (src/ffi/interface.rs:49-50) -- and calls on one device take turns.
+ * Naming another device tears nothing down.  divans_batch_release returns every device's lanes, divans_batch_release_device one
+ * device's (both wait for a call that is running there); the next call builds them again. */
 void divans_batch_release(void);
+void divans_batch_release_device(int device);
 
 /* Diagnostic: where the calling thread's time went in the last batch call, milliseconds: out[0] CMD coders (plans / container
  * parsing), [1] staging into page-locked memory + enqueueing, [2] waiting for the GPU, [3] container assembly / copy-out,
- * [4] final gather of the containers (compress only).  Overwritten by every call. */
+ * [4] final gather of the containers (compress only).  Per calling thread; overwritten by that thread's next call. */
 void divans_batch_last_phases(double *out, int n);
 
 /* Why does (or does not) this library take a container?  Host only, no GPU work: header, Mux framing, end marker, CRC-32C

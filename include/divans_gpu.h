@@ -251,18 +251,42 @@ int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
  * call-by-call stream decoder); there divans_gpu_codec_set_geometry / _set_split_cache only shape the streaming encoder pass. */
 int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4],
                                  uint32_t blocks);
+/* Stride-1 configurations (every mixing value 4): the order in which the decoder's private tables lay out the rows of the 256 previous-byte
+ * values, i.e. which rows share a 128-byte line.  0 (default) = a text-frequency rank: lower-case letters by English frequency, separators,
+ * capitals, digits, then everything else numerically -- on text an L2 line then holds rows that are hot together (-4 % decode time,
+ * profiles/r03c_byte_rank_layout_same_box.txt); 1 = numeric order, for input that is not text.  Bytes >= 0x80 are in numeric order either way.
+ * The decoded bytes do not depend on it. */
+int divans_gpu_codec_set_byte_order(divans_gpu_codec *c, uint32_t order);
 /* 1 if this library was built with the decoders that lost their measurements (generation 4; generation 1 with unified / split caches) */
 int divans_gpu_experimental_decoders(void);
 
-/* Where the CDF tables' pages lie in device memory moves the decode time by several percent from one allocation to the next
- * (DESIGN.md section 5).  A long-lived codec can ask for the placement to be tuned: the next divans_gpu_lit_decode_batch call whose
- * batch fills at least half the persistent grid runs its launch `candidates` times (1..16; 1 = off, the default; about one placement in six is a fast one, profiles/r04e_table_placement.txt), each time on a freshly allocated
- * copy of the tables -- alternately 32 MiB chunks mapped side by side (what tables of 2 GiB and more use by default) and one hipMalloc block; which
- * kind is faster differs from box to box --, the same bytes come out every time; it synchronises and keeps the fastest.  The copies
- * exist side by side while it runs.  Tuned again after the tables had to be re-allocated. */
+/* Where the CDF tables' pages lie in device memory moves the decode time by 10-20 % from one allocation to the next (DESIGN.md section 5;
+ * about one placement in six is a fast one, profiles/r04e_table_placement.txt), so the library measures: the first divans_gpu_lit_decode_batch
+ * call whose batch fills at least half the persistent grid runs its launch on several placements of the tables -- alternately 32 MiB chunks
+ * mapped side by side and one hipMalloc block; which kind is faster differs from box to box -- and keeps the fastest; the same bytes come out
+ * every time.  `candidates`: 0 = the library's policy, the default: tables of 2 GiB and more (whole-GPU batches) up to 12 placements,
+ * stopping as soon as one is >= 5 % ahead of the slowest seen; smaller tables are not tuned.  1 = off.  2..16 = exactly that many.
+ * THAT CALL SYNCHRONISES THE STREAM (every other decode call is asynchronous) and takes (placements tried) x (one decode + one allocation of
+ * the tables): seconds, once per codec and again after the tables had to grow.  Memory while it runs: two copies of the tables (the best so
+ * far and the candidate; a rejected copy is released before the next is allocated).  Address space: every chunk-mapped candidate reserves a
+ * range that is never returned (the ROCm remap defect, scripts/probes/README.md) -- see divans_gpu_table_memory. */
 int divans_gpu_codec_tune_tables(divans_gpu_codec *c, uint32_t candidates);
-/* A destroyed codec's tables stay mapped (at most two ranges per process) for the next codec that fits -- their address ranges are never
- * handed back to the driver, see DESIGN.md section 5.  This gives the MEMORY of the idle ranges back now. */
+typedef struct divans_gpu_table_placement {
+    uint32_t policy_candidates;    /* what the next tuning would try at most (the library's policy or divans_gpu_codec_tune_tables) */
+    uint32_t tried;                /* placements the last tuning decoded on (0 = not tuned yet / not tuned at all) */
+    float first_ms, best_ms, worst_ms;   /* decode kernel time on the first placement, on the one kept, on the slowest seen */
+    uint32_t kept_chunks;          /* 1 = the kept tables are chunks mapped into a reserved range, 0 = one hipMalloc block */
+} divans_gpu_table_placement;
+int divans_gpu_codec_table_placement(divans_gpu_codec *c, divans_gpu_table_placement *out);
+/* Memory the library keeps beyond its codecs.  A destroyed codec's chunk-mapped tables (2 GiB and more) stay MAPPED -- at most two ranges
+ * per process -- for the next codec that fits: idle_ranges / idle_bytes; divans_gpu_trim() gives that memory back now, and every other
+ * device allocation of the library does so before it would fail.  Their ADDRESS RANGES are never handed back to the driver (on ROCm 7.2 a
+ * range that is unmapped and mapped again reads and writes through stale translations, scripts/probes/README.md): va_reserved_bytes counts
+ * them, and past va_cap_bytes (default 256 GiB, divans_gpu_set_table_va_cap) new tables are plain hipMalloc blocks, which hipFree returns
+ * in full.  A process that creates and destroys big codecs for days therefore ends on the allocator's ordinary behaviour. */
+typedef struct divans_gpu_table_memory_info { uint64_t va_reserved_bytes, va_cap_bytes, idle_bytes; uint32_t idle_ranges; } divans_gpu_table_memory_info;
+int divans_gpu_table_memory(divans_gpu_table_memory_info *out);
+void divans_gpu_set_table_va_cap(uint64_t bytes);
 void divans_gpu_trim(void);
 
 /* separate caches for the rows of the high-nibble and of the low-nibble table (0 = that table goes to HBM/L2 directly) */

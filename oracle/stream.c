@@ -735,7 +735,7 @@ size_t orc_stream_compress_raw(const orc_stream_options *o, const uint8_t *in, s
     r.ring = (size_t)1 << w; r.in = in;
     size_t ncalls = o->call_inputs ? o->n_call_inputs : 1;
     r.cmds = (orc_stream_command *)calloc(2 * (n / (r.ring - 1) + 2) + 2 * ncalls + 8, sizeof(orc_stream_command));
-    static uint8_t cmap[64], dmap[4], mixing[ORC_NUM_MIXING_VALUES];
+    uint8_t cmap[64], dmap[4], mixing[ORC_NUM_MIXING_VALUES];      /* (locals: the function is called from concurrent test threads) */
     for (int i = 0; i < 64; ++i) cmap[i] = (uint8_t)(i & 0x3f);
     for (int i = 0; i < 4; ++i) dmap[i] = (uint8_t)(i & 3);
     memset(mixing, 4, sizeof(mixing));

@@ -2,7 +2,11 @@
 // divans_amd/csrc/batch.cpp: length classes, slices on lanes, persistent thread pool, plans / parsing under the "GPU work", container
 // assembly) with the oracle standing in for the literal kernels, under AddressSanitizer + UBSan or ThreadSanitizer.
 //
-//   hostsim_batch <file> <seed> <rounds> [largest batch, default 700]
+//   hostsim_batch <file> <seed> <rounds> [largest batch, default 700] [devices, default 1]
+//
+// devices = 2: the rounds run on two threads at once, one per stand-in device (fakehip knows two): the per-device lane pools of batch.cpp
+//  -- concurrent calls on different devices, divans_batch_release / _release_device from one thread while the other is
+// inside a call -- under ThreadSanitizer.
 //
 // Per round: a batch of streams of mixed lengths (empty, tiny, around the 64 KiB class bound, now and then several hundred KB; every
 // fourth round incompressible ones) under
@@ -15,7 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/divans_batch.h"
@@ -23,7 +29,8 @@ extern "C" {
 #include "../../oracle/divans_oracle.h"
 }
 
-static uint64_t rng_state;
+static thread_local uint64_t rng_state;
+static thread_local int t_device = 0;
 static uint64_t rnd() { rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27; return rng_state * 2685821237909765ull; }
 static size_t rnd_below(size_t n) { return n ? (size_t)(rnd() % n) : 0; }
 typedef std::vector<uint8_t> Bytes;
@@ -40,6 +47,7 @@ static divans_batch_options random_options() {
     for (auto& sp : o.literal_adaptation) sp = palette[rnd_below(6)];
     o.call_buffer_size = (rnd() & 1) ? 65536u : (uint32_t)(1 + rnd_below(70000));
     o.host_threads = (int)rnd_below(9);          // 0 = all the process is granted
+    o.device = t_device;
     return o;
 }
 
@@ -76,21 +84,13 @@ static Batch random_batch(const Bytes& data, size_t max_streams, size_t from = 0
     return b;
 }
 
-#define FAIL(...) do { std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, " (%s)\n", divans_gpu_last_error()); return 1; } while (0)
+#define FAIL(...) do { std::fprintf(stderr, "device %d: ", t_device); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, " (%s)\n", divans_gpu_last_error()); return 1; } while (0)
 
-int main(int argc, char** argv) {
-    if (argc < 4) { std::fprintf(stderr, "usage: hostsim_batch <file> <seed> <rounds>\n"); return 2; }
-    FILE* f = std::fopen(argv[1], "rb");
-    if (!f) return 2;
-    Bytes data; { uint8_t tmp[65536]; size_t n; while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) data.insert(data.end(), tmp, tmp + n); }
-    std::fclose(f);
-    if (data.size() < 200000) { std::fprintf(stderr, "the input file should hold at least 200 000 bytes\n"); return 2; }
-    rng_state = std::strtoull(argv[2], nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
-    const size_t noise_from = data.size();                      // incompressible tail: packed streams larger than the staging guess (5/8 of the input)
-    for (size_t i = 0; i < 300000; ++i) data.push_back((uint8_t)rnd());
-    const long rounds = std::strtol(argv[3], nullptr, 0);
-    const size_t largest = argc > 4 ? (size_t)std::strtoul(argv[4], nullptr, 0) : 700;
-    size_t n_containers = 0, bytes_in = 0;
+static std::atomic<size_t> n_containers{0}, bytes_in{0};
+
+// the rounds of one device (its own thread when there are two)
+static int run_rounds(const Bytes& data, size_t noise_from, uint64_t seed, long rounds, size_t largest, int device) {
+    rng_state = seed; t_device = device;
     for (long round = 0; round < rounds; ++round) {
         const divans_batch_options oa = random_options(), ob = random_options();
         const Batch a = random_batch(data, round % 4 == 0 ? largest : std::min<size_t>(60, largest), round % 4 == 2 ? noise_from : 0), b = random_batch(data, 20);
@@ -123,14 +123,14 @@ int main(int argc, char** argv) {
             }
             n_containers += x.len.size(); for (size_t l : x.len) bytes_in += l;
         }
-        if (round % 3 == 1) divans_batch_release();
+        if (round % 3 == 1) { if ((round / 3) & 1) divans_batch_release_device(device); else divans_batch_release(); }    // (the other thread may be inside a call)
         // both batches interleaved through one decompress call
         std::vector<size_t> order;                               // index into `containers`
         { size_t ia = 0, ib = 0; while (ia < a.len.size() || ib < b.len.size()) { if (ib < b.len.size() && (ia >= a.len.size() || (rnd() & 3) == 0)) order.push_back(a.len.size() + ib++); else order.push_back(ia++); } }
         std::vector<const uint8_t*> cp; std::vector<size_t> cl; size_t total = 0;
         auto original = [&](size_t k, const uint8_t*& p, size_t& l) { if (k < a.len.size()) { p = a.ptr[k]; l = a.len[k]; } else { p = b.ptr[k - a.len.size()]; l = b.len[k - a.len.size()]; } };
         for (size_t k : order) { cp.push_back(containers[k].data()); cl.push_back(containers[k].size()); const uint8_t* p; size_t l; original(k, p, l); total += l; }
-        divans_batch_options od; divans_batch_options_default(&od); od.host_threads = (int)rnd_below(9);
+        divans_batch_options od; divans_batch_options_default(&od); od.host_threads = (int)rnd_below(9); od.device = device;
         Bytes back(total + 1); std::vector<size_t> off(order.size()), sz(order.size());
         if (divans_batch_decompress(&od, cp.data(), cl.data(), order.size(), back.data(), back.size(), off.data(), sz.data(), nullptr) != 0)
             FAIL("round %ld: divans_batch_decompress failed", round);
@@ -161,7 +161,34 @@ int main(int argc, char** argv) {
             }
         }
     }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) { std::fprintf(stderr, "usage: hostsim_batch <file> <seed> <rounds> [largest] [devices]\n"); return 2; }
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    Bytes data; { uint8_t tmp[65536]; size_t n; while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) data.insert(data.end(), tmp, tmp + n); }
+    std::fclose(f);
+    if (data.size() < 200000) { std::fprintf(stderr, "the input file should hold at least 200 000 bytes\n"); return 2; }
+    const uint64_t seed = std::strtoull(argv[2], nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
+    rng_state = seed;
+    const size_t noise_from = data.size();                      // incompressible tail: packed streams larger than the staging guess (5/8 of the input)
+    for (size_t i = 0; i < 300000; ++i) data.push_back((uint8_t)rnd());
+    const long rounds = std::strtol(argv[3], nullptr, 0);
+    const size_t largest = argc > 4 ? (size_t)std::strtoul(argv[4], nullptr, 0) : 700;
+    const int devices = argc > 5 ? std::atoi(argv[5]) : 1;
+    int rc = 0;
+    if (devices <= 1) rc = run_rounds(data, noise_from, seed ^ 0x5bd1e995u, rounds, largest, 0);
+    else {
+        std::atomic<int> failed{0};
+        std::vector<std::thread> ts;
+        for (int d = 0; d < 2; ++d) ts.emplace_back([&, d]() { if (run_rounds(data, noise_from, seed ^ (0x5bd1e995u * (uint64_t)(d + 1)), rounds, largest, d)) failed = 1; });
+        for (auto& t : ts) t.join();
+        rc = failed.load();
+    }
     divans_batch_release();
-    std::printf("%ld rounds: %zu containers, %zu bytes, all equal to the oracle's and back\n", rounds, n_containers, bytes_in);
+    if (rc) return rc;
+    std::printf("%ld rounds on %d device(s): %zu containers, %zu bytes, all equal to the oracle's and back\n", rounds, devices > 1 ? 2 : 1, n_containers.load(), bytes_in.load());
     return 0;
 }

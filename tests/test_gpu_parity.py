@@ -819,6 +819,27 @@ def test_table_placement_tuning_changes_no_byte(cfg_name, corpus):
     codec2.close()
 
 
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_byte_order_of_the_tables_changes_no_byte(cfg_name, corpus, random_then_unicode):
+    """divans_gpu_codec_set_byte_order: the order in which the stride-1 decoder lays out a table's rows (text-frequency rank or numeric) is
+    private to a launch -- the same bytes come back either way, for text and for bytes the rank knows nothing about"""
+    L = 5000
+    blocks = np.stack([corpus[100:100 + L], random_then_unicode[:L], random_then_unicode[250000:250000 + L],
+                       np.random.default_rng(5).integers(0, 256, L, dtype=np.uint8)] * 12)
+    da, codec = _codec(cfg_name, L)
+    codec.set_decoder(3, (8, 8, 0, 0), (5, 5, 5, 5), blocks=1)       # tiny caches: most rows go to the table in memory
+    packed, offs, sizes = codec.encode_host(blocks, L)
+    ocfg = _oracle_cfg(cfg_name)
+    for i in range(4):
+        assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == po.lit_encode(ocfg, blocks[i])).all()
+    for order in (1, 0, 1):
+        codec.set_byte_order(order)
+        assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), order
+    with pytest.raises(da.DivansGpuError):
+        codec.set_byte_order(2)
+    codec.close()
+
+
 def test_default_build_does_not_offer_the_decoders_that_lost():
     """generation 4 (one lane per stream, 30-45 % slower) and a user-selected generation 1 exist only in a library built
     with DIVANS_WITH_EXPERIMENTAL_DECODERS=1; the default one answers EINVAL and keeps decoding with what it had"""

@@ -339,16 +339,19 @@ def test_option_stage_and_state_helpers(lib, corpus):
     assert lib.divans_decode(None, None, 0, None, None, 0, None) == 3
 
 
-@pytest.mark.parametrize("sanitizer,rounds,largest", [("address,undefined", 3, 250), ("thread", 2, 16)])
-def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, tmp_path, corpus):
+@pytest.mark.parametrize("sanitizer,rounds,largest,devices", [("address,undefined", 3, 250, 1), ("thread", 2, 16, 1), ("thread", 3, 16, 2), ("address,undefined", 2, 40, 2)])
+def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, devices, tmp_path, corpus):
     """include/divans_batch.h without a GPU: divans_amd/csrc/batch.cpp itself (length classes, slices on lanes, persistent thread pool,
     plans and parsing under the "GPU work", container assembly, error paths), compiled by g++ against a stand-in for the 16 HIP runtime
     calls it makes (tests/c/fakehip) and the oracle-backed device stub.  tests/c/hostsim_batch.cpp: batches of mixed lengths and options,
     containers == the oracle's, two configurations interleaved through one decompress call, short buffers, a damaged container that
-    has to be named -- under AddressSanitizer + UBSan, and again under ThreadSanitizer."""
+    has to be named -- under AddressSanitizer + UBSan, and again under ThreadSanitizer.  devices = 2: two host threads, each on its own
+    stand-in device, at once -- batch.cpp keeps one set of lanes per device (one process drives all of a node's GPUs; the reference's states
+    are independent, src/ffi/interface.rs:49-50), a call on one device does not wait for the other's, and divans_batch_release /
+    _release_device from one thread wait for the other thread's running call."""
     exe = hostsim.build_batch_test(sanitizer)
     src = tmp_path / "in.bin"
     corpus.tofile(src)
-    r = _run([exe, str(src), "9", str(rounds), str(largest)], timeout=1500, env=SAN_ENV)
+    r = _run([exe, str(src), "9", str(rounds), str(largest), str(devices)], timeout=1500, env=SAN_ENV)
     assert r.returncode == 0 and "all equal to the oracle's and back" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
