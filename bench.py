@@ -399,8 +399,7 @@ def main():
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
     ap.add_argument("--decoder-generation", type=int, default=0, help="decode kernel: 1 = lit_kernels.hip, 2 / 3 = lit_decode2.hip direct-mapped / 2-way caches (tuning; 0 = the codec's default)")
     ap.add_argument("--table-candidates", type=int, default=0, help="placements of the CDF tables the first (untimed) decode of a codec tries before it keeps "
-                    "the fastest: 0 = the library's own policy, i.e. what every divans_gpu_codec_create caller gets (tables of 2 GiB and more: up to 12, "
-                    "stopping at the first fast one); 1 = take the first allocation as it comes; k = exactly k (divans_gpu_codec_tune_tables)")
+                    "the fastest: 0 = the library's own policy, i.e. what every divans_gpu_codec_create caller gets (tables of 2 GiB and more: 12); 1 = take the first allocation as it comes; k = exactly k (divans_gpu_codec_tune_tables)")
     ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
     ap.add_argument("--bucket-batch", type=int, default=0, help="streams per launch sequence of the two-model bucketed pass (tuning; default 32768)")
     ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")

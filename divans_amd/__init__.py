@@ -153,6 +153,7 @@ def load_library():
     L.divans_gpu_codec_set_decoder.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]
     L.divans_gpu_codec_set_decoder.restype = ctypes.c_int
     L.divans_gpu_codec_set_byte_order.argtypes = [vp, u32]
+    L.divans_gpu_codec_set_rans_split.argtypes = [vp, u32]
     L.divans_gpu_experimental_decoders.argtypes = []; L.divans_gpu_experimental_decoders.restype = ctypes.c_int
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
     L.divans_gpu_codec_set_bucket_batch.argtypes = [vp, u32]
@@ -223,7 +224,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_encode_packed", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_codec_table_placement", "divans_gpu_table_memory", "divans_gpu_set_table_va_cap", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_experimental_decoders", "divans_gpu_codec_set_byte_order", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_codec_table_placement", "divans_gpu_table_memory", "divans_gpu_set_table_va_cap", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_experimental_decoders", "divans_gpu_codec_set_byte_order", "divans_gpu_codec_set_rans_split", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_status_async", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
@@ -405,6 +406,10 @@ class LiteralCodec:
         r = u32x4(*[int(x) for x in rows]) if rows is not None else None
         sh = u32x4(*[int(x) for x in (shifts if shifts is not None else (5, 5, 5, 5))]) if rows is not None else None
         _check(self._lib.divans_gpu_codec_set_decoder(self._h, int(generation), r, sh, int(blocks)), "set_decoder")
+
+    def set_rans_split(self, mode):
+        """rANS pass: 0 automatic, 1 one lane per 65 536-symbol chunk, 2 two lanes per chunk (one per rANS state)"""
+        _check(self._lib.divans_gpu_codec_set_rans_split(self._h, int(mode)), "set_rans_split")
 
     def set_byte_order(self, order):
         """0 = the stride-1 tables lay the previous byte's rows out by a text-frequency rank (default), 1 = numerically (non-text input)"""

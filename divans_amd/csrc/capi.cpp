@@ -140,6 +140,7 @@ struct divans_gpu_codec {
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     TableMem tm;                          // what d_tables points into (table_alloc)
     uint32_t byte_order = 0;       // divans_gpu_codec_set_byte_order
+    uint32_t rans_split = 0;       // divans_gpu_codec_set_rans_split
     uint32_t table_candidates = 0; bool tables_tuned = false;   // divans_gpu_codec_tune_tables: 0 = the library's policy (table_candidates_of)
     divans_gpu_table_placement placement = {0u, 0u, 0.f, 0.f, 0.f, 0u};   // what the tuning saw (divans_gpu_codec_table_placement)
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
@@ -823,6 +824,13 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
 
 extern "C" void divans_gpu_trim(void) { table_pool_drop(-1); }
 
+extern "C" int divans_gpu_codec_set_rans_split(divans_gpu_codec* c, uint32_t mode) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (mode > 2u) return fail(DIVANS_GPU_EINVAL, "rANS split must be 0 (automatic), 1 (one lane per chunk) or 2 (two lanes per chunk)");
+    c->rans_split = mode;
+    return 0;
+}
+
 extern "C" int divans_gpu_codec_set_byte_order(divans_gpu_codec* c, uint32_t order) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (order > 1u) return fail(DIVANS_GPU_EINVAL, "byte order must be 0 (text-frequency rank) or 1 (numeric)");
@@ -1011,6 +1019,9 @@ static int rans_pass(divans_gpu_codec* c, const SfView& v, uint32_t count, uint3
     r.status = c->d_status; r.chunk_bytes = d_chunk_bytes; r.max_chunks = max_chunks;
     r.scratch = nullptr; r.scratch_stride = 0; r.chunk0_sizes = nullptr;
     if (chunk_lanes) { int rr = ensure_rans_scratch(c, count, v, r); if (rr) return rr; }
+    // two lanes per chunk (one per rANS state) when whole-chunk lanes would leave SIMDs without a wave: 4 lanes per stream on at most
+    // one wave per SIMD (rans_encode2_split_kernel; c->rans_split: 0 automatic, 1 never, 2 always -- a test / measurement knob)
+    r.split_states = (c->rans_split == 2u || (c->rans_split == 0u && (uint64_t)count * 4u <= (uint64_t)c->num_cus * 4u * 64u)) ? 1u : 0u;
     hipEvent_t* pair = nullptr;
     int rr = rans_event_pair(c, pairs, pair); if (rr) return rr;
     HIP_TRY(hipEventRecord(pair[0], c->stream));
@@ -1242,8 +1253,9 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     rc = launch(); if (rc) return rc;
     // divans_gpu_codec_tune_tables / the library's policy: the first batch that fills at least half the grid is decoded once per candidate placement
     // of the tables (the same bytes come out every time) and the fastest placement stays.  Two copies of the tables are alive at most -- the best so
-    // far and the candidate under test; a rejected one gives its memory back before the next is allocated -- and the loop stops early once it holds
-    // a placement of the fast population (>= 5 % ahead of the slowest seen; the two populations lie ~9 % apart, profiles/r04e_table_placement.txt).
+    // far and the candidate under test; a rejected one gives its memory back before the next is allocated.  (Stopping at the first placement
+    // that is 5 % ahead of the slowest seen was tried and costs the mixing configurations 5 %: their times spread over three clusters, and a very
+    // slow placement ends the search on a middling one -- profiles/r05a_bench_line_early_stop.json: 436.6 ms kept after 4, best of 12 is 415.)
     // This path synchronises the stream (the call is otherwise asynchronous); it runs once per codec.
     const uint32_t want = table_candidates_of(c);
     if (want > 1u && !c->tables_tuned && 2u * (uint64_t)n_streams >= resident_groups(c)) {
@@ -1252,7 +1264,7 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         HIP_TRY(hipEventElapsedTime(&best, c->ev[3], c->ev[4]));
         float worst = best;
         c->placement.first_ms = best; c->placement.tried = 1u;
-        for (uint32_t k = 1; k < want && !(c->table_candidates == 0u && best <= 0.95f * worst); ++k) {
+        for (uint32_t k = 1; k < want; ++k) {
             TableMem cand;
             if (table_alloc(c->device, c->tm.bytes, cand, true, (k & 1u) != 0u) != hipSuccess) { (void)hipGetLastError(); break; }     // no room for a second copy: keep what we have
             std::swap(c->tm, cand);

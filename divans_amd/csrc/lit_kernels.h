@@ -92,6 +92,7 @@ struct RansBatch {
     // chunk-parallel variant (streams of at most two chunks): chunk 0 is coded into scratch + (s + 1) * scratch_stride
     // (right-aligned) and then moved in front of chunk 1; null scratch selects the one-lane-per-stream kernel
     uint8_t* scratch; uint64_t scratch_stride; uint32_t* chunk0_sizes;
+    uint32_t split_states;      // chunk-parallel variant: two lanes per chunk, one per rANS state (rans_encode2_split_kernel) -- for batches too small to fill the SIMDs
 };
 
 typedef unsigned int bk_u32x2 __attribute__((ext_vector_type(2)));

@@ -374,14 +374,36 @@ __device__ __forceinline__ void rans_store_word(uint32_t* p, uint32_t v) {
 // the product of (double)state and a reciprocal refined to full precision and biased low by 2^-49 is below the true
 // quotient x by less than x * 2^-48.4 + rounding < 1, so its integer part is q or q - 1 and a single compare of the
 // remainder (which then fits 32 bits) finishes it.  Checked against 64-bit '/' and '%' by selftest_division_kernel.
+#ifndef DIVANS_RANS_DIVMOD      // experiment switch: 0 = round 1-4's form (two Newton steps, float -> integer through trunc / floor / cvt)
+#define DIVANS_RANS_DIVMOD 1
+#endif
+// Every kernel that calls rans_divmod runs its double-precision arithmetic ROUNDING TOWARD ZERO (rans_round_toward_zero() at its top; the
+// mode bits belong to the wave).  Then fma(state, y, 2^52) IS floor(state * y) + 2^52 -- the quotient sits in the mantissa, no trunc / floor /
+// convert sequence -- and every rounding on the way (the state's 63 bits into 53, the Newton step) errs low, the side the remainder test repairs.
+__device__ __forceinline__ void rans_round_toward_zero() {
+#if DIVANS_RANS_DIVMOD
+    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);      // hwreg(HW_REG_MODE, 2, 2) = FP_ROUND of f64 / f16: 3 = toward zero
+#endif
+}
 __device__ __forceinline__ uint64_t rans_divmod(uint64_t state, uint32_t freq, uint32_t& rem) {
     const double fd = (double)freq;
     double y = __builtin_amdgcn_rcp(fd);
+#if DIVANS_RANS_DIVMOD
+    // one Newton step: v_rcp_f64 delivers well over 26 bits, the step squares its error to below 2^-52, and the estimate is then biased low
+    // by 2^-49 -- far more than what is left -- so state * y never reaches the true quotient and falls short of it by less than
+    // 2^48 * 2^-48 = 1: the truncated product is the quotient or one below (selftest_division_kernel checks every divisor at its boundaries)
+    y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
+    y *= (1.0 - 0x1p-49);
+    const double sd = __builtin_fma((double)(uint32_t)(state >> 32), 0x1p32, (double)(uint32_t)state);
+    const uint64_t m = (uint64_t)__builtin_bit_cast(unsigned long long, __builtin_fma(sd, y, 0x1p52));
+    uint64_t q = m & ((1ull << 52) - 1ull);
+#else
     y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
     y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
     y *= (1.0 - 0x1p-49);
     const double qd = (double)state * y;
     uint64_t q = (uint64_t)qd;
+#endif
     uint32_t r = (uint32_t)state - (uint32_t)q * freq;     // low 32 bits are enough: the true remainder is below 2 * freq
     if (r >= freq) { q += 1; r -= freq; }
     rem = r;
@@ -390,7 +412,7 @@ __device__ __forceinline__ uint64_t rans_divmod(uint64_t state, uint32_t freq, u
 
 __device__ __forceinline__ uint64_t rans_put(uint64_t state, uint32_t start, uint32_t freq, uint32_t*& wp) {
     // rescale_lim = ((2^31 >> 15) << 32) * freq = freq << 48
-    if (state >= ((uint64_t)freq << 48)) { rans_store_word(--wp, (uint32_t)state); state >>= 32; }
+    if ((uint32_t)(state >> 32) >= (freq << 16)) { rans_store_word(--wp, (uint32_t)state); state >>= 32; }     // (freq << 48 has no low half)
     uint32_t r;
     const uint64_t q = rans_divmod(state, freq, r);        // ans.rs:318-323: ((state / freq) << 15) + state % freq + start
     return (q << 15) + (uint64_t)r + (uint64_t)start;
@@ -480,6 +502,90 @@ __global__ __launch_bounds__(RANS_THREADS) void rans_encode_kernel(const RansBat
 // as long as one -- so all that matters is that the one-wave workgroups are spread evenly, and left to itself the dispatcher stacks
 // three on some SIMDs of a CU while others hold one: 65 536 streams = 2048 waves = two per SIMD took 19.0 ms, pinned 14.7
 // (profiles/r03g_rans_wave_placement.txt).  Larger batches simply run in rounds of 2048 waves.
+// ---- the same chunk coded by TWO lanes, one per rANS state (ans.rs:302-329) ----------------------------------------------------------
+// ANSEncoder's two states alternate symbol by symbol and never meet: state_a takes the symbols at even distances from the chunk's end,
+// state_b the odd ones.  What they share is the output: every symbol step may push one 32-bit word, and the words lie in step order.
+// Lanes 2k (state a) and 2k + 1 (state b) of a wave run the same instruction stream, so at every step each lane sees through one DPP
+// swap whether its partner pushes a word too, and both keep the same running count: lane a's word goes first, lane b's behind it.  A lane
+// walks half the chunk -- 32 768 dependent steps instead of 65 536 -- which is what matters when the batch is too small to give every SIMD
+// a wave of whole chunks (a 16 384-stream batch = one of eight GPUs' share of BASELINE configs[4]: 512 such waves on 1024 SIMDs).
+// When the one-lane kernel already fills the SIMDs the total work is the same and this form only adds the bookkeeping; launch_rans_encode picks.
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false); }
+
+__device__ __forceinline__ uint32_t rans_encode_chunk_split(const uint32_t* sf, uint32_t beg, uint32_t end, uint32_t* top, uint32_t second, uint32_t& bad) {
+    uint64_t st = 1ull << 31;       // this lane's state
+    uint32_t cnt = 0;               // words pushed so far by the pair (the same value in both lanes)
+    uint32_t i = end;
+    // one step of the pair: lane `second` = 0 codes pa (the later symbol), lane 1 codes pb (the one before it)
+    auto put2 = [&](uint32_t pa, uint32_t pb) {
+        const uint32_t p = second ? pb : pa;
+        const uint32_t start = p & 0xffffu;
+        uint32_t freq = p >> 16;
+        bad |= (freq == 0u) | (freq >> 15) | (start >> 15);
+        freq = freq ? freq : 1u;
+        // rescale_lim = freq << 48 has no low half: the test needs the state's high word only
+        const uint32_t mine = (uint32_t)(st >> 32) >= (freq << 16) ? 1u : 0u;
+        const uint32_t theirs = (uint32_t)pair_swap((int)mine);
+        if (mine) { rans_store_word(top - 1u - cnt - (second ? theirs : 0u), (uint32_t)st); st >>= 32; }
+        cnt += mine + theirs;
+        uint32_t r;
+        const uint64_t q = rans_divmod(st, freq, r);
+        st = (q << 15) + (uint64_t)r + (uint64_t)start;
+    };
+    if (i > beg && (i & 3u)) { put2(sf[i - 1u], sf[i - 2u]); i -= 2u; }      // ragged tail (nsym is even: 0 or 2 symbols)
+    struct Quad { u32x4 a, b, c, d; };
+    auto sat = [](uint32_t x, uint32_t k) { return x >= k ? x - k : 0u; };
+    auto request1 = [&](u32x4& q, uint32_t t) {
+        const uint32_t* p = sf + (t >= beg + 4u ? t - 4u : beg);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q) : "v"(p) : "memory");
+    };
+    auto request = [&](Quad& q, uint32_t t) { request1(q.a, t); request1(q.b, sat(t, 4u)); request1(q.c, sat(t, 8u)); request1(q.d, sat(t, 12u)); };
+    auto code = [&](const u32x4& g) { if (i > beg) { put2(g.w, g.z); put2(g.y, g.x); i -= 4u; } };
+    Quad q0, q1, q2, q3;
+    request(q0, i); request(q1, sat(i, 16u)); request(q2, sat(i, 32u)); request(q3, sat(i, 48u));
+#define RANS_STEP(Q)                                                                    \
+    {                                                                                   \
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(Q.a), "+v"(Q.b), "+v"(Q.c), "+v"(Q.d) : : "memory"); \
+        const uint32_t t0 = i;                                                          \
+        code(Q.a); code(Q.b); code(Q.c); code(Q.d);                                     \
+        request(Q, sat(t0, 64u));                                                       \
+    }
+    while (i > beg) { RANS_STEP(q0) RANS_STEP(q1) RANS_STEP(q2) RANS_STEP(q3) }
+#undef RANS_STEP
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.a), "+v"(q0.b), "+v"(q0.c), "+v"(q0.d), "+v"(q1.a), "+v"(q1.b), "+v"(q1.c), "+v"(q1.d) : : "memory");
+    asm volatile("" : "+v"(q2.a), "+v"(q2.b), "+v"(q2.c), "+v"(q2.d), "+v"(q3.a), "+v"(q3.b), "+v"(q3.c), "+v"(q3.d) : : "memory");
+    // ans.rs:354-356: after the (even number of) symbols the reference's `a` is the state that coded the chunk's LAST symbol -- this pair's
+    // lane 0 -- and the unconditional swap puts the other one first: [state of lane 1][state of lane 0] in front of the words
+    uint32_t* wp = top - cnt - (second ? 4u : 2u);
+    rans_store_word(wp, (uint32_t)st); rans_store_word(wp + 1, (uint32_t)(st >> 32));
+    return 4u * (cnt + 4u);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rans_encode2_split_kernel(const RansBatch b) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t s = g >> 2, ck = (g >> 1) & 1u, second = g & 1u;
+    const bool live = s < b.n_streams;
+    const uint32_t len = live ? (b.in_sizes ? b.in_sizes[s] : b.stream_len) : 0u;
+    const uint32_t nsym = 2u * len, beg = ck << 16;
+    uint8_t* slot_end = b.out + (uint64_t)(s + 1) * b.out_slot;
+    uint32_t size = 0, bad = 0;
+    if (live && beg < nsym) {
+        const uint32_t end = beg + 65536u < nsym ? beg + 65536u : nsym;
+        const uint32_t* sf = b.sf + (size_t)s * b.sf_stride;
+        uint8_t* top = ck ? slot_end : b.scratch + (uint64_t)(s + 1) * b.scratch_stride;
+        size = rans_encode_chunk_split(sf, beg, end, (uint32_t*)top, second, bad);
+        if (b.chunk_bytes && !second) b.chunk_bytes[(size_t)s * b.max_chunks + ck] = size;
+    }
+    const uint32_t other = (uint32_t)__shfl_xor((int)size, 2);
+    if (live && (g & 3u) == 0u) {
+        const uint32_t total = size + other;
+        b.out_sizes[s] = total;
+        b.out_offsets[s] = (uint64_t)(slot_end - b.out) - total + b.out_base;
+        b.chunk0_sizes[s] = size;
+    }
+    if (bad) atomicOr(b.status, LIT_STATUS_BAD_MODEL);
+}
+
 #ifndef DIVANS_RANS2_THREADS    // experiment switch (scripts/build_variants.sh rans2)
 #define DIVANS_RANS2_THREADS 256
 #endif
@@ -897,8 +1003,13 @@ hipError_t launch_model_encode(const LitBatch& b_in, bool mix, uint32_t blocks, 
 }
 hipError_t launch_rans_encode(const RansBatch& b, hipStream_t st) {
     if (b.scratch) {   // one lane per chunk (streams of at most two chunks), then move chunk 0 in front of chunk 1
-        const uint32_t blocks = (2u * b.n_streams + RANS2_THREADS - 1) / RANS2_THREADS;
-        hipLaunchKernelGGL(rans_encode2_kernel, dim3(blocks), dim3(RANS2_THREADS), 0, st, b);
+        // one lane per chunk while that gives every SIMD a wave (2 x n_streams lanes >= 1024 waves on the 256-CU part); two lanes per chunk below that
+        if (b.split_states) {
+            hipLaunchKernelGGL(rans_encode2_split_kernel, dim3((4u * b.n_streams + 255u) / 256u), dim3(256), 0, st, b);
+        } else {
+            const uint32_t blocks = (2u * b.n_streams + RANS2_THREADS - 1) / RANS2_THREADS;
+            hipLaunchKernelGGL(rans_encode2_kernel, dim3(blocks), dim3(RANS2_THREADS), 0, st, b);
+        }
         const uint32_t sblocks = (b.n_streams + 3u) / 4u < 8192u ? (b.n_streams + 3u) / 4u : 8192u;
         hipLaunchKernelGGL(rans_stitch_kernel, dim3(sblocks), dim3(256), 0, st, b);
         return hipGetLastError();

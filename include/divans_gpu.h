@@ -251,6 +251,11 @@ int divans_gpu_codec_set_bucket_batch(divans_gpu_codec *c, uint32_t streams);
  * call-by-call stream decoder); there divans_gpu_codec_set_geometry / _set_split_cache only shape the streaming encoder pass. */
 int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4],
                                  uint32_t blocks);
+/* The rANS pass of streams of at most two 65 536-symbol chunks: 1 = one lane per chunk, 2 = two lanes per chunk, one per rANS state
+ * (ans.rs:302-329: the states alternate symbol by symbol and only share the output order), 0 = automatic (default): two lanes while
+ * that still gives every SIMD at most one wave -- batches up to 64 streams per CU, where it halves the pass (a lane's chain is half as
+ * long); larger batches fill the SIMDs with whole-chunk lanes and the total work is the same.  The coded bytes do not depend on it. */
+int divans_gpu_codec_set_rans_split(divans_gpu_codec *c, uint32_t mode);
 /* Stride-1 configurations (every mixing value 4): the order in which the decoder's private tables lay out the rows of the 256 previous-byte
  * values, i.e. which rows share a 128-byte line.  0 (default) = a text-frequency rank: lower-case letters by English frequency, separators,
  * capitals, digits, then everything else numerically -- on text an L2 line then holds rows that are hot together (-4 % decode time,
@@ -264,8 +269,8 @@ int divans_gpu_experimental_decoders(void);
  * about one placement in six is a fast one, profiles/r04e_table_placement.txt), so the library measures: the first divans_gpu_lit_decode_batch
  * call whose batch fills at least half the persistent grid runs its launch on several placements of the tables -- alternately 32 MiB chunks
  * mapped side by side and one hipMalloc block; which kind is faster differs from box to box -- and keeps the fastest; the same bytes come out
- * every time.  `candidates`: 0 = the library's policy, the default: tables of 2 GiB and more (whole-GPU batches) up to 12 placements,
- * stopping as soon as one is >= 5 % ahead of the slowest seen; smaller tables are not tuned.  1 = off.  2..16 = exactly that many.
+ * every time.  `candidates`: 0 = the library's policy, the default: tables of 2 GiB and more (whole-GPU batches) 12 placements;
+ * smaller tables are not tuned.  1 = off.  2..16 = that many.
  * THAT CALL SYNCHRONISES THE STREAM (every other decode call is asynchronous) and takes (placements tried) x (one decode + one allocation of
  * the tables): seconds, once per codec and again after the tables had to grow.  Memory while it runs: two copies of the tables (the best so
  * far and the candidate; a rejected copy is released before the next is allocated).  Address space: every chunk-mapped candidate reserves a

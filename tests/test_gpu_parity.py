@@ -788,10 +788,12 @@ def test_table_placement_tuning_changes_no_byte(cfg_name, corpus):
     codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, plain)
     assert torch.equal(plain, d_in) and codec.status() == 0
     with pytest.raises(da.DivansGpuError):
-        codec.tune_tables(0)
-    with pytest.raises(da.DivansGpuError):
         codec.tune_tables(17)
+    codec.tune_tables(0)                            # the library's policy (the default): tables of 2 GiB and more are tuned, smaller ones are not
+    pl = codec.table_placement()
+    assert pl["policy_candidates"] == (12 if codec.info().table_bytes >= (2 << 30) else 1), pl
     codec.tune_tables(3)
+    assert codec.table_placement()["policy_candidates"] == 3
     few = torch.zeros((40, 2048), dtype=torch.uint8, device="cuda")
     codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], 40, 2048, few)          # below half the grid: not the batch to time
     assert torch.equal(few, d_in[:40])
@@ -800,23 +802,66 @@ def test_table_placement_tuning_changes_no_byte(cfg_name, corpus):
         codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
         assert torch.equal(back, d_in) and codec.status() == 0
         assert codec.info().last_decode_ms > 0
+    pl = codec.table_placement()                                                            # three placements were decoded on, the fastest stayed
+    assert pl["tried"] == 3 and 0 < pl["best_ms"] <= pl["first_ms"] <= pl["worst_ms"], pl
     # a damaged stream is still reported by a tuning decode
     codec.tune_tables(2)
     coded = outs["out"].clone(); coded[int(outs["offsets"][5]) + 30] ^= 0x40
     codec.decode_batch(coded, outs["offsets"], outs["sizes"], n, 2048, back)
     assert codec.status() & 2
-    tables = codec.info().table_bytes
     codec.close()
-    # the tables of a closed codec wait (mapped) for the next one; divans_gpu_trim gives their memory back
+    # chunk-mapped tables of a closed codec wait (mapped) for the next one; divans_gpu_trim gives their memory back.  The address ranges the
+    # placements used are counted and stay below the cap
     torch.cuda.synchronize()
+    tm = da.table_memory()
+    assert tm["va_reserved_bytes"] <= tm["va_cap_bytes"] and tm["idle_ranges"] <= 2, tm
     before = torch.cuda.mem_get_info()[0]
     da.trim()
-    assert torch.cuda.mem_get_info()[0] >= before + tables // 2
+    assert torch.cuda.mem_get_info()[0] >= before + tm["idle_bytes"] // 2
+    assert da.table_memory()["idle_ranges"] == 0 and da.table_memory()["va_reserved_bytes"] == tm["va_reserved_bytes"]     # memory back, addresses not
     da.trim()                                       # nothing left: a no-op
     da2, codec2 = _codec(cfg_name, 2048)            # and a codec made afterwards maps a new range
     codec2.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
     assert torch.equal(back, d_in) and codec2.status() == 0
     codec2.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+@pytest.mark.parametrize("split", [1, 2])
+def test_rans_pass_with_one_or_two_lanes_per_chunk(cfg_name, split, corpus, shuffle384, random_then_unicode):
+    """ans.rs:302-378: the chunk-parallel rANS pass with one lane per 65 536-symbol chunk and with two lanes per chunk, one per rANS state
+    (the states alternate symbol by symbol; the two lanes merge their pushed words in step order) -- the oracle's bytes either way, for
+    ragged batches around the chunk seam, streams of one and of two chunks, one symbol pair, and bytes that make a state push at every step"""
+    import torch
+    L = 65536
+    lens = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 4095, 32766, 32767, 32768, 32769, 32770, 40001, 65535, 65536, 12345, 50000]
+    srcs = [corpus, random_then_unicode, np.resize(shuffle384, 200000), np.random.default_rng(9).integers(0, 256, 200000, dtype=np.uint8),
+            np.zeros(200000, np.uint8)]
+    parts = [srcs[i % 5][777 * i:777 * i + n] for i, n in enumerate(lens)]
+    n = len(lens)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    flat = np.concatenate(parts)
+    dev = torch.device("cuda", 0)
+    da, codec = _codec(cfg_name, L)
+    codec.set_rans_split(split)
+    d_in = torch.from_numpy(np.concatenate([flat, np.zeros(64, np.uint8)])).to(dev)
+    outs = codec.alloc_encode_outputs(n)
+    d_off = torch.tensor(starts, dtype=torch.int64, device=dev); d_sz = torch.tensor(lens, dtype=torch.int32, device=dev)
+    codec.encode_batch(d_in, n, L, outs, in_offsets=d_off, in_sizes=d_sz)
+    torch.cuda.synchronize()
+    assert codec.status() == 0
+    offs = outs["offsets"].cpu().numpy(); szs = outs["sizes"].cpu().numpy(); blob = outs["out"].cpu().numpy()
+    ocfg = _oracle_cfg(cfg_name)
+    for i in range(n):
+        ref = po.lit_encode(ocfg, parts[i])
+        assert szs[i] == ref.size and (blob[offs[i]:offs[i] + szs[i]] == ref).all(), (split, i, lens[i], int(szs[i]), ref.size)
+    d_back = torch.zeros(sum(lens) + 64, dtype=torch.uint8, device=dev)
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, L, d_back, out_offsets=d_off, out_sizes=d_sz)
+    torch.cuda.synchronize()
+    assert (d_back.cpu().numpy()[:sum(lens)] == flat).all() and codec.status() == 0
+    with pytest.raises(da.DivansGpuError):
+        codec.set_rans_split(3)
+    codec.close()
 
 
 @pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
