@@ -374,32 +374,27 @@ __device__ __forceinline__ void rans_store_word(uint32_t* p, uint32_t v) {
 // the product of (double)state and a reciprocal refined to full precision and biased low by 2^-49 is below the true
 // quotient x by less than x * 2^-48.4 + rounding < 1, so its integer part is q or q - 1 and a single compare of the
 // remainder (which then fits 32 bits) finishes it.  Checked against 64-bit '/' and '%' by selftest_division_kernel.
-#ifndef DIVANS_RANS_DIVMOD      // experiment switch: 0 = round 1-4's form (two Newton steps, float -> integer through trunc / floor / cvt)
+#ifndef DIVANS_RANS_DIVMOD      // experiment switch: 0 = round 1-4's form (float -> integer through trunc / ldexp / floor / fma / two cvt)
 #define DIVANS_RANS_DIVMOD 1
 #endif
-// Every kernel that calls rans_divmod runs its double-precision arithmetic ROUNDING TOWARD ZERO (rans_round_toward_zero() at its top; the
-// mode bits belong to the wave).  Then fma(state, y, 2^52) IS floor(state * y) + 2^52 -- the quotient sits in the mantissa, no trunc / floor /
-// convert sequence -- and every rounding on the way (the state's 63 bits into 53, the Newton step) errs low, the side the remainder test repairs.
-__device__ __forceinline__ void rans_round_toward_zero() {
-#if DIVANS_RANS_DIVMOD
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);      // hwreg(HW_REG_MODE, 2, 2) = FP_ROUND of f64 / f16: 3 = toward zero
-#endif
-}
+// 64-bit state / freq in one double-precision step.  The reciprocal is biased LOW by 2^-49 -- sixteen times what the Newton step and the
+// roundings on the way can add back (two Newton steps refine v_rcp_f64 to full precision; the state's 63 bits round into 53 at 2^-53) -- so the product never reaches the true quotient, and since the quotient is below 2^48 it falls short of it by less
+// than 2^48 * 2^-48 = 1: its integer part is the quotient or one below, which the remainder decides.  The integer part leaves the double
+// through its mantissa (trunc, + 2^52: exact for an integer below 2^52) instead of the compiler's six-instruction f64 -> u64 conversion.
+// selftest_division_kernel checks every divisor at its boundary states against 64-bit '/' and '%'.
+// (Rounding the whole kernel's f64 arithmetic toward zero, so that one fma(state, y, 2^52) IS the floor, does not survive the compiler: its
+// mode-register pass restores round-to-nearest in front of the first f64 FMA -- tried in round 5, the self-test caught it.)
 __device__ __forceinline__ uint64_t rans_divmod(uint64_t state, uint32_t freq, uint32_t& rem) {
     const double fd = (double)freq;
     double y = __builtin_amdgcn_rcp(fd);
-#if DIVANS_RANS_DIVMOD
-    // one Newton step: v_rcp_f64 delivers well over 26 bits, the step squares its error to below 2^-52, and the estimate is then biased low
-    // by 2^-49 -- far more than what is left -- so state * y never reaches the true quotient and falls short of it by less than
-    // 2^48 * 2^-48 = 1: the truncated product is the quotient or one below (selftest_division_kernel checks every divisor at its boundaries)
     y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);     // (one step is not enough: 2218 of 8e8 self-test divisions came out wrong with it)
+#if DIVANS_RANS_DIVMOD
     y *= (1.0 - 0x1p-49);
     const double sd = __builtin_fma((double)(uint32_t)(state >> 32), 0x1p32, (double)(uint32_t)state);
-    const uint64_t m = (uint64_t)__builtin_bit_cast(unsigned long long, __builtin_fma(sd, y, 0x1p52));
-    uint64_t q = m & ((1ull << 52) - 1ull);
+    const double t = __builtin_trunc(sd * y) + 0x1p52;
+    uint64_t q = (uint64_t)__builtin_bit_cast(unsigned long long, t) & ((1ull << 52) - 1ull);
 #else
-    y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
-    y = __builtin_fma(__builtin_fma(-fd, y, 1.0), y, y);
     y *= (1.0 - 0x1p-49);
     const double qd = (double)state * y;
     uint64_t q = (uint64_t)qd;
