@@ -820,6 +820,18 @@ def test_table_placement_tuning_changes_no_byte(cfg_name, corpus):
     assert torch.cuda.mem_get_info()[0] >= before + tm["idle_bytes"] // 2
     assert da.table_memory()["idle_ranges"] == 0 and da.table_memory()["va_reserved_bytes"] == tm["va_reserved_bytes"]     # memory back, addresses not
     da.trim()                                       # nothing left: a no-op
+    # past the cap on reserved-and-never-returned address space, big tables are plain hipMalloc blocks (which hipFree does return)
+    L = da.load_library()
+    L.divans_gpu_set_table_va_cap(0)
+    try:
+        da3, codec3 = _codec(cfg_name, 2048)
+        codec3.tune_tables(2)
+        codec3.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
+        assert torch.equal(back, d_in) and codec3.status() == 0
+        assert codec3.table_placement()["kept"] == "one block" and da.table_memory()["va_reserved_bytes"] == tm["va_reserved_bytes"]
+        codec3.close()
+    finally:
+        L.divans_gpu_set_table_va_cap(tm["va_cap_bytes"])
     da2, codec2 = _codec(cfg_name, 2048)            # and a codec made afterwards maps a new range
     codec2.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
     assert torch.equal(back, d_in) and codec2.status() == 0
