@@ -308,10 +308,14 @@ struct PoolRegistry {
     void release(int device) {           // device < 0: all
         std::vector<LanePool*> pools;
         { std::lock_guard<std::mutex> l(mu); for (auto& kv : by_device) if (device < 0 || kv.first == device) pools.push_back(kv.second.get()); }
+        int before = -1;
+        const bool have_before = hipGetDevice(&before) == hipSuccess;
         for (LanePool* p : pools) {
             std::lock_guard<std::mutex> l(p->mu);       // waits for a call that is running on that device
             if (p->lanes) { (void)hipSetDevice(p->device); p->lanes.reset(); }
         }
+        if (have_before) (void)hipSetDevice(before);    // the caller's current device is not ours to change
+
     }
 };
 PoolRegistry& registry() { static PoolRegistry r; return r; }

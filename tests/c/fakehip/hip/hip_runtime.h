@@ -21,6 +21,7 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 // two "devices", the current one per thread as in the HIP runtime (the batch interface keeps one set of lanes per device)
 static inline int& fake_hip_current_device() { static thread_local int d = 0; return d; }
 static inline hipError_t hipSetDevice(int d) { if (d < 0 || d > 1) return hipErrorInvalidValue; fake_hip_current_device() = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = fake_hip_current_device(); return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
