@@ -181,9 +181,13 @@ def roofline_of(kern_ms, alg_bytes, traffic):
     achieved = alg_bytes[dom] / 1e9 / (kern_ms[dom] / 1e3) if kern_ms[dom] > 0 else 0.0
     ent = _traffic_entry(traffic, dom)
     t = ent.get("hbm_bytes_per_launch") if ent else None
+    moved = (t / 1e9 / (kern_ms[dom] / 1e3)) if (t and kern_ms[dom] > 0) else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": t,
             "traffic_ratio": (round(t / alg_bytes[dom], 1) if t else None),     # HBM bytes moved per algorithmic byte
+            # what the launch actually moves over the fabric per second (2 x FETCH_SIZE + WRITE_SIZE of the replayed PMC pass over THIS run's kernel
+            # time): randomly addressed 128-byte fills and 32-byte write-backs, the pattern HBM sustains worst -- the kernel's real operating point
+            "traffic_GBps": (round(moved, 1) if moved else None), "traffic_frac_of_peak": (round(moved / HBM_PEAK_GBS, 4) if moved else None),
             "traffic_source": (traffic.get("_source") if t is not None else "no committed PMC pass matches this kernel / workload"),
             "algorithmic_bytes_per_launch": alg_bytes[dom]}
 
