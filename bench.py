@@ -543,8 +543,8 @@ def main():
             step_s = elapsed / K
             m = dict(mg)
             m.update({"gather_ms": round(gather_s * 1e3, 3), "gathered_bytes": int(coded_all), "gather_checked_on_rank0": bool(g_ok == world),
-                      "rccl_world_size": world, "transport": ("gloo, all ranks on one GPU (DIVANS_BENCH_SHARE_GPU: path verification only; the RCCL branch of this file has never executed on hardware -- "
-                                    "every lease of rounds 1-5 was one GPU)") if share_gpu else "rccl",
+                      "rccl_world_size": world, "transport": ("gloo, all ranks on one GPU (DIVANS_BENCH_SHARE_GPU: path verification only; RCCL itself has only run at world 1 -- init, all_reduce, all_gather, barrier, "
+                                    "a batched isend / irecv pair, tests/test_gpu_sharding.py -- every lease of rounds 1-5 was one GPU: shards have never moved between two GPUs)") if share_gpu else "rccl",
                       "scatter_gather_inclusive_MBps": round(total_streams * L / 1e6 / (step_s + mg["scatter_ms"] / 1e3 + gather_s), 2)})
             t = torch.zeros((3, world), dtype=torch.float64, device="cpu" if share_gpu else dev)
             t[0, rank] = res["elapsed"] / K * 1e3; t[1, rank] = res["roofline"]["frac"]; t[2, rank] = res["roofline"]["achieved"]

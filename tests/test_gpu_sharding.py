@@ -97,3 +97,46 @@ def test_world2_hip_coder_shards_through_gloo_staging(cfg_name):
         p.join(timeout=120)
         assert p.exitcode == 0
     _check_against_oracle(res, n_streams, cfg_name)
+
+
+def _rccl_world1(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    except Exception as e:      # an image without a working RCCL: nothing to test here
+        q.put(("skip", repr(e))); return
+    dev = torch.device("cuda", 0)
+    out = {}
+    t = torch.tensor([3.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); out["max"] = float(t.item())
+    v = torch.arange(5, dtype=torch.int64, device=dev); dist.all_reduce(v, op=dist.ReduceOp.SUM); out["sum"] = v.tolist()
+    parts = [torch.empty(7, dtype=torch.int32, device=dev)]; dist.all_gather(parts, torch.arange(7, dtype=torch.int32, device=dev)); out["gather"] = parts[0].tolist()
+    dist.barrier()
+    try:    # the variable-length gather's transport: batched point-to-point, here to the only rank there is
+        src = torch.arange(1 << 20, dtype=torch.int64, device=dev).to(torch.uint8); dst = torch.zeros_like(src)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, 0), dist.P2POp(dist.irecv, dst, 0)]):
+            w.wait()
+        torch.cuda.synchronize()
+        out["p2p_self"] = bool(torch.equal(src, dst))
+    except Exception as e:
+        out["p2p_self"] = "unsupported: " + repr(e)[:200]
+    dist.destroy_process_group()
+    q.put(("ok", out))
+
+
+def test_rccl_backend_runs_on_this_box_at_world_1():
+    """The "nccl" (= RCCL) branch of bench.py / sharding.py needs more than one GPU to move shards, and every lease of rounds 1-5 was one GPU.
+    What one GPU can show: the backend initialises on this ROCm image, takes device tensors without staging, and the collective calls the
+    N > 1 path makes (all_reduce MAX / SUM, all_gather, barrier, a batched isend / irecv pair) run through it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1, args=(32500 + os.getpid() % 1500, q))
+    p.start()
+    kind, res = q.get(timeout=300)
+    p.join(timeout=120)
+    if kind == "skip":
+        pytest.skip("no working RCCL here: " + res)
+    assert res["max"] == 3.5 and res["sum"] == [0, 1, 2, 3, 4] and res["gather"] == list(range(7)), res
+    assert res["p2p_self"] is True or str(res["p2p_self"]).startswith("unsupported"), res
+    print("RCCL at world 1:", res)
