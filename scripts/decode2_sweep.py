@@ -57,10 +57,12 @@ def main():
         except Exception as e:  # noqa: BLE001
             print(f"{label}: FAILED {e}", flush=True)
 
-    run("gen1 default", lambda c: c.set_decoder(1))
+    if da.experimental_decoders():      # generations 1 and 4 exist only in DIVANS_WITH_EXPERIMENTAL_DECODERS=1 builds
+        run("gen1 default", lambda c: c.set_decoder(1))
     run("gen2 default (direct mapped)", lambda c: c.set_decoder(2))
     run("gen3 default (2-way)", lambda c: c.set_decoder(3))
-    run("gen4 default (one lane per stream, no caches, one wave per SIMD)", lambda c: c.set_decoder(4))
+    if da.experimental_decoders():
+        run("gen4 default (one lane per stream, no caches, one wave per SIMD)", lambda c: c.set_decoder(4))
     if args.geoms:
         geoms = [tuple(int(x) for x in g.split(":")) for g in args.geoms.split(",")]
     elif args.config == "simple":
