@@ -178,6 +178,8 @@ int main(int argc, char** argv) {
     const long rounds = std::strtol(argv[3], nullptr, 0);
     const size_t largest = argc > 4 ? (size_t)std::strtoul(argv[4], nullptr, 0) : 700;
     const int devices = argc > 5 ? std::atoi(argv[5]) : 1;
+    // the oracle is single-threaded test infrastructure with lazily built tables (CRC-32C, context lookups): build them before the threads start
+    { Bytes warm; divans_batch_options wo; divans_batch_options_default(&wo); wo.dynamic_context_mixing = 2; (void)oracle_container(wo, data.data(), 3000, warm); }
     int rc = 0;
     if (devices <= 1) rc = run_rounds(data, noise_from, seed ^ 0x5bd1e995u, rounds, largest, 0);
     else {
