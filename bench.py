@@ -176,13 +176,33 @@ def _traffic_entry(traffic, kernel):
     return None
 
 
-def roofline_of(kern_ms, alg_bytes, traffic):
+def roofline_of(kern_ms, alg_bytes, traffic, replay_ms=None):
+    """`frac` = algorithmic bytes of the dominant kernel over its time over 8 TB/s (the contract's roofline).  Beside it, what the kernel is
+    actually up against -- the fabric's rate for randomly addressed 32-byte rows: `request_rate_Gps` = the L2 -> fabric requests of the
+    launch (TCC_EA0_RDREQ + WRREQ of the committed PMC pass) over THIS run's kernel time, `request_ceiling_Gps` = the same requests over
+    the time of divans_gpu_codec_row_replay measured in THIS run on THIS box (the same rows through the same caches, layout and grid with
+    no decoding in between), `request_frac` = their ratio = replay time / decode time."""
     dom = max(kern_ms, key=kern_ms.get)
     achieved = alg_bytes[dom] / 1e9 / (kern_ms[dom] / 1e3) if kern_ms[dom] > 0 else 0.0
     ent = _traffic_entry(traffic, dom)
     t = ent.get("hbm_bytes_per_launch") if ent else None
     moved = (t / 1e9 / (kern_ms[dom] / 1e3)) if (t and kern_ms[dom] > 0) else None
-    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    req = (ent.get("rdreq_per_launch", 0) + ent.get("wrreq_per_launch", 0)) if ent and ent.get("rdreq_per_launch") else None
+    rp = _traffic_entry(traffic, "row_replay_kernel")
+    rp_req = (rp.get("rdreq_per_launch", 0) + rp.get("wrreq_per_launch", 0)) if rp and rp.get("rdreq_per_launch") else None
+    extra = {}
+    if replay_ms and kern_ms[dom] > 0:
+        frac = replay_ms / kern_ms[dom]
+        extra = {"replay_ms": round(replay_ms, 3), "request_frac": round(frac, 4),
+                 "request_rate_Gps": (round(req / 1e9 / (kern_ms[dom] / 1e3), 2) if req else None),
+                 "request_ceiling_Gps": (round((rp_req or req) / 1e9 / (replay_ms / 1e3), 2) if (rp_req or req) else None),
+                 "requests_per_launch": req, "replay_requests_per_launch": rp_req,
+                 "request_note": "replay = divans_gpu_codec_row_replay on this box in this run: every CDF row this batch's decode touches, loaded / blended / stored through the same LDS caches, table "
+                                 "layout, byte order and persistent grid, without entropy decoding and with the low-nibble rows requested a byte ahead (a decoder cannot); request counts replayed from the committed PMC pass"}
+        bound = ("fabric requests: randomly addressed 32-byte CDF rows (the decode kernel runs at %d %% of the memory side's own time for its row traffic)" % round(100 * frac)) if frac >= 0.75 else \
+                ("a stream's dependency chain + VALU issue (the row traffic alone would take %d %% of the kernel's time)" % round(100 * frac))
+        extra["bound_detail"] = bound
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", **extra,
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": t,
             "traffic_ratio": (round(t / alg_bytes[dom], 1) if t else None),     # HBM bytes moved per algorithmic byte
             # what the launch actually moves over the fabric per second (2 x FETCH_SIZE + WRITE_SIZE of the replayed PMC pass over THIS run's kernel
@@ -267,7 +287,28 @@ def verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, n_check)
     return ok and bad == 0, len(picks)
 
 
-def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note="", traffic_name=None, byte_order=0):
+def _order_record(codec):
+    """the byte order the decoder's tables are laid out in (divans_gpu_codec_byte_order): mode, and the 12 most frequent byte values of a learned rank"""
+    bo = codec.byte_order(with_rank=True)
+    rec = {"mode": {0: "learned from the codec's first batch (64 streams x 2 KiB sampled on the device)", 1: "numeric", 2: "English-text hint"}[bo["mode"]], "in_use": bo["ready"]}
+    if bo["ready"]:
+        inv = sorted(range(256), key=lambda b: bo["rank"][b])
+        rec["first_ranks"] = "".join(chr(b) if 32 < b < 127 else ("_" if b == 32 else "?") for b in inv[:16])
+    return rec
+
+
+def settle_placement(codec, step, limit=20):
+    """untimed steps until the library's call-by-call placement search is over (one placement per decode call)"""
+    extra = 0
+    p = codec.table_placement()
+    if p["policy_candidates"] > 1 and p["tried"] == 0 and not p["searching"]:
+        step(); extra += 1       # the search starts with the first decode that fills half the grid once the byte order is settled
+    while codec.table_placement()["searching"] and extra < limit:
+        step(); extra += 1
+    return extra
+
+
+def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note="", traffic_name=None, byte_order=None, steps=None):
     """encode+decode config (simple or mixing): verify, time, report."""
     cfg = da.config_simple() if name == "simple" else da.config_context_mixing()
     ocfg = po.config_simple() if name == "simple" else po.config_context_mixing()
@@ -286,20 +327,25 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     if args.split_cache:
         hi_rows, lo_rows = (int(x) for x in args.split_cache.split(","))
         codec.set_split_cache(hi_rows, lo_rows)
-    if byte_order:
+    if byte_order is not None:
         codec.set_byte_order(byte_order)
     if args.table_candidates:
-        codec.tune_tables(args.table_candidates)      # 0 = what a plain divans_gpu_codec_create caller gets (the library's policy); acts on the first
-                                                      # decode below (verification or warm-up), never inside the timed region
+        codec.tune_tables(args.table_candidates)      # 0 = what a plain divans_gpu_codec_create caller gets: the library's call-by-call search, which the
+                                                      # untimed passes below complete (verification + warm-up + settle_placement); k >= 2 = eager, on the first decode
     outs = alloc_packed_outputs(torch, N, L, dev)
     d_back = torch.empty((N, L), dtype=torch.uint8, device=dev)
     ok, checked = True, 0
     if not args.no_verify:
         ok, checked = verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, args.check_streams)
         first_sizes = outs["sizes"].clone(); d_back.zero_()
-    steps, warm = args.steps, args.warmup
+    steps, warm = (steps or args.steps), args.warmup
     if args.no_verify and args.table_candidates != 1:
         warm = max(warm, 1)          # the decode that tries the table placements is never a timed one
+
+    def untimed_step():
+        codec.encode_packed(d_in, N, L, outs["packed"], outs["packed_offsets"], outs["sizes"], outs["packed_total"])
+        codec.decode_batch(outs["packed"], outs["packed_offsets"], outs["sizes"], N, L, d_back)
+    search_steps = settle_placement(codec, untimed_step)      # the placement search ends before the warm-up: no timed step runs on a candidate
     elapsed, rec = timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, warm, barrier)
     if not args.no_verify:   # the timed passes must have produced the same thing
         ok = ok and bool(torch.equal(outs["sizes"], first_sizes)) and bool(torch.equal(d_back, d_in)) and codec.status() == 0
@@ -309,6 +355,12 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     kern = {dk: avg(rec["dkern"]), "encode_model_pass": avg(rec["model"]), "encode_rans_pass": avg(rec["rans"]),
             "pack_streams": avg(rec["pack"])}
     raw = N * L
+    replay_ms = None
+    try:
+        codec.row_replay(d_in, N, L)                 # (first launch: untimed)
+        replay_ms = min(codec.row_replay(d_in, N, L) for _ in range(2))
+    except Exception as e:       # no replay instance for this configuration / cache organisation
+        sys.stderr.write(f"bench: row replay not available ({e})\n")
     # algorithmic bytes per launch: decode reads C + writes raw; the model pass reads raw and hands
     # 4 B per nibble to the rANS pass; the rANS pass reads that spill and writes C
     alg = {dk: raw + coded_total, "encode_model_pass": raw + 8 * raw, "encode_rans_pass": 8 * raw + coded_total,
@@ -317,7 +369,8 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
         "elapsed": elapsed, "steps": steps, "ok": ok, "checked_vs_oracle": checked, "coded_total": coded_total,
         "encode_MBps": round(raw / 1e6 / (avg(rec["enc"]) / 1e3), 2), "decode_MBps": round(raw / 1e6 / (avg(rec["dec"]) / 1e3), 2),
         "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
-        "roofline": roofline_of(kern, alg, load_traffic(traffic_name or name, N, L)),
+        "roofline": roofline_of(kern, alg, load_traffic(traffic_name or name, N, L), replay_ms),
+        "byte_order": _order_record(codec), "placement_search_steps": search_steps,
         # HBM the codec holds besides the caller's buffers: the encoder's work arrays (+ the decoder's CDF tables)
         "encoder_work_bytes_per_input_byte": round(codec.info().scratch_bytes / raw, 2),
         "table_bytes": int(codec.info().table_bytes),
@@ -326,7 +379,7 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     return res, codec, outs
 
 
-def run_decode_only(torch, da, po, args, dev, copies=4096):
+def run_decode_only(torch, da, po, args, dev, copies=4096, steps=None):
     """BASELINE configs[3]: testdata/random_then_unicode (291 949 B) cut into 5 blocks of at most 64 KiB, each coded ONCE
     on the CPU by the oracle as an independent stream under TestContextMixing options, the coded streams replicated
     x4096 in HBM, all decoded by the GPU and every copy compared with the original."""
@@ -363,8 +416,10 @@ def run_decode_only(torch, da, po, args, dev, copies=4096):
 
     decode(); torch.cuda.synchronize()
     ok = bool((d_out.view(copies, data.size) == orig[None, :]).all().item()) and codec.status() == 0
+    search_steps = settle_placement(codec, decode)
+    torch.cuda.synchronize()
     d_out.zero_()
-    steps = max(1, args.steps)
+    steps = max(1, steps or args.steps)
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     ms, kms = [], []
     for _ in range(steps):
@@ -374,14 +429,20 @@ def run_decode_only(torch, da, po, args, dev, copies=4096):
     raw, ctot = copies * int(data.size), copies * int(sum(c.size for c in coded))
     dk = codec.last_decode_kernel() or "lit_decode_kernel"
     kern = {dk: sum(kms) / len(kms)}
+    replay_ms = None
+    try:
+        codec.row_replay(d_out, N, L, offsets=d_out_off, sizes=d_out_sz)
+        replay_ms = min(codec.row_replay(d_out, N, L, offsets=d_out_off, sizes=d_out_sz) for _ in range(2))
+    except Exception as e:
+        sys.stderr.write(f"bench: row replay not available ({e})\n")
     res = {
         "workload": f"BASELINE configs[3]: testdata/random_then_unicode ({data.size} B) as {nb} independent streams (4 x 65536 + {blocks[-1].size} B), coded once by the "
                     f"oracle under TestContextMixing options, x{copies} copies = {N} streams resident in HBM, decode only, every copy compared",
         "bit_exact": ok, "streams": N, "steps": steps, "ms_per_step": round(sum(ms) / len(ms), 3),
         "value": round(raw / 1e6 / (sum(ms) / len(ms) / 1e3), 2), "unit": "MB/s decode",
         "compressed_ratio": round(ctot / raw, 4), "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
-        "roofline": roofline_of(kern, {dk: raw + ctot}, load_traffic("decode_only", N, L)),
-        "table_placement": codec.table_placement(),
+        "roofline": roofline_of(kern, {dk: raw + ctot}, load_traffic("decode_only", N, L), replay_ms),
+        "table_placement": codec.table_placement(), "byte_order": _order_record(codec), "placement_search_steps": search_steps,
     }
     codec.close()
     return res
@@ -514,10 +575,12 @@ def main():
     shard_text = (f"{total_streams} independent {L} B streams in total, split into contiguous ranges over the GPUs ({N} on this rank)" if strong
                   else f"{N} independent {L} B streams per GPU")
 
-    def pair_record(name, d_in=d_in, traffic_name=None, byte_order=0):
+    sub_steps = min(args.steps, 6)       # the sub-records time fewer steps than the headline's K (their own "steps" says how many)
+
+    def pair_record(name, d_in=d_in, traffic_name=None, byte_order=None, steps=None):
         """One encode+decode configuration on every rank: verify, time (max over ranks), at world > 1 gather the coded streams
         to rank 0 and check them there.  Returns (record for rank 0, bit-exact on all ranks)."""
-        res, codec, outs = run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, traffic_name=traffic_name, byte_order=byte_order)
+        res, codec, outs = run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, traffic_name=traffic_name, byte_order=byte_order, steps=steps)
         elapsed = sharding.max_over_ranks(res["elapsed"], dev)
         coded_all, ok_count = sharding.sum_over_ranks([res["coded_total"], int(res["ok"])], dev)
         ok_all = ok_count == world
@@ -563,7 +626,7 @@ def main():
                "bit_exact": bool(ok_all), "checked_vs_oracle": res["checked_vs_oracle"], "compressed_ratio": round(coded_all / float(total_bytes), 4),
                "encode_MBps": res["encode_MBps"], "decode_MBps": res["decode_MBps"], "kernel_ms": res["kernel_ms"], "roofline": res["roofline"],
                "encoder_work_bytes_per_input_byte": res["encoder_work_bytes_per_input_byte"], "table_bytes": res["table_bytes"],
-               "table_placement": res["table_placement"]}
+               "table_placement": res["table_placement"], "byte_order": res["byte_order"], "placement_search_steps": res["placement_search_steps"]}
         if m:
             rec["multi_gpu"] = m
         return rec, ok_all
@@ -594,7 +657,8 @@ def main():
                 "encode_MBps": rec["encode_MBps"], "decode_MBps": rec["decode_MBps"],
                 "kernel_ms": rec["kernel_ms"], "roofline": rec["roofline"],
                 "encoder_work_bytes_per_input_byte": rec["encoder_work_bytes_per_input_byte"], "table_bytes": rec["table_bytes"],
-                "table_placement": rec["table_placement"],
+                "table_placement": rec["table_placement"], "byte_order": rec["byte_order"],
+                "untimed_passes": {"verification": 0 if args.no_verify else 1, "placement_search": rec["placement_search_steps"], "warmup": args.warmup},
             }
             if "multi_gpu" in rec:
                 line["multi_gpu"] = rec["multi_gpu"]
@@ -607,7 +671,7 @@ def main():
         sub = {}
         if args.config == "all":
             # configs[2] on the same streams; at world > 1 this is configs[4]'s second option set, with its own scatter/gather record
-            r2, ok2 = pair_record("mixing")
+            r2, ok2 = pair_record("mixing", steps=sub_steps)
             r2 = dict(r2)
             r2.update({"workload": "BASELINE configs[2]: same streams, TestContextMixing: context map cm[i]=i&63, utf8, block type 1, dynamic_context_mixing=2 (BASELINE configs[2])",
                        "unit": "MB/s encode+decode"})
@@ -616,21 +680,20 @@ def main():
                 sub["mixing"]["cpu_baseline"] = cpu_baseline("mixing", workload, corpus, L)
         if world == 1 and args.config == "all" and args.diag_data == "corpus":
             # configs[1]'s options on input that is not English text: the same cut (stride 4099, 1 % perturbation) out of testdata/
-            # random_then_unicode (random bytes, then UTF-8 in several scripts), decoded with the tables in numeric byte order
-            # (divans_gpu_codec_set_byte_order: the text-frequency rank that is the default buys nothing on such input).
+            # random_then_unicode (random bytes, then UTF-8 in several scripts); the decoder's table order is learned from the data here as in the headline
             import lzma
             with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
                 rtu_t = torch.from_numpy(np.frombuffer(f.read(), dtype=np.uint8).copy()).to(dev)
             d_bin = device_blocks(torch, rtu_t, first, N, L)
-            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", byte_order=1)
+            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", steps=sub_steps)
             rb = dict(rb)
             rb.update({"workload": f"BASELINE configs[1] options on non-text input: {N} x {L} B streams cut from testdata/random_then_unicode (stride 4099, 1% perturbation: random bytes and multi-script "
-                                   "UTF-8), TestSimple options as the headline, decoder tables in numeric byte order (divans_gpu_codec_set_byte_order 1)", "unit": "MB/s encode+decode"})
+                                   "UTF-8), TestSimple options as the headline, the decoder's table order learned from this data like the headline's (byte_order)", "unit": "MB/s encode+decode"})
             sub["simple_binary"] = rb
             del d_bin
             torch.cuda.empty_cache()
         if world == 1 and args.config in ("all", "decode_only"):
-            sub["decode_only"] = run_decode_only(torch, da, po, args, dev)
+            sub["decode_only"] = run_decode_only(torch, da, po, args, dev, steps=sub_steps)
             if not args.no_cpu_baseline:
                 import lzma
                 with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:

@@ -82,7 +82,7 @@ class BatchTiming(ctypes.Structure):
 
 class TablePlacement(ctypes.Structure):
     _fields_ = [("policy_candidates", ctypes.c_uint32), ("tried", ctypes.c_uint32), ("first_ms", ctypes.c_float), ("best_ms", ctypes.c_float),
-                ("worst_ms", ctypes.c_float), ("kept_chunks", ctypes.c_uint32)]
+                ("worst_ms", ctypes.c_float), ("kept_chunks", ctypes.c_uint32), ("searching", ctypes.c_uint32)]
 
 
 class TableMemoryInfo(ctypes.Structure):
@@ -146,6 +146,7 @@ def load_library():
     L.divans_gpu_codec_set_geometry.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_set_split_cache.argtypes = [vp, u32, u32]
     L.divans_gpu_codec_tune_tables.argtypes = [vp, u32]
+    L.divans_gpu_codec_search_tables.argtypes = [vp, u32]
     L.divans_gpu_trim.argtypes = []; L.divans_gpu_trim.restype = None
     L.divans_gpu_codec_table_placement.argtypes = [vp, ctypes.POINTER(TablePlacement)]
     L.divans_gpu_table_memory.argtypes = [ctypes.POINTER(TableMemoryInfo)]
@@ -153,6 +154,8 @@ def load_library():
     L.divans_gpu_codec_set_decoder.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), u32]
     L.divans_gpu_codec_set_decoder.restype = ctypes.c_int
     L.divans_gpu_codec_set_byte_order.argtypes = [vp, u32]
+    L.divans_gpu_codec_byte_order.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), vp]
+    L.divans_gpu_codec_row_replay.argtypes = [vp, vp, vp, vp, u32, u32, ctypes.POINTER(ctypes.c_float)]
     L.divans_gpu_codec_set_rans_split.argtypes = [vp, u32]
     L.divans_gpu_experimental_decoders.argtypes = []; L.divans_gpu_experimental_decoders.restype = ctypes.c_int
     L.divans_gpu_codec_set_encode_path.argtypes = [vp, u32]
@@ -224,7 +227,7 @@ def exported_symbols():
         "divans_gpu_codec_destroy", "divans_gpu_last_error", "divans_gpu_lit_encode_bound",
         "divans_gpu_lit_encode_batch", "divans_gpu_lit_encode_packed", "divans_gpu_lit_decode_batch", "divans_gpu_pack_streams",
         "divans_gpu_lit_encode_host", "divans_gpu_lit_encode_host_chunks", "divans_gpu_lit_decode_host", "divans_gpu_codec_info",
-        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_codec_table_placement", "divans_gpu_table_memory", "divans_gpu_set_table_va_cap", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_experimental_decoders", "divans_gpu_codec_set_byte_order", "divans_gpu_codec_set_rans_split", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
+        "divans_gpu_codec_set_geometry", "divans_gpu_codec_set_split_cache", "divans_gpu_codec_tune_tables", "divans_gpu_codec_search_tables", "divans_gpu_codec_table_placement", "divans_gpu_table_memory", "divans_gpu_set_table_va_cap", "divans_gpu_trim", "divans_gpu_codec_set_decoder", "divans_gpu_experimental_decoders", "divans_gpu_codec_set_byte_order", "divans_gpu_codec_byte_order", "divans_gpu_codec_row_replay", "divans_gpu_codec_set_rans_split", "divans_gpu_codec_set_encode_path", "divans_gpu_codec_set_bucket_batch", "divans_gpu_lit_model_batch",
         "divans_gpu_selftest_division", "divans_gpu_speed_supported", "divans_gpu_speed_accepted", "divans_gpu_codec_status", "divans_gpu_codec_clear_status", "divans_gpu_codec_status_async", "divans_gpu_codec_last_decode_kernel", "divans_gpu_codec_set_stream_flags", "divans_gpu_codec_set_block_types",
         "divans_gpu_lit_encode_segments_batch", "divans_gpu_lit_decode_segments_batch",
         "divans_gpu_selftest_cdf_ops", "divans_gpu_selftest_rans_pairs", "divans_gpu_lit_encode_batch_chunks",
@@ -412,20 +415,42 @@ class LiteralCodec:
         _check(self._lib.divans_gpu_codec_set_rans_split(self._h, int(mode)), "set_rans_split")
 
     def set_byte_order(self, order):
-        """0 = the stride-1 tables lay the previous byte's rows out by a text-frequency rank (default), 1 = numerically (non-text input)"""
+        """order of the previous byte's rows in the stride-1 decoder's tables: 0 = learned from the codec's own data (default), 1 = numeric,
+        2 = the fixed English-text rank (a hint)"""
         _check(self._lib.divans_gpu_codec_set_byte_order(self._h, int(order)), "set_byte_order")
+
+    def byte_order(self, with_rank=False):
+        """dict(mode, ready[, rank]): divans_gpu_codec_byte_order"""
+        mode = ctypes.c_uint32(); ready = ctypes.c_uint32()
+        rank = (ctypes.c_uint8 * 256)() if with_rank else None
+        _check(self._lib.divans_gpu_codec_byte_order(self._h, ctypes.byref(mode), ctypes.byref(ready), rank), "byte_order")
+        d = {"mode": int(mode.value), "ready": bool(ready.value)}
+        if with_rank:
+            d["rank"] = list(rank)
+        return d
+
+    def row_replay(self, d_literals, n_streams, stream_len, offsets=None, sizes=None):
+        """divans_gpu_codec_row_replay: ms the batch's CDF-row traffic takes by itself (device tensor of literal bytes)"""
+        ms = ctypes.c_float()
+        _check(self._lib.divans_gpu_codec_row_replay(self._h, d_literals.data_ptr(), offsets.data_ptr() if offsets is not None else None,
+                                                     sizes.data_ptr() if sizes is not None else None, int(n_streams), int(stream_len), ctypes.byref(ms)), "row_replay")
+        return float(ms.value)
 
     def tune_tables(self, candidates=3):
         """The next decode_batch call that fills the persistent grid runs on up to `candidates` differently placed copies of the CDF
         tables and keeps the fastest placement (divans_gpu_codec_tune_tables; 0 = the library's policy, 1 = off)."""
         _check(self._lib.divans_gpu_codec_tune_tables(self._h, int(candidates)), "tune_tables")
 
+    def search_tables(self, candidates=0):
+        """The call-by-call placement search with `candidates` placements, one per qualifying decode_batch call (divans_gpu_codec_search_tables)"""
+        _check(self._lib.divans_gpu_codec_search_tables(self._h, int(candidates)), "search_tables")
+
     def table_placement(self):
         """what the placement tuning saw: dict(policy_candidates, tried, first_ms, best_ms, worst_ms, kept_chunks)"""
         t = TablePlacement()
         _check(self._lib.divans_gpu_codec_table_placement(self._h, ctypes.byref(t)), "table_placement")
         return {"policy_candidates": t.policy_candidates, "tried": t.tried, "first_ms": round(t.first_ms, 3), "best_ms": round(t.best_ms, 3),
-                "worst_ms": round(t.worst_ms, 3), "kept": "chunks" if t.kept_chunks else "one block"}
+                "worst_ms": round(t.worst_ms, 3), "kept": "chunks" if t.kept_chunks else "one block", "searching": bool(t.searching)}
 
     def set_split_cache(self, high_rows, low_rows):
         _check(self._lib.divans_gpu_codec_set_split_cache(self._h, int(high_rows), int(low_rows)), "set_split_cache")

@@ -262,6 +262,9 @@ struct Lane {
             divans_gpu_codec* c = nullptr;
             const int rc = divans_gpu_codec_create(&c, &cfg, device, stream, bound);
             if (rc) return rc;
+            // a lane's codec is never placement-tuned, whatever its configuration's table size: the search would hold a second copy of
+            // the tables per lane and compare launches of slices that differ from call to call
+            (void)divans_gpu_codec_tune_tables(c, 1);
             divans_gpu_info info;
             if (divans_gpu_codec_info(c, &info)) { divans_gpu_codec_destroy(c); return DIVANS_GPU_EHIP; }
             it = codecs.emplace(key, Entry{c, info.blocks, info.blocks, 0}).first;

@@ -15,6 +15,7 @@
 
 #include "../../include/divans_gpu.h"
 #include "lit_kernels.h"
+#include "lit_device.h"      // BytePerm (host side: the English-text hint of divans_gpu_codec_set_byte_order)
 
 using namespace divans_hip;
 
@@ -139,10 +140,25 @@ struct divans_gpu_codec {
     uint8_t* d_blob = nullptr;
     int16_t* d_tables = nullptr;  size_t tables_bytes = 0;
     TableMem tm;                          // what d_tables points into (table_alloc)
-    uint32_t byte_order = 0;       // divans_gpu_codec_set_byte_order
+    uint32_t byte_order = 0;       // divans_gpu_codec_set_byte_order: 0 learned from the codec's own data, 1 numeric, 2 the English-text hint
+    uint8_t* d_rank = nullptr;     // [256] rank of every byte value in that order (device); what LitBatch::byte_rank points at once rank_ready
+    bool rank_ready = false;       // d_rank holds a permutation (in stream order: the launch that fills it is enqueued before any that reads it)
     uint32_t rans_split = 0;       // divans_gpu_codec_set_rans_split
-    uint32_t table_candidates = 0; bool tables_tuned = false;   // divans_gpu_codec_tune_tables: 0 = the library's policy (table_candidates_of)
-    divans_gpu_table_placement placement = {0u, 0u, 0.f, 0.f, 0.f, 0u};   // what the tuning saw (divans_gpu_codec_table_placement)
+    uint32_t table_candidates = 0; bool tables_tuned = false;   // divans_gpu_codec_tune_tables / _search_tables: 0 = the library's policy (table_candidates_of)
+    bool eager_tune = false;                                    // divans_gpu_codec_tune_tables(c, k >= 2): every placement on the first qualifying call
+    divans_gpu_table_placement placement = {0u, 0u, 0.f, 0.f, 0.f, 0u, 0u};   // what the tuning saw (divans_gpu_codec_table_placement)
+    // The library's own placement policy explores ACROSS calls (placement_step): every qualifying decode call runs on one placement -- a new
+    // candidate or the best so far -- and the call after it reads that launch's time.  `best_tm` holds the best placement while c->tm is a
+    // candidate under test (empty: c->tm is the best); two copies alive at most.
+    struct PlacementSearch {
+        bool active = false, pending = false;       // pending: the launch of the previous qualifying call is the measurement in flight
+        uint32_t sig_streams = 0, sig_len = 0;      // only calls of this shape are compared with each other
+        TableMem best_tm;
+        float best_ms = 0.f, worst_ms = 0.f;
+        hipEvent_t e0 = nullptr, e1 = nullptr;      // around the measured launch (ev[3] / ev[4] are re-recorded by every decode call)
+        uint64_t seq_at_measure = 0;                // table_launch_seq right after the measured launch
+    } ps;
+    uint64_t table_launch_seq = 0;                  // launches that read or write the CDF tables (may a placement be freed without a stream sync?)
     uint32_t* d_sf = nullptr;     size_t sf_bytes = 0;
     uint32_t* d_status = nullptr;
     // bucketed encoder model pass (lit_bucket.hip)
@@ -396,7 +412,10 @@ static hipError_t device_alloc(void** p, size_t bytes) {
     return e;
 }
 
-static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, bool shuffle, TableMem& t) {
+// *over_cap: nothing was tried because the address-space budget (g_va_cap) is spent -- not an out-of-memory condition: the caller goes
+// straight to one hipMalloc block and leaves the pool's idle ranges alone
+static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, bool shuffle, TableMem& t, bool* over_cap) {
+    *over_cap = false;
     hipMemAllocationProp prop;
     std::memset(&prop, 0, sizeof(prop));
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
@@ -406,11 +425,13 @@ static hipError_t table_alloc_chunks(int device, size_t need, size_t chunk_mib, 
     size_t chunk = std::max<size_t>(gran, chunk_mib << 20);
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t n = (need + chunk - 1) / chunk;
-    if (g_va_reserved.load() + n * chunk > g_va_cap.load()) return hipErrorOutOfMemory;     // the caller falls back to one hipMalloc block
+    // the budget is taken before the reservation (callers on several devices run concurrently) and handed back if there is none to keep
+    const uint64_t want_va = (uint64_t)n * chunk;
+    if (g_va_reserved.fetch_add(want_va) + want_va > g_va_cap.load()) { g_va_reserved.fetch_sub(want_va); *over_cap = true; return hipErrorOutOfMemory; }
     void* va = nullptr;
     e = hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0);
-    if (e != hipSuccess) return e;
-    g_va_reserved += n * chunk;      // from here on the range is never returned, whether the mapping below succeeds or not
+    if (e != hipSuccess) { g_va_reserved.fetch_sub(want_va); return e; }
+    // from here on the range is never returned, whether the mapping below succeeds or not
     std::vector<hipMemGenericAllocationHandle_t> hs;
     for (size_t i = 0; i < n && e == hipSuccess; ++i) {
         hipMemGenericAllocationHandle_t h;
@@ -472,8 +493,9 @@ static hipError_t table_alloc(int device, size_t need, TableMem& t, bool fresh =
                 return hipSuccess;
             }
         }
-        e = table_alloc_chunks(device, need, mib ? mib : 32, std::strcmp(tail, "noshuffle") != 0, t);
-        if (e != hipSuccess) { table_pool_drop(device); e = table_alloc_chunks(device, need, mib ? mib : 32, std::strcmp(tail, "noshuffle") != 0, t); }   // out of memory: the idle ranges first
+        bool over_cap = false;
+        e = table_alloc_chunks(device, need, mib ? mib : 32, std::strcmp(tail, "noshuffle") != 0, t, &over_cap);
+        if (e != hipSuccess && !over_cap) { table_pool_drop(device); e = table_alloc_chunks(device, need, mib ? mib : 32, std::strcmp(tail, "noshuffle") != 0, t, &over_cap); }   // out of memory: the idle ranges first
     } else if (mode[0] == 'c') {
         e = hipExtMallocWithFlags((void**)&t.p, need, hipDeviceMallocContiguous);
         if (e != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; }
@@ -483,7 +505,11 @@ static hipError_t table_alloc(int device, size_t need, TableMem& t, bool fresh =
     return e;
 }
 
-static void free_tables(divans_gpu_codec* c) { table_free(c->tm); c->d_tables = nullptr; c->tables_bytes = 0; c->tables_tuned = false; }
+static void free_tables(divans_gpu_codec* c) {     // (callers have synchronised the stream when kernels may still use the tables)
+    table_free(c->tm); c->d_tables = nullptr; c->tables_bytes = 0; c->tables_tuned = false;
+    table_free(c->ps.best_tm, false);
+    c->ps.active = c->ps.pending = false;
+}
 
 static int ensure_tables(divans_gpu_codec* c) {
     // big geometries (many context columns / planes) shrink the persistent grid instead of asking for hundreds of GB:
@@ -582,6 +608,9 @@ extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_
     configure_from_geometry(c);
     hipError_t he = hipMalloc(&c->d_blob, LIT_BLOB_MAX_BYTES);
     if (he == hipSuccess) he = hipMalloc(&c->d_status, 64);
+    if (he == hipSuccess) he = hipMalloc(&c->d_rank, 256);
+    if (he == hipSuccess) he = hipEventCreate(&c->ps.e0);
+    if (he == hipSuccess) he = hipEventCreate(&c->ps.e1);
     if (he != hipSuccess) { divans_gpu_codec_destroy(c); return fail(DIVANS_GPU_ENOMEM, "hipMalloc(config) failed"); }
     if (he == hipSuccess) he = hipMemcpy(c->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemset(c->d_status, 0, 64);
@@ -607,6 +636,9 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
     if (c->d_wstate) (void)hipFree(c->d_wstate);
     for (void* q : c->host_scratch) if (q) (void)hipFree(q);
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_rank) (void)hipFree(c->d_rank);
+    if (c->ps.e0) (void)hipEventDestroy(c->ps.e0);
+    if (c->ps.e1) (void)hipEventDestroy(c->ps.e1);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_rans) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_in) if (e) (void)hipEventDestroy(e);
@@ -750,7 +782,6 @@ extern "C" int divans_gpu_codec_set_decoder(divans_gpu_codec* c, uint32_t genera
 // (dm_auto) and whether a later set_block_types keeps the geometry (user_geometry) stay as they were
 static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint32_t rows[4], const uint32_t shifts[4], uint32_t blocks, bool by_user) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    if (by_user) c->user_geometry = true;
     if (generation < 1u || generation > 4u) return fail(DIVANS_GPU_EINVAL, "decoder generation must be 1, 2 (second generation, direct-mapped caches), 3 (second generation, 2-way caches) or 4 (one lane per stream)");
     HIP_TRY(hipSetDevice(c->device));
 #if !DIVANS_WITH_EXPERIMENTAL_DECODERS
@@ -758,7 +789,9 @@ static int set_decoder_impl(divans_gpu_codec* c, uint32_t generation, const uint
     // speeds and of the call-by-call interface, where the library selects it by itself
     if (generation == 4u || (generation == 1u && by_user))
         return fail(DIVANS_GPU_EINVAL, "decoder generations 1 and 4 are experiment builds (DIVANS_WITH_EXPERIMENTAL_DECODERS=1 python divans_amd/build.py --force)");
+    if (by_user) c->user_geometry = true;        // (only a call that is accepted changes the codec)
 #else
+    if (by_user) c->user_geometry = true;
     if (generation == 4u) {
         // lit_decode_t.hip: rows[i] slots of the four direct-mapped per-stream caches (0 = one slot, the staging buffer the kernel needs anyway)
         if (c->geom.wrap_check) return fail(DIVANS_GPU_EINVAL, "generation 4 does not run speeds whose row totals leave i16");
@@ -833,8 +866,39 @@ extern "C" int divans_gpu_codec_set_rans_split(divans_gpu_codec* c, uint32_t mod
 
 extern "C" int divans_gpu_codec_set_byte_order(divans_gpu_codec* c, uint32_t order) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
-    if (order > 1u) return fail(DIVANS_GPU_EINVAL, "byte order must be 0 (text-frequency rank) or 1 (numeric)");
+    if (order > 2u) return fail(DIVANS_GPU_EINVAL, "byte order must be 0 (learned from the codec's data), 1 (numeric) or 2 (English-text hint)");
+    HIP_TRY(hipSetDevice(c->device));
     c->byte_order = order;
+    c->rank_ready = false;             // 0: learn again from the next batch
+    if (order == 2u) {
+        static const BytePerm kTextOrder{};
+        HIP_TRY(hipMemcpyAsync(c->d_rank, kTextOrder.rank, 256, hipMemcpyHostToDevice, c->stream));
+        c->rank_ready = true;
+    }
+    return 0;
+}
+
+extern "C" int divans_gpu_codec_byte_order(divans_gpu_codec* c, uint32_t* mode, uint32_t* ready, uint8_t* rank256) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (mode) *mode = c->byte_order;
+    if (ready) *ready = (c->byte_order != 1u && c->rank_ready) ? 1u : 0u;
+    if (rank256) {
+        if (c->byte_order != 1u && c->rank_ready) {
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipMemcpyAsync(rank256, c->d_rank, 256, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        } else for (int i = 0; i < 256; ++i) rank256[i] = (uint8_t)i;
+    }
+    return 0;
+}
+
+// Order 0: the first batch the codec sees -- the literal bytes an encode call is given, or the bytes a decode call produced -- is sampled
+// (64 streams spread over the batch, their first 2 KiB) and the byte values are ranked by frequency; launches enqueued after that index
+// the stride-1 tables by the rank.  Nothing is synchronised and nothing is ever read back: the order is a private layout of each launch.
+static int maybe_learn_rank(divans_gpu_codec* c, const uint8_t* d_data, const uint64_t* d_offsets, const uint32_t* d_sizes, uint32_t n_streams, uint32_t stream_len) {
+    if (c->byte_order != 0u || c->rank_ready || !c->d_rank || n_streams == 0u || c->geom.mm_uniform != 4) return 0;
+    HIP_TRY(launch_learn_byte_rank(d_data, d_offsets, d_sizes, n_streams, stream_len, 64u, 2048u, c->d_rank, c->stream));
+    c->rank_ready = true;
     return 0;
 }
 
@@ -842,23 +906,38 @@ extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t candid
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (candidates > 16u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [0, 16] (0 = the library's policy, 1 = off)");
     c->table_candidates = candidates;
+    c->eager_tune = candidates >= 2u;
     c->tables_tuned = false;
     return 0;
 }
 
-// The one placement policy: tables of 2 GiB and more -- the persistent grids of whole-GPU batches, where a slow placement
-// costs 10-20 % of every later decode -- are tried on up to kDefaultTableCandidates placements by the first decode that fills half the grid;
-// smaller tables (the lanes of divans_batch_*, tests) are not tuned.  bench.py measures what this gives a plain divans_gpu_codec_create caller.
+extern "C" int divans_gpu_codec_search_tables(divans_gpu_codec* c, uint32_t candidates) {
+    if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
+    if (candidates > 16u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [0, 16] (0 = the library's policy, 1 = off)");
+    c->table_candidates = candidates;
+    c->eager_tune = false;
+    c->tables_tuned = false;
+    return 0;
+}
+
+// The one placement policy: tables of 2 GiB and more -- the persistent grids of whole-GPU batches, where a
+// slow placement costs 10-20 % of every later decode -- are tried on up to kDefaultTableCandidates placements, ONE PER CALL: each of the
+// codec's first decode calls that fill half the grid runs on one placement and the next such call reads its time (placement_step), so no
+// call decodes twice and the first one costs what every later one costs.  divans_gpu_codec_tune_tables(c, k >= 2) is the eager form: all
+// k on the first such call.  Smaller tables (tests) are not tuned, and the lanes of divans_batch_* switch it off.
 constexpr uint32_t kDefaultTableCandidates = 12u;
 static uint32_t table_candidates_of(const divans_gpu_codec* c) {
     if (c->table_candidates) return c->table_candidates;
-    return c->tm.bytes >= ((size_t)2 << 30) ? kDefaultTableCandidates : 1u;
+    // (before the tables exist: the size they will have)
+    const size_t bytes = c->tm.bytes ? c->tm.bytes : (size_t)resident_groups(c) * c->geom.total_rows * 32u;
+    return bytes >= ((size_t)2 << 30) ? kDefaultTableCandidates : 1u;
 }
 
 extern "C" int divans_gpu_codec_table_placement(divans_gpu_codec* c, divans_gpu_table_placement* out) {
     if (!c || !out) return fail(DIVANS_GPU_EINVAL, "null argument");
     *out = c->placement;
     out->policy_candidates = table_candidates_of(c);
+    out->searching = (c->ps.active && !c->tables_tuned) ? 1u : 0u;
     return 0;
 }
 
@@ -926,7 +1005,8 @@ extern "C" size_t divans_gpu_lit_encode_bound(size_t n) {
 template <class After>
 static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets, const uint32_t* d_in_sizes,
                       uint32_t stream_len, uint32_t n_streams, const uint32_t* d_seg_begin, const divans_lit_segment* d_segs, After&& after) {
-    int rc = 0;
+    int rc = maybe_learn_rank(c, d_in, d_in_offsets, d_in_sizes, n_streams, stream_len);     // byte order 0: the decoder's table order follows the data the codec sees
+    if (rc) return rc;
     SfView view;
     if (use_bucket(c) && n_streams < (1u << 24) && !d_segs) {   // segment lists (context reloads between Literal commands) go through the streaming kernels
         BucketBatch k;
@@ -990,6 +1070,7 @@ static int model_pass(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* 
     set_cache_fields(c, b);
     if (d_segs && b.cache_mode != 2u && b.cache_mode != 0u) return fail(DIVANS_GPU_EINVAL, "segment lists need the default (high-nibble-row) cache or none");
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    ++c->table_launch_seq;
     HIP_TRY(launch_model_encode(b, c->mix, c->blocks, c->stream));
     view.sf = c->d_sf; view.stride = 2u * c->max_stream_len;
     return after(0u, n_streams, view);
@@ -1172,6 +1253,84 @@ extern "C" int divans_gpu_lit_decode_segments_batch(divans_gpu_codec* c, const u
     return decode_batch_impl(c, d_in, d_in_offsets, d_in_sizes, n_streams, d_out, d_out_offsets, d_out_sizes, stream_len, d_seg_begin, d_segs);
 }
 
+// Cache organisation and grid of lit_decode2_kernel for a batch of n_streams (also what divans_gpu_codec_row_replay launches with)
+static void decode2_shape(divans_gpu_codec* c, uint32_t n_streams, bool segs, LitBatch& b, uint32_t& grid) {
+    b.dm_log2 = lit_decode2_effective_caches(c->dm_log2, c->mix, segs); b.dm_shift = c->dm_shift;
+    // A batch that is resident all at once runs at the latency of a stream's dependency chain, and the direct-mapped lookup is
+    // the shorter chain (16 384 streams: 60.3 vs 63.5 ms, mixing 138 vs 142); only a batch that keeps the grid busy for several
+    // rounds gains from the 2-way sets' fewer misses (profiles/r03c_small_batch_geometry.txt)
+    grid = c->blocks2;
+    if (c->dm_auto && n_streams <= c->blocks2 * groups_per_block(c)) {
+        b.dm_shift &= 0x7fffffffu;
+        // ... and such a batch leaves LDS unused that shortens the chain further: the largest high-row caches under which every
+        // stream is still resident at once (profiles/r04c_small_batch_caches.txt: 16 384 streams 60.1 -> 54.2 ms with 64 instead of
+        // 32 high rows, 8192: 44.5 -> 40.4; mixing 20 480 streams 162.8 -> 152.5 ms with 32 + 16, 16 384: 134.4 -> 123.4 with 32 + 32;
+        // low-row caches do not pay even there)
+        if (!segs && c->geom.total_rows < 0x7fffu) {
+            const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
+            const uint32_t fixed = 256u + (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
+            const uint32_t mix_cands[2] = {6u | (6u << 8), 6u | (5u << 8)};      // (log2 rows + 1) per table: high stride | FirstNibble << 8
+            const uint32_t plain_cands[1] = {7u};
+            const uint32_t* cands = c->mix ? mix_cands : plain_cands;
+            for (uint32_t i = 0; i < (c->mix ? 2u : 1u); ++i) {
+                const uint32_t lg = lit_decode2_effective_caches(cands[i], c->mix, false);
+                const uint32_t per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(lg) + fixed;
+                const uint32_t fit = std::min(8u, (160u * 1024u) / per_wg);
+                if (lg == cands[i] && (uint64_t)n_streams <= (uint64_t)c->num_cus * fit * groups_per_block(c)) { b.dm_log2 = lg; break; }
+            }
+        }
+        grid = std::min(grid, (n_streams + groups_per_block(c) - 1u) / groups_per_block(c));
+    }
+    b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
+}
+
+static void placement_finish(divans_gpu_codec* c) {
+    c->placement.best_ms = c->ps.best_ms; c->placement.worst_ms = c->ps.worst_ms; c->placement.kept_chunks = c->tm.chunks.empty() ? 0u : 1u;
+    c->tables_tuned = true; c->ps.active = false; c->ps.pending = false;
+}
+
+// One step of the library's placement search, run by a qualifying decode call BEFORE its launch.  Reads the time of the previous
+// qualifying call's launch (the one wait of the search: for a launch of an EARLIER call -- this call's own launch is never waited for),
+// keeps the faster of {best so far, that candidate}, gives the loser's memory back and maps the next candidate for this call's launch;
+// after the last candidate the best stays for good.  *measure: this call's launch is a measurement (the caller records ps.e0 / ps.e1).
+static int placement_step(divans_gpu_codec* c, uint32_t want, uint32_t n_streams, uint32_t stream_len, bool* measure) {
+    auto& ps = c->ps;
+    *measure = false;
+    if (!ps.active) {        // the first qualifying call: the tables as ensure_tables allocated them are placement 0
+        ps.active = true; ps.pending = false; ps.sig_streams = n_streams; ps.sig_len = stream_len;
+        ps.best_ms = ps.worst_ms = 0.f;
+        c->placement = {0u, 0u, 0.f, 0.f, 0.f, 0u, 0u};
+        *measure = true;
+        return 0;
+    }
+    if (n_streams != ps.sig_streams || stream_len != ps.sig_len) return 0;      // another shape: decoded on the placement in use, not compared
+    if (ps.pending) {
+        float t = 0.f;
+        HIP_TRY(hipEventSynchronize(ps.e1));
+        HIP_TRY(hipEventElapsedTime(&t, ps.e0, ps.e1));
+        ps.pending = false;
+        // a table is only given back once nothing enqueued can touch it: the measured launch is complete; anything enqueued on the tables
+        // after it (decode calls of other shapes, streaming encoder passes) is waited for
+        if (c->table_launch_seq != ps.seq_at_measure) HIP_TRY(hipStreamSynchronize(c->stream));
+        const bool first = c->placement.tried == 0u;
+        if (first) c->placement.first_ms = t;
+        ++c->placement.tried;
+        ps.worst_ms = first ? t : std::max(ps.worst_ms, t);
+        if (first || t < ps.best_ms) { ps.best_ms = t; table_free(ps.best_tm, false); }
+        else { table_free(c->tm, false); c->tm = std::move(ps.best_tm); ps.best_tm = TableMem(); c->d_tables = c->tm.p; }
+        c->placement.best_ms = ps.best_ms; c->placement.worst_ms = ps.worst_ms;
+    }
+    if (c->placement.tried >= want) { placement_finish(c); return 0; }
+    TableMem cand;
+    // alternately one hipMalloc block and chunks mapped side by side: which kind is faster differs from box to box
+    if (table_alloc(c->device, c->tm.bytes, cand, true, (c->placement.tried & 1u) != 0u) != hipSuccess) { (void)hipGetLastError(); placement_finish(c); return 0; }   // no room for a second copy
+    ps.best_tm = std::move(c->tm);
+    c->tm = std::move(cand);
+    c->d_tables = c->tm.p;
+    *measure = true;
+    return 0;
+}
+
 static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uint64_t* d_in_offsets,
                              const uint32_t* d_in_sizes, uint32_t n_streams, uint8_t* d_out,
                              const uint64_t* d_out_offsets, const uint32_t* d_out_sizes, uint32_t stream_len,
@@ -1182,6 +1341,15 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     if (stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "stream_len exceeds the codec's max_stream_len");
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_tables(c); if (rc) return rc;
+    // The table placements are compared on launches that differ in nothing else: the byte order is settled first (order 0 learns it from
+    // the first batch -- an earlier encode call's input or this call's output)
+    const bool order_settled = !(c->byte_order == 0u && !c->rank_ready && c->geom.mm_uniform == 4);
+    const uint32_t want = table_candidates_of(c);
+    const bool qualifies = want > 1u && !c->tables_tuned && 2u * (uint64_t)n_streams >= resident_groups(c) && order_settled &&
+                           !c->sp_started && !c->sd_started;      // (a stream coded call by call keeps its state IN the tables)
+    const bool eager = c->eager_tune;                   // divans_gpu_codec_tune_tables(c, k >= 2): every placement on this call
+    bool measure = false;
+    if (qualifies && !eager) { rc = placement_step(c, want, n_streams, stream_len, &measure); if (rc) return rc; }
     LitBatch b;
     std::memset(&b, 0, sizeof(b));
     b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
@@ -1190,7 +1358,7 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
     b.out = d_out; b.out_offsets = d_out_offsets; b.out_sizes = d_out_sizes; b.status = c->d_status;
     b.stream_bad = c->d_stream_flags;
     b.seg_begin = d_seg_begin; b.segs = (const LitSegment*)d_segs;
-    b.byte_order = c->byte_order;
+    b.byte_rank = (c->byte_order != 1u && c->rank_ready) ? c->d_rank : nullptr;
     set_cache_fields(c, b);
 #if !DIVANS_WITH_EXPERIMENTAL_DECODERS
     if (!use_decode2(c) && (b.cache_mode == 1u || b.cache_mode == 3u)) {     // the generation-1 fallback of this build knows the high-row cache or none
@@ -1209,38 +1377,10 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         c->last_decode_grid = std::min(c->blocks_t, (n_streams + 63u) / 64u);
     } else
 #endif
-    if (use_decode2(c)) {
-        b.dm_log2 = lit_decode2_effective_caches(c->dm_log2, c->mix, d_segs != nullptr); b.dm_shift = c->dm_shift;
-        // A batch that is resident all at once runs at the latency of a stream's dependency chain, and the direct-mapped lookup is
-        // the shorter chain (16 384 streams: 60.3 vs 63.5 ms, mixing 138 vs 142); only a batch that keeps the grid busy for several
-        // rounds gains from the 2-way sets' fewer misses (profiles/r03c_small_batch_geometry.txt)
-        uint32_t grid = c->blocks2;
-        if (c->dm_auto && n_streams <= c->blocks2 * groups_per_block(c)) {
-            b.dm_shift &= 0x7fffffffu;
-            // ... and such a batch leaves LDS unused that shortens the chain further: the largest high-row caches under which every
-            // stream is still resident at once (profiles/r04c_small_batch_caches.txt: 16 384 streams 60.1 -> 54.2 ms with 64 instead of
-            // 32 high rows, 8192: 44.5 -> 40.4; mixing 20 480 streams 162.8 -> 152.5 ms with 32 + 16, 16 384: 134.4 -> 123.4 with 32 + 32;
-            // low-row caches do not pay even there)
-            if (!d_segs && c->geom.total_rows < 0x7fffu) {
-                const bool mask_in_lds = !(c->geom.mm_uniform == 0 || c->geom.mm_uniform == 4);
-                const uint32_t fixed = 256u + (c->geom.ctx_const < 0 ? LIT_BLOB_CTXF + LIT_CTXF_BYTES * c->geom.n_btypes : 0u) + (mask_in_lds ? 8192u : 0u);
-                const uint32_t mix_cands[2] = {6u | (6u << 8), 6u | (5u << 8)};      // (log2 rows + 1) per table: high stride | FirstNibble << 8
-                const uint32_t plain_cands[1] = {7u};
-                const uint32_t* cands = c->mix ? mix_cands : plain_cands;
-                for (uint32_t i = 0; i < (c->mix ? 2u : 1u); ++i) {
-                    const uint32_t lg = lit_decode2_effective_caches(cands[i], c->mix, false);
-                    const uint32_t per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(lg) + fixed;
-                    const uint32_t fit = std::min(8u, (160u * 1024u) / per_wg);
-                    if (lg == cands[i] && (uint64_t)n_streams <= (uint64_t)c->num_cus * fit * groups_per_block(c)) { b.dm_log2 = lg; break; }
-                }
-            }
-            grid = std::min(grid, (n_streams + groups_per_block(c) - 1u) / groups_per_block(c));
-        }
-        b.cache_bytes_per_wg = (LIT_THREADS / 16) * lit_decode2_stream_lds(b.dm_log2);
-        c->last_decode_grid = grid;
-    }
+    if (use_decode2(c)) decode2_shape(c, n_streams, d_segs != nullptr, b, c->last_decode_grid);
     auto launch = [&]() -> int {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        ++c->table_launch_seq;
 #if DIVANS_WITH_EXPERIMENTAL_DECODERS
         if (transposed) { lit_decode_t_kernel_name(b, c->mix, c->last_decode_kernel, sizeof(c->last_decode_kernel)); HIP_TRY(launch_decode_t(b, c->mix, c->last_decode_grid, c->stream)); }
         else
@@ -1250,20 +1390,22 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         HIP_TRY(hipEventRecord(c->ev[4], c->stream));
         return 0;
     };
+    if (measure) HIP_TRY(hipEventRecord(c->ps.e0, c->stream));
     rc = launch(); if (rc) return rc;
-    // divans_gpu_codec_tune_tables / the library's policy: the first batch that fills at least half the grid is decoded once per candidate placement
-    // of the tables (the same bytes come out every time) and the fastest placement stays.  Two copies of the tables are alive at most -- the best so
-    // far and the candidate under test; a rejected one gives its memory back before the next is allocated.  (Stopping at the first placement
+    if (measure) { HIP_TRY(hipEventRecord(c->ps.e1, c->stream)); c->ps.pending = true; c->ps.seq_at_measure = c->table_launch_seq; }
+    if (!order_settled) { rc = maybe_learn_rank(c, d_out, d_out_offsets, d_out_sizes, n_streams, stream_len); if (rc) return rc; }
+    // divans_gpu_codec_tune_tables(c, k >= 2), the eager form: this batch is decoded once per candidate placement of the tables (the same
+    // bytes come out every time) and the fastest placement stays.  Two copies of the tables are alive at most -- the best so far and the
+    // candidate under test; a rejected one gives its memory back before the next is allocated.  (Stopping at the first placement
     // that is 5 % ahead of the slowest seen was tried and costs the mixing configurations 5 %: their times spread over three clusters, and a very
     // slow placement ends the search on a middling one -- profiles/r05a_bench_line_early_stop.json: 436.6 ms kept after 4, best of 12 is 415.)
-    // This path synchronises the stream (the call is otherwise asynchronous); it runs once per codec.
-    const uint32_t want = table_candidates_of(c);
-    if (want > 1u && !c->tables_tuned && 2u * (uint64_t)n_streams >= resident_groups(c)) {
+    // This path synchronises the stream and decodes k times; the library's own policy (placement_step) does neither.
+    if (qualifies && eager) {
         float best = 0.f;
         HIP_TRY(hipEventSynchronize(c->ev[4]));
         HIP_TRY(hipEventElapsedTime(&best, c->ev[3], c->ev[4]));
         float worst = best;
-        c->placement.first_ms = best; c->placement.tried = 1u;
+        c->placement = {0u, 1u, best, 0.f, 0.f, 0u, 0u};
         for (uint32_t k = 1; k < want; ++k) {
             TableMem cand;
             if (table_alloc(c->device, c->tm.bytes, cand, true, (k & 1u) != 0u) != hipSuccess) { (void)hipGetLastError(); break; }     // no room for a second copy: keep what we have
@@ -1276,6 +1418,7 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
             if (rc || t >= best) { std::swap(c->tm, cand); c->d_tables = c->tm.p; b.tables = c->d_tables; }    // the earlier one stays
             else best = t;
             if (!rc) { worst = std::max(worst, t); ++c->placement.tried; }
+            if (rc) (void)hipStreamSynchronize(c->stream);      // a launch that failed half way may still be running on the candidate
             table_free(cand, false);      // the loser's memory goes back now (its address range stays reserved: the remap defect)
             if (rc) break;
         }
@@ -1286,6 +1429,36 @@ static int decode_batch_impl(divans_gpu_codec* c, const uint8_t* d_in, const uin
         return 0;       // (the events hold the last candidate's time; last_decode_ms the kept one's)
     }
     c->timing_pending_dec = true;
+    return 0;
+}
+
+// The memory side's own time for a batch's row traffic (launch_row_replay, lit_kernels.h): the literal bytes are given, every row the
+// decoder of this configuration touches is read, blended and written back through the same caches, table layout, byte order and grid
+// as divans_gpu_lit_decode_batch would use for the batch -- no entropy decoding, nothing that makes a byte wait for the one before it.
+// A measurement aid (bench.py's roofline.request_ceiling), synchronous; stride-1 configurations without segment lists.
+extern "C" int divans_gpu_codec_row_replay(divans_gpu_codec* c, const uint8_t* d_literals, const uint64_t* d_offsets, const uint32_t* d_sizes,
+                                           uint32_t n_streams, uint32_t stream_len, float* ms) {
+    if (!c || !d_literals || !ms) return fail(DIVANS_GPU_EINVAL, "null argument");
+    if ((d_offsets == nullptr) != (d_sizes == nullptr)) return fail(DIVANS_GPU_EINVAL, "offsets and sizes go together");
+    if (n_streams == 0 || stream_len > c->max_stream_len) return fail(DIVANS_GPU_EINVAL, "bad batch shape");
+    if (!use_decode2(c) || c->geom.mm_uniform != 4) return fail(DIVANS_GPU_EINVAL, "row replay exists for the stride-1 configurations of the second-generation decoder");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_tables(c); if (rc) return rc;
+    LitBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.blob = c->d_blob; b.geom = c->geom; b.tables = c->d_tables;
+    b.n_streams = n_streams; b.stream_len = stream_len; b.max_stream_len = c->max_stream_len;
+    b.in = d_literals; b.in_offsets = d_offsets; b.in_sizes = d_sizes;
+    b.byte_rank = (c->byte_order != 1u && c->rank_ready) ? c->d_rank : nullptr;
+    uint32_t grid = 0;
+    decode2_shape(c, n_streams, false, b, grid);
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    ++c->table_launch_seq;
+    if (launch_row_replay(b, c->mix, grid, c->stream) != hipSuccess) { (void)hipGetLastError(); return fail(DIVANS_GPU_EINVAL, "no row-replay instance for this cache organisation"); }
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev[4]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev[3], c->ev[4]));
+    c->timing_pending_dec = false;
     return 0;
 }
 
@@ -1552,6 +1725,7 @@ extern "C" int divans_gpu_lit_stream_encode(divans_gpu_codec* c, const uint8_t* 
     b.seg_begin = d_seg; b.segs = (const LitSegment*)(d_seg + 4);
     b.resume = c->sp_started ? 1u : 0u; b.wstate = c->d_wstate;
     set_cache_fields(c, b);
+    ++c->table_launch_seq;
     HIP_TRY(launch_model_encode(b, c->mix, 1u, c->stream));
     c->sp_started = true;
     c->sp_pending += 2u * len;
@@ -1604,6 +1778,7 @@ extern "C" int divans_gpu_lit_stream_decode(divans_gpu_codec* c, const uint8_t* 
     b.seg_begin = d_meta + 4; b.segs = (const LitSegment*)(d_meta + 8);
     b.resume = c->sd_started ? 1u : 0u; b.wstate = c->d_wstate;
     set_cache_fields(c, b);
+    ++c->table_launch_seq;
     HIP_TRY(launch_decode(b, c->mix, 1u, c->stream));
     c->sd_started = true;
     uint32_t words = 0, status = 0;

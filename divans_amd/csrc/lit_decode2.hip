@@ -28,7 +28,7 @@
 #ifndef DIVANS_D2_W7
 #define DIVANS_D2_W7 1
 #endif
-#ifndef DIVANS_D2_PERM          // stride-1 instances: index the tables by a text-frequency rank of the previous byte (BytePerm)
+#ifndef DIVANS_D2_PERM          // stride-1 instances: index the tables by a frequency rank of the previous byte (LitBatch::byte_rank)
 #define DIVANS_D2_PERM 1
 #endif
 #ifndef DIVANS_D2_LOAD_AUX      // cache-policy bits of the row loads / stores that go to memory: 1 = sc0, 2 = nt, 16 = sc1
@@ -54,9 +54,6 @@ __device__ __forceinline__ void lds_write16(uint32_t a, uint32_t v) { *(lds_u16*
 __device__ __forceinline__ uint32_t lds_read8(uint32_t a) { return *(const lds_u8*)(uintptr_t)a; }
 __device__ __forceinline__ uint32_t lds_read32(uint32_t a) { return *(const lds_u32*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_write32(uint32_t a, uint32_t v) { *(lds_u32*)(uintptr_t)a = v; }
-
-// BytePerm (lit_device.h): the order in which the stride-1 tables lay the previous byte's rows out
-__device__ const BytePerm kBytePerm{};
 
 constexpr uint32_t kRingWords = 32u;
 constexpr uint32_t kRingBytes = kRingWords * 4u;
@@ -217,7 +214,7 @@ struct WordRing {
 template <bool NEED8>
 struct History {
     uint64_t last8; uint32_t p1, p2;
-    uint32_t pb;         // rank of p1 in BytePerm's order (stride-1 instances), read from the LDS copy at perm_off
+    uint32_t pb;         // rank of p1 in the launch's byte order (stride-1 instances), read from the LDS copy at perm_off
     uint32_t perm_off;
     __device__ __forceinline__ void set(uint64_t v, bool perm) { last8 = v; p1 = (uint32_t)(v >> 56); p2 = (uint32_t)(v >> 48) & 0xffu; if (perm) pb = lds_read8(perm_off + p1); }
     __device__ __forceinline__ void push(uint32_t byte, bool perm) {
@@ -435,8 +432,8 @@ __device__ __forceinline__ void decode2_body(const LitBatch& b, uint8_t* lds) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
     constexpr bool PERM = DIVANS_D2_PERM && MM == 4;
     const uint32_t perm_off = lds_base + (uint32_t)(lv.mix - lv.base);   // behind the configuration tables (lit_lds_bytes2; MM >= 0: no mixing mask there)
-    if (PERM) {     // LitBatch::byte_order: BytePerm's text-frequency ranks, or the bytes themselves
-        if (threadIdx.x < 64u) lds_write32(perm_off + 4u * threadIdx.x, b.byte_order ? 0x03020100u + 0x04040404u * threadIdx.x : ((const uint32_t*)kBytePerm.rank)[threadIdx.x]);
+    if (PERM) {     // LitBatch::byte_rank: the ranks the codec learned from its data (or was given), or the bytes themselves
+        if (threadIdx.x < 64u) lds_write32(perm_off + 4u * threadIdx.x, b.byte_rank ? ((const uint32_t*)b.byte_rank)[threadIdx.x] : 0x03020100u + 0x04040404u * threadIdx.x);
         __syncthreads();
     }
     const uint32_t stream_base = lds_base + (threadIdx.x >> 4) * (b.cache_bytes_per_wg / (LIT_THREADS / 16));
@@ -563,6 +560,125 @@ __global__ __launch_bounds__(LIT_THREADS) void lit_decode2_kernel_any(const LitB
     decode2_body<MM, CTXC, MIX, SEG, CM>(b, lds);
 }
 
+
+// ---- the decoder's row traffic without the decoder (launch_row_replay, lit_kernels.h) ----
+// Same table layout, LDS caches, persistent grid and per-byte row selection as decode2_body for the stride-1 configurations (every
+// mixing value 4); the bytes come from memory instead of from the rANS states, so the rows of byte k + 1 -- the low-nibble row
+// included, which a decoder can only name once it has decoded the high nibble -- are requested while byte k is being blended.
+template <bool CTXC, bool MIX, int CM>
+__device__ __forceinline__ void replay_body(const LitBatch& b, uint8_t* lds) {
+    constexpr int MM = 4;
+    const LdsView lv = load_config_to_lds<MM, CTXC>(lds, b);
+    const LitGeometry& g = b.geom;
+    const int lane = threadIdx.x & 63, li = lane & 15, rbase = lane & 48, li1 = li + 1;
+    const uint32_t gg = blockIdx.x * (LIT_THREADS / 16) + (threadIdx.x >> 4);
+    const uint32_t G = gridDim.x * (LIT_THREADS / 16);
+    Table2 tb;
+    {
+        const uint32_t slab = g.total_rows * 32u;
+        const uint64_t base = (uint64_t)((uint8_t*)b.tables + (size_t)blockIdx.x * (LIT_THREADS / 16) * slab);
+        const uint64_t ubase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        tb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ubase, 0, __builtin_amdgcn_readfirstlane((int)((LIT_THREADS / 16) * slab)), 0x00020000);
+        tb.lane_off = (threadIdx.x >> 4) * slab + 2u * (uint32_t)li;
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    constexpr bool PERM = DIVANS_D2_PERM != 0;
+    const uint32_t perm_off = lds_base + (uint32_t)(lv.mix - lv.base);
+    if (PERM) {
+        if (threadIdx.x < 64u) lds_write32(perm_off + 4u * threadIdx.x, b.byte_rank ? ((const uint32_t*)b.byte_rank)[threadIdx.x] : 0x03020100u + 0x04040404u * threadIdx.x);
+        __syncthreads();
+    }
+    const uint32_t stream_base = lds_base + (threadIdx.x >> 4) * (b.cache_bytes_per_wg / (LIT_THREADS / 16));
+    const Caches cc = make_caches<(CM & CM_2WAY) != 0>(b, stream_base, li);
+    constexpr bool W2 = (CM & CM_2WAY) != 0;
+    constexpr bool HS_C = (CM & CM_HS) != 0, HC_C = (CM & CM_HC) != 0, LS_C = (CM & CM_LS) != 0, LC_C = (CM & CM_LC) != 0;
+    for (uint32_t s = gg; s < b.n_streams; s += G) {
+        const uint32_t len = b.in_sizes ? b.in_sizes[s] : b.stream_len;
+        const uint8_t* in = b.in + (b.in_offsets ? b.in_offsets[s] : (uint64_t)s * b.stream_len);
+        init_table2<CM>(tb, cc, g.total_rows, li);
+        History<false> hist;
+        hist.perm_off = perm_off;
+        hist.set(0ull, PERM);
+        uint32_t k1 = CTXC ? 0u : lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];
+        uint32_t ctx_cur = context_of<CTXC>(g, lv.ctx, LIT_BLOB_CTXF, hist.p1, k1);
+        // rows of the byte in hand: requested one byte ahead
+        RowSlot hs_ref = {}, hc_ref = {}, ls_ref = {}, lc_ref = {};
+        int hs_v = 0, hc_v = 0, ls_v = 0, lc_v = 0;
+        uint32_t cur = len ? in[0] : 0u;
+        {
+            const RowSel rh = select_rows2<true, MM, false>(g, lv.mix, ctx_cur, hist, 0u);
+            const RowSel rl = select_rows2<false, MM, false>(g, lv.mix, ctx_cur, hist, cur >> 4);
+            hs_v = tb.template load<HS_C, W2, false>(cc.hs, rh.stride_row, hs_ref);
+            if (MIX) hc_v = tb.template load<HC_C, W2, false>(cc.hc, rh.cm_row, hc_ref);
+            ls_v = tb.template load<LS_C, W2, false>(cc.ls, rl.stride_row, ls_ref);
+            if (MIX) lc_v = tb.template load<LC_C, W2, false>(cc.lc, rl.cm_row, lc_ref);
+        }
+        for (uint32_t base = 0; base < len; base += 16u) {
+            const uint32_t cnt = len - base < 16u ? len - base : 16u;
+            // the 16 bytes AFTER this group's first: byte base + 1 + lane (the first is already in `cur`)
+            const uint32_t mine = (base + 1u + (uint32_t)li < len) ? in[base + 1u + (uint32_t)li] : 0u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_ds_bpermute((rbase + (int)k) << 2, (int)mine);
+                const uint32_t hi = cur >> 4, lo = cur & 15u;
+                // high nibble of the byte in hand
+                {
+                    const bool above = (uint32_t)li >= hi;
+                    const int st = blend2(hs_v, li1, above, g.inc0, g.lim0, row_bcast<15>(hs_v));
+                    tb.template store<HS_C>(cc.hs, hs_ref, st);
+                    if (MIX) { const int cm = blend2(hc_v, li1, above, g.inc3, g.lim3, row_bcast<15>(hc_v)); tb.template store<HC_C>(cc.hc, hc_ref, cm); }
+                }
+                hist.push(cur, PERM);
+                if (!CTXC) k1 = lv.ctx[LIT_BLOB_LUT1CLASS + hist.p2];
+                ctx_cur = context_of<CTXC>(g, lv.ctx, LIT_BLOB_CTXF, hist.p1, k1);
+                // every row of the next byte, its low-nibble rows included
+                const RowSel rh = select_rows2<true, MM, false>(g, lv.mix, ctx_cur, hist, 0u);
+                const RowSel rl = select_rows2<false, MM, false>(g, lv.mix, ctx_cur, hist, nxt >> 4);
+                RowSlot nhs = {}, nhc = {}, nls = {}, nlc = {};
+                const int nhs_v = tb.template load<HS_C, W2, false>(cc.hs, rh.stride_row, nhs);
+                int nhc_v = 0; if (MIX) nhc_v = tb.template load<HC_C, W2, false>(cc.hc, rh.cm_row, nhc);
+                // low nibble of the byte in hand
+                {
+                    const bool above = (uint32_t)li >= lo;
+                    const int st = blend2(ls_v, li1, above, g.inc0, g.lim0, row_bcast<15>(ls_v));
+                    tb.template store<LS_C>(cc.ls, ls_ref, st);
+                    if (MIX) { const int cm = blend2(lc_v, li1, above, g.inc2, g.lim2, row_bcast<15>(lc_v)); tb.template store<LC_C>(cc.lc, lc_ref, cm); }
+                }
+                const int nls_v = tb.template load<LS_C, W2, false>(cc.ls, rl.stride_row, nls);
+                int nlc_v = 0; if (MIX) nlc_v = tb.template load<LC_C, W2, false>(cc.lc, rl.cm_row, nlc);
+                hs_ref = nhs; hc_ref = nhc; ls_ref = nls; lc_ref = nlc; hs_v = nhs_v; hc_v = nhc_v; ls_v = nls_v; lc_v = nlc_v;
+                cur = nxt;
+            }
+        }
+    }
+}
+
+template <bool CTXC, bool MIX, int CM>
+__global__ __launch_bounds__(LIT_THREADS) __attribute__((amdgpu_waves_per_eu(7))) void row_replay_kernel(const LitBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    replay_body<CTXC, MIX, CM>(b, lds);
+}
+
+// one workgroup: histogram of a sample of the batch in LDS, then every thread ranks its own byte value
+__global__ __launch_bounds__(256) void learn_byte_rank_kernel(const uint8_t* data, const uint64_t* offsets, const uint32_t* sizes, uint32_t n_streams,
+                                                              uint32_t stream_len, uint32_t sample_streams, uint32_t sample_len, uint8_t* rank) {
+    __shared__ uint32_t cnt[256];
+    cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t j = 0; j < sample_streams; ++j) {
+        const uint32_t s = (uint32_t)(((uint64_t)j * n_streams) / sample_streams);
+        const uint8_t* p = data + (offsets ? offsets[s] : (uint64_t)s * stream_len);
+        uint32_t len = sizes ? sizes[s] : stream_len;
+        len = len < sample_len ? len : sample_len;
+        for (uint32_t i = threadIdx.x; i < len; i += 256u) atomicAdd(&cnt[p[i]], 1u);
+    }
+    __syncthreads();
+    const uint32_t mine = cnt[threadIdx.x];
+    uint32_t r = 0;
+    for (uint32_t x = 0; x < 256u; ++x) { const uint32_t c = cnt[x]; r += (c > mine || (c == mine && x < threadIdx.x)) ? 1u : 0u; }
+    rank[threadIdx.x] = (uint8_t)r;
+}
+
 typedef void (*LitKernel)(const LitBatch);
 
 template <bool MIX, bool SEG, int CM>
@@ -623,7 +739,7 @@ uint32_t lit_lds_bytes2(const LitBatch& b) {
     uint32_t bytes = b.cache_bytes_per_wg;
     if (b.geom.ctx_const < 0) bytes += LIT_BLOB_CTXF + LIT_CTXF_BYTES * b.geom.n_btypes;
     if (!(b.geom.mm_uniform == 0 || b.geom.mm_uniform == 4)) bytes += 8192u;
-    if (DIVANS_D2_PERM && b.geom.mm_uniform == 4) bytes += 256u;   // BytePerm's ranks
+    if (DIVANS_D2_PERM && b.geom.mm_uniform == 4) bytes += 256u;   // the byte ranks
     return bytes;
 }
 
@@ -651,6 +767,36 @@ hipError_t launch_decode2(const LitBatch& b, bool mix, uint32_t blocks, hipStrea
     const uint32_t cm = wanted_cache_mask(b.dm_log2);
     if (cm != supported_cache_mask(mix, b.segs != nullptr, cm)) return hipErrorInvalidValue;   // the host passes lit_decode2_effective_caches()
     LitKernel k = pick_decode2(mix, b.segs != nullptr, cm, (b.dm_shift >> 31) != 0u, mm, b.geom.ctx_const >= 0);
+    const uint32_t lds = lit_lds_bytes2(b);
+    if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);
+    return hipGetLastError();
+}
+
+
+hipError_t launch_learn_byte_rank(const uint8_t* data, const uint64_t* offsets, const uint32_t* sizes, uint32_t n_streams, uint32_t stream_len,
+                                  uint32_t sample_streams, uint32_t sample_len, uint8_t* rank, hipStream_t st) {
+    if (n_streams == 0u) return hipSuccess;
+    if (sample_streams > n_streams) sample_streams = n_streams;
+    hipLaunchKernelGGL(learn_byte_rank_kernel, dim3(1), dim3(256), 0, st, data, offsets, sizes, n_streams, stream_len, sample_streams, sample_len, rank);
+    return hipGetLastError();
+}
+
+// the instances the benchmark configurations use: constant context without mixing (high-row cache, 2-way or direct mapped),
+// context table with mixing (high stride + FirstNibble caches)
+hipError_t launch_row_replay(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st) {
+    if (b.geom.mm_uniform != 4 || b.segs) return hipErrorInvalidValue;
+    const uint32_t cm = wanted_cache_mask(b.dm_log2);
+    const bool two_way = (b.dm_shift >> 31) != 0u, ctxc = b.geom.ctx_const >= 0;
+    LitKernel k = nullptr;
+    if (!mix && cm == (uint32_t)CM_HS) {
+        if (ctxc) k = two_way ? row_replay_kernel<true, false, CM_HS | CM_2WAY> : row_replay_kernel<true, false, CM_HS>;
+        else k = two_way ? row_replay_kernel<false, false, CM_HS | CM_2WAY> : row_replay_kernel<false, false, CM_HS>;
+    } else if (mix && cm == (uint32_t)(CM_HS | CM_HC)) {
+        if (ctxc) k = two_way ? row_replay_kernel<true, true, CM_HS | CM_HC | CM_2WAY> : row_replay_kernel<true, true, CM_HS | CM_HC>;
+        else k = two_way ? row_replay_kernel<false, true, CM_HS | CM_HC | CM_2WAY> : row_replay_kernel<false, true, CM_HS | CM_HC>;
+    }
+    if (!k) return hipErrorInvalidValue;
     const uint32_t lds = lit_lds_bytes2(b);
     if (lds > 65536u) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(LIT_THREADS), lds, st, b);

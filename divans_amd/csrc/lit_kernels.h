@@ -73,9 +73,10 @@ struct LitBatch {
     // else carries over); `consumed` (optional, [n_streams]) receives the coded words a stream read, and with it set the words
     // offered may outnumber the words read (the caller passes what has arrived so far)
     uint32_t* consumed;
-    // lit_decode2.hip, stride-1 instances: the order in which a table lays out the rows of the 256 previous-byte values -- 0 = by a
-    // text-frequency rank (BytePerm, lit_device.h), 1 = numeric.  A private layout of the launch: any order decodes the same bytes.
-    uint32_t byte_order;
+    // lit_decode2.hip, stride-1 instances: the order in which a table lays out the rows of the 256 previous-byte values -- a device
+    // array of 256 ranks (a permutation: the codec learns it from the bytes it has seen, divans_gpu_codec_set_byte_order), or null =
+    // numeric.  A private layout of the launch: any order decodes the same bytes.
+    const uint8_t* byte_rank;
 };
 constexpr uint32_t LIT_STATUS_BAD_MODEL = 1u;     // rANS pass: freq == 0 or start/freq outside 15 bits
 constexpr uint32_t LIT_STATUS_BAD_SEGMENT = 4u;   // a segment names a literal block type outside the codec's context tables
@@ -170,6 +171,17 @@ uint32_t lit_decode_t_stream_lds(uint32_t dm_log2, bool mix);   // LDS bytes one
 #endif
 hipError_t launch_pack(const uint8_t* slots, const uint64_t* src_off, const uint32_t* sizes, uint32_t n, uint8_t* packed,
                        uint64_t* dst_off, uint64_t* total, hipStream_t st, bool accumulate = false, uint64_t cap = ~0ull, uint32_t* status = nullptr);
+// rank[b] = position of byte value b when the 256 values are ordered by how often they occur in a sample of the batch (the first
+// `sample_len` bytes of `sample_streams` streams spread over it), ties by value: one workgroup, enqueued behind the launch that
+// produced / consumed the bytes (lit_decode2.hip)
+hipError_t launch_learn_byte_rank(const uint8_t* data, const uint64_t* offsets, const uint32_t* sizes, uint32_t n_streams, uint32_t stream_len,
+                                  uint32_t sample_streams, uint32_t sample_len, uint8_t* rank, hipStream_t st);
+// The decoder's row traffic without the decoder: the streams' bytes are KNOWN (b.in = the literal bytes, in_offsets / in_sizes theirs),
+// every row the decoder of this configuration would touch is loaded, blended with the byte's nibble and stored through the same
+// per-stream LDS caches, table layout and persistent grid -- no rANS state, no search, no division, nothing that makes one byte wait
+// for the previous one except the rows themselves.  Its time is the memory side's own ceiling for this access stream (bench.py:
+// roofline.request_ceiling).  Leaves the tables as a decode of the same bytes would; writes nothing else.
+hipError_t launch_row_replay(const LitBatch& b, bool mix, uint32_t blocks, hipStream_t st);
 hipError_t launch_selftest_division(unsigned long long* d_mismatches, hipStream_t st);
 hipError_t launch_selftest_cdf_ops(const uint32_t* d_ops, uint32_t n, int32_t* d_out, hipStream_t st);
 

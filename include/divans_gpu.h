@@ -257,30 +257,59 @@ int divans_gpu_codec_set_decoder(divans_gpu_codec *c, uint32_t generation, const
  * long); larger batches fill the SIMDs with whole-chunk lanes and the total work is the same.  The coded bytes do not depend on it. */
 int divans_gpu_codec_set_rans_split(divans_gpu_codec *c, uint32_t mode);
 /* Stride-1 configurations (every mixing value 4): the order in which the decoder's private tables lay out the rows of the 256 previous-byte
- * values, i.e. which rows share a 128-byte line.  0 (default) = a text-frequency rank: lower-case letters by English frequency, separators,
- * capitals, digits, then everything else numerically -- on text an L2 line then holds rows that are hot together (-4 % decode time,
- * profiles/r03c_byte_rank_layout_same_box.txt); 1 = numeric order, for input that is not text.  Bytes >= 0x80 are in numeric order either way.
- * The decoded bytes do not depend on it. */
+ * values, i.e. which rows share a 128-byte line -- the byte values that are hot together should (on text -4..5 % decode time against numeric
+ * order, profiles/r03c_byte_rank_layout_same_box.txt, r05_byte_order_ab.txt).
+ *   0 (default) = LEARNED from the codec's own data: the first batch the codec sees -- the literal bytes of an encode call, or what a decode
+ *       call produced -- is sampled on the device (64 streams x 2 KiB, one small kernel behind that call's launches, nothing synchronised)
+ *       and the byte values are ranked by frequency; every later launch uses that rank.  Until then (a decode-only codec's first call) the
+ *       order is numeric.  Calling this function with 0 again makes the next batch re-learn it.
+ *   1 = numeric order.
+ *   2 = a fixed English-text rank (lower-case letters by frequency, separators, capitals, digits, the rest numerically): a caller's hint,
+ *       what rounds 3-5 used as the default.
+ * The decoded bytes do not depend on it (a private layout of each launch). */
 int divans_gpu_codec_set_byte_order(divans_gpu_codec *c, uint32_t order);
+/* What is in force: *mode = the order set; *ready = 1 when a rank table is in use (mode 2, or mode 0 after the first batch);
+ * rank256 (optional, 256 bytes) = rank of every byte value (identity while none is in use).  Synchronises the stream when rank256 is given. */
+int divans_gpu_codec_byte_order(divans_gpu_codec *c, uint32_t *mode, uint32_t *ready, uint8_t *rank256);
+/* Measurement aid: the memory side's own time for a batch's CDF-row traffic.  `d_literals` (+ offsets / sizes, or NULL for n_streams x stream_len
+ * contiguous) are the streams' LITERAL bytes; every row the decoder of this configuration touches for them is loaded, blended with the byte's
+ * nibble and stored through the same per-stream LDS caches, table layout, byte order and persistent grid divans_gpu_lit_decode_batch would use
+ * for a batch of this size -- with no entropy decoding and nothing that makes a byte wait for the one before it (the low-nibble rows, which a
+ * decoder can only name once the high nibble is decoded, are requested a byte ahead).  *ms = that launch's duration: what the decode
+ * kernel would take if the memory system were its only limit.  Synchronous.  Stride-1 configurations (divans_lit_config_simple /
+ * _context_mixing and the like), default cache organisation; DIVANS_GPU_EINVAL elsewhere. */
+int divans_gpu_codec_row_replay(divans_gpu_codec *c, const uint8_t *d_literals, const uint64_t *d_offsets, const uint32_t *d_sizes,
+                                uint32_t n_streams, uint32_t stream_len, float *ms);
 /* 1 if this library was built with the decoders that lost their measurements (generation 4; generation 1 with unified / split caches) */
 int divans_gpu_experimental_decoders(void);
 
-/* Where the CDF tables' pages lie in device memory moves the decode time by 10-20 % from one allocation to the next (DESIGN.md section 5;
- * about one placement in six is a fast one, profiles/r04e_table_placement.txt), so the library measures: the first divans_gpu_lit_decode_batch
- * call whose batch fills at least half the persistent grid runs its launch on several placements of the tables -- alternately 32 MiB chunks
- * mapped side by side and one hipMalloc block; which kind is faster differs from box to box -- and keeps the fastest; the same bytes come out
- * every time.  `candidates`: 0 = the library's policy, the default: tables of 2 GiB and more (whole-GPU batches) 12 placements;
- * smaller tables are not tuned.  1 = off.  2..16 = that many.
- * THAT CALL SYNCHRONISES THE STREAM (every other decode call is asynchronous) and takes (placements tried) x (one decode + one allocation of
- * the tables): seconds, once per codec and again after the tables had to grow.  Memory while it runs: two copies of the tables (the best so
- * far and the candidate; a rejected copy is released before the next is allocated).  Address space: every chunk-mapped candidate reserves a
- * range that is never returned (the ROCm remap defect, scripts/probes/README.md) -- see divans_gpu_table_memory. */
+/* Where the CDF tables' pages lie in device memory moves the decode time by up to 10-20 % from one allocation to the next (DESIGN.md
+ * section 5; profiles/r04e_table_placement.txt), so the library measures placements -- alternately one hipMalloc block and 32 MiB chunks
+ * mapped side by side; which kind is faster differs from box to box -- and keeps the fastest; the same bytes come out whatever the placement.
+ * `candidates`:
+ *   0 = the library's policy, the default: tables of 2 GiB and more (whole-GPU batches) are tried on 12 placements, ONE PER CALL -- each of
+ *       the codec's first divans_gpu_lit_decode_batch calls whose batch fills at least half the persistent grid decodes ONCE, on one
+ *       placement (a new candidate, or the best so far), and the next such call reads that launch's time before it picks its own.  No call
+ *       decodes twice; a call waits at most for the decode launch of the PREVIOUS such call (never for its own), only while the search
+ *       lasts (13 calls), and spends one allocation of the tables on the host.  Calls of another shape (stream count / length) than the
+ *       first are decoded on the placement in use and not compared.  A caller that stops after fewer calls keeps what was in use.
+ *       Smaller tables are not tuned.
+ *   1 = off: the first allocation as it comes (the lanes of divans_batch_* use this).
+ *   2..16 = the EAGER form: the first qualifying call decodes its batch that many times, once per placement, synchronises the stream
+ *       and returns with the fastest in place -- seconds, for a caller that wants the search over before its first timed call.
+ * Memory while a search runs (either form): two copies of the tables (the best so far and the candidate; a rejected copy is released before
+ * the next is allocated).  Address space: every chunk-mapped candidate reserves a range that is never returned (the ROCm remap defect,
+ * scripts/probes/README.md) -- see divans_gpu_table_memory.  The search starts again after the tables had to grow. */
 int divans_gpu_codec_tune_tables(divans_gpu_codec *c, uint32_t candidates);
+/* The call-by-call search (what `0` above gives tables of 2 GiB and more) with `candidates` placements whatever the tables' size:
+ * 0 = the library's policy, 1 = off, 2..16 = that many, one per qualifying decode call. */
+int divans_gpu_codec_search_tables(divans_gpu_codec *c, uint32_t candidates);
 typedef struct divans_gpu_table_placement {
-    uint32_t policy_candidates;    /* what the next tuning would try at most (the library's policy or divans_gpu_codec_tune_tables) */
-    uint32_t tried;                /* placements the last tuning decoded on (0 = not tuned yet / not tuned at all) */
-    float first_ms, best_ms, worst_ms;   /* decode kernel time on the first placement, on the one kept, on the slowest seen */
-    uint32_t kept_chunks;          /* 1 = the kept tables are chunks mapped into a reserved range, 0 = one hipMalloc block */
+    uint32_t policy_candidates;    /* what a search tries at most (the library's policy or divans_gpu_codec_tune_tables); valid before the tables exist */
+    uint32_t tried;                /* placements measured so far (0 = no search yet / none at all) */
+    float first_ms, best_ms, worst_ms;   /* decode kernel time on the first placement, on the best so far (the one kept once the search is over), on the slowest seen */
+    uint32_t kept_chunks;          /* 1 = the kept tables are chunks mapped into a reserved range, 0 = one hipMalloc block (once the search is over) */
+    uint32_t searching;            /* 1 = the call-by-call search is still running: the next qualifying call tries another placement */
 } divans_gpu_table_placement;
 int divans_gpu_codec_table_placement(divans_gpu_codec *c, divans_gpu_table_placement *out);
 /* Memory the library keeps beyond its codecs.  A destroyed codec's chunk-mapped tables (2 GiB and more) stay MAPPED -- at most two ranges

@@ -20,17 +20,20 @@ for spec in sys.argv[2:]:
     config, summary, cmd, streams, block = spec.split(":")
     vals = {}
     for line in open(summary):
-        m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE)\s+avg=(\S+) n=(\d+)", line)
+        m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ_sum|TCC_EA0_WRREQ_sum|TCC_EA0_WRREQ_64B_sum)\s+avg=(\S+) n=(\d+)", line)
         if not m or "divans" not in m.group(1):
             continue
         short = re.sub(r"^void ", "", m.group(1).strip()).split("<")[0].split("(")[0].replace("divans_hip::", "")
         # bench.py names the decode kernel as rocprofv3 does and falls back to this base name (without template arguments) for the lookup
-        vals.setdefault(short, {})[m.group(2)] = float(m.group(3)) * 1024.0      # counters are in KiB
+        vals.setdefault(short, {})[m.group(2)] = float(m.group(3)) * (1024.0 if m.group(2).endswith("_SIZE") else 1.0)      # the size counters are in KiB
     out["configs"][config] = {"command": open(cmd).read().strip(), "streams": int(streams), "block_bytes": int(block), "config": config,
                               "kernels": {k: {"fetch_counter": v.get("FETCH_SIZE"), "write_counter": v.get("WRITE_SIZE"),
                                               "fetch_bytes": FETCH_BYTES_PER_COUNTED_BYTE * (v.get("FETCH_SIZE") or 0),
                                               "write_bytes": WRITE_BYTES_PER_COUNTED_BYTE * (v.get("WRITE_SIZE") or 0),
                                               "hbm_bytes_per_launch": FETCH_BYTES_PER_COUNTED_BYTE * (v.get("FETCH_SIZE") or 0) +
-                                                                      WRITE_BYTES_PER_COUNTED_BYTE * (v.get("WRITE_SIZE") or 0)} for k, v in vals.items()}}
+                                                                      WRITE_BYTES_PER_COUNTED_BYTE * (v.get("WRITE_SIZE") or 0),
+                                              # L2 -> fabric requests (the "ea" pass, where it ran): 128-byte fills, 32- / 64-byte write requests
+                                              "rdreq_per_launch": v.get("TCC_EA0_RDREQ_sum"), "wrreq_per_launch": v.get("TCC_EA0_WRREQ_sum"),
+                                              "wrreq_64B_per_launch": v.get("TCC_EA0_WRREQ_64B_sum")} for k, v in vals.items()}}
 json.dump(out, open("profiles/traffic_latest.json", "w"), indent=1)
 print(json.dumps({c: {k: v["hbm_bytes_per_launch"] for k, v in e["kernels"].items()} for c, e in out["configs"].items()}, indent=1))

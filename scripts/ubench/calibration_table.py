@@ -15,6 +15,9 @@ def short(kernel_name):
     m = re.search(r"rows_kernel<(\d+), (\d+)>", kernel_name)
     if m:
         return "row_%s_mask%s" % (("read", "write", "rmw")[int(m.group(2))], m.group(1))
+    m = re.search(r"rmw_private<(\d+)>", kernel_name)
+    if m:
+        return "rmw_private_%s" % m.group(1)
     for k in ("stream_read16", "stream_read1", "stream_write16"):
         if re.search(r"\b%s\b" % k, kernel_name):
             return k

@@ -53,6 +53,7 @@ extern "C" void divans_gpu_codec_destroy(divans_gpu_codec* c) {
 }
 
 extern "C" int divans_gpu_codec_set_geometry(divans_gpu_codec* c, uint32_t blocks, uint32_t) { if (!c) return DIVANS_GPU_EINVAL; if (blocks) c->blocks = blocks; return 0; }
+extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t) { return c ? 0 : DIVANS_GPU_EINVAL; }     // (batch.cpp switches the placement search of its lanes off)
 
 // the rule of divans_amd/csrc/capi.cpp (the one trajectory of cdf[15] from 64 under FrequentistCDF16::blend), so that the stub refuses
 // what the library refuses

@@ -889,11 +889,115 @@ def test_byte_order_of_the_tables_changes_no_byte(cfg_name, corpus, random_then_
     ocfg = _oracle_cfg(cfg_name)
     for i in range(4):
         assert (packed[int(offs[i]):int(offs[i]) + int(sizes[i])] == po.lit_encode(ocfg, blocks[i])).all()
-    for order in (1, 0, 1):
+    for order in (1, 0, 2, 1, 0):
         codec.set_byte_order(order)
         assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), order
+        assert (codec.decode_host(packed, offs, sizes, L) == blocks).all(), order       # (order 0: the second call uses what the first learned)
     with pytest.raises(da.DivansGpuError):
-        codec.set_byte_order(2)
+        codec.set_byte_order(3)
+    codec.close()
+
+
+@pytest.mark.gpu
+def test_byte_order_is_learned_from_the_data_the_codec_sees(corpus, random_then_unicode):
+    """no constant decides the default.  Order 0 ranks the byte values by their frequency in the first batch the codec
+    sees -- an encode call's input, or a decode-only codec's first output -- on the device; the rank is a permutation, puts the data's own
+    frequent bytes first, and changes no decoded byte"""
+    import torch
+    L = 4096
+    text = np.stack([corpus[i * 1000:i * 1000 + L] for i in range(96)])
+    da, codec = _codec("simple", L)
+    assert codec.byte_order() == {"mode": 0, "ready": False}
+    packed, offs, sizes = codec.encode_host(text, L)            # the encoder's input teaches it
+    bo = codec.byte_order(with_rank=True)
+    assert bo["ready"] and sorted(bo["rank"]) == list(range(256))
+    top = sorted(range(256), key=lambda b: bo["rank"][b])[:8]
+    counts = np.bincount(np.concatenate([text[(j * 96) // 64, :2048] for j in range(64)]), minlength=256)       # the sample the kernel takes
+    expect = sorted(range(256), key=lambda b: (-int(counts[b]), b))[:8]
+    assert top == expect and ord(" ") in top and ord("e") in top, (top, expect)
+    assert (codec.decode_host(packed, offs, sizes, L) == text).all()
+    codec.close()
+    # a codec that only ever decodes: numeric for its first call, learned from that call's output for the next
+    da, dec = _codec("simple", L)
+    assert (dec.decode_host(packed, offs, sizes, L) == text).all()
+    bo2 = dec.byte_order(with_rank=True)
+    assert bo2["ready"] and bo2["rank"] == bo["rank"]
+    assert (dec.decode_host(packed, offs, sizes, L) == text).all()
+    # other data, other order: asking for 0 again re-learns
+    binary = np.stack([random_then_unicode[200000 + i * 500:200000 + i * 500 + L] for i in range(96)])
+    p2, o2, s2 = dec.encode_host(binary, L)
+    assert dec.byte_order(with_rank=True)["rank"] == bo["rank"]            # learned once ...
+    dec.set_byte_order(0)
+    assert dec.byte_order()["ready"] is False
+    p2, o2, s2 = dec.encode_host(binary, L)                                    # ... until asked again
+    assert dec.byte_order(with_rank=True)["rank"] != bo["rank"]
+    assert (dec.decode_host(p2, o2, s2, L) == binary).all() and (dec.decode_host(packed, offs, sizes, L) == text).all()
+    dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_placement_search_one_candidate_per_call_changes_no_byte(cfg_name, corpus):
+    """the library's own placement policy never decodes a batch twice.  Each qualifying call runs on one placement and the
+    next reads its time: k candidates are settled after k + 1 calls, every call returns the right bytes, calls of another shape are served
+    in between without being compared, and the first call is not synchronised"""
+    import torch
+    da, codec = _codec(cfg_name, 2048)
+    resident = codec.info().resident_groups
+    n = resident // 2 + 16
+    blocks = workload.make_blocks(corpus, 5, n, block_len=2048)
+    d_in = torch.from_numpy(blocks).cuda()
+    outs = codec.alloc_encode_outputs(n, 2048)
+    codec.encode_batch(d_in, n, 2048, outs)
+    codec.search_tables(4)
+    pl = codec.table_placement()
+    assert pl["policy_candidates"] == 4 and pl["tried"] == 0 and not pl["searching"]
+    back = torch.zeros((n, 2048), dtype=torch.uint8, device="cuda")
+    seen = []
+    for call in range(7):
+        back.zero_()
+        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
+        if call == 2:      # another shape in between: decoded on the placement in use, not part of the comparison
+            few = torch.zeros((48, 2048), dtype=torch.uint8, device="cuda")
+            codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], 48, 2048, few)
+            assert torch.equal(few, d_in[:48])
+        assert torch.equal(back, d_in) and codec.status() == 0, call
+        pl = codec.table_placement()
+        seen.append((pl["tried"], pl["searching"]))
+    # call i (0-based) has read the times of i placements; the fifth call reads the fourth time and ends the search
+    assert seen == [(0, True), (1, True), (2, True), (3, True), (4, False), (4, False), (4, False)], seen
+    assert 0 < pl["best_ms"] <= pl["first_ms"] <= pl["worst_ms"], pl
+    # the search starts again when asked to, and a damaged stream is reported from a searching call like from any other
+    codec.search_tables(2)
+    coded = outs["out"].clone(); coded[int(outs["offsets"][7]) + 30] ^= 0x40
+    codec.decode_batch(coded, outs["offsets"], outs["sizes"], n, 2048, back)
+    assert codec.status() & 2
+    for _ in range(3):
+        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
+    assert torch.equal(back, d_in) and codec.status() == 0 and not codec.table_placement()["searching"]
+    codec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["simple", "mixing"])
+def test_row_replay_runs_the_decoders_row_traffic_and_leaves_the_codec_usable(cfg_name, corpus):
+    """divans_gpu_codec_row_replay (bench.py's roofline.request_ceiling): a measurement aid -- it returns a time, refuses what it has no
+    instance for, and a decode after it is unharmed"""
+    import torch
+    da, codec = _codec(cfg_name, 4096)
+    n = 512
+    blocks = workload.make_blocks(corpus, 9, n, block_len=4096)
+    d_in = torch.from_numpy(blocks).cuda()
+    packed, offs, sizes = codec.encode_host(blocks, 4096)
+    ms = codec.row_replay(d_in, n, 4096)
+    assert 0 < ms < 1000
+    lens = torch.full((n,), 4096, dtype=torch.int32, device="cuda"); lens[::3] = 1000
+    offsets = (torch.arange(n, dtype=torch.int64, device="cuda") * 4096)
+    assert codec.row_replay(d_in, n, 4096, offsets=offsets, sizes=lens) > 0          # ragged batches too
+    assert (codec.decode_host(packed, offs, sizes, 4096) == blocks).all() and codec.status() == 0
+    codec.set_decoder(3, (8, 8, 8, 0), (5, 5, 5, 5))             # a cache organisation the replay has no instance for
+    with pytest.raises(da.DivansGpuError):
+        codec.row_replay(d_in, n, 4096)
     codec.close()
 
 
