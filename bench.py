@@ -308,7 +308,7 @@ def settle_placement(codec, step, limit=20):
     return extra
 
 
-def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note="", traffic_name=None, byte_order=None, steps=None):
+def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_note="", traffic_name=None, byte_order=None, steps=None, warmup=None):
     """encode+decode config (simple or mixing): verify, time, report."""
     cfg = da.config_simple() if name == "simple" else da.config_context_mixing()
     ocfg = po.config_simple() if name == "simple" else po.config_context_mixing()
@@ -338,14 +338,15 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     if not args.no_verify:
         ok, checked = verify_first_pass(torch, po, codec, ocfg, d_in, N, L, outs, d_back, args.check_streams)
         first_sizes = outs["sizes"].clone(); d_back.zero_()
-    steps, warm = (steps or args.steps), args.warmup
+    steps, warm = (steps or args.steps), (args.warmup if warmup is None else warmup)
     if args.no_verify and args.table_candidates != 1:
         warm = max(warm, 1)          # the decode that tries the table placements is never a timed one
 
-    def untimed_step():
-        codec.encode_packed(d_in, N, L, outs["packed"], outs["packed_offsets"], outs["sizes"], outs["packed_total"])
+    def untimed_decode():      # (the coded streams are in `outs` since the verification pass; without one the warm-up's first step fills them)
         codec.decode_batch(outs["packed"], outs["packed_offsets"], outs["sizes"], N, L, d_back)
-    search_steps = settle_placement(codec, untimed_step)      # the placement search ends before the warm-up: no timed step runs on a candidate
+    if args.no_verify:
+        codec.encode_packed(d_in, N, L, outs["packed"], outs["packed_offsets"], outs["sizes"], outs["packed_total"])
+    search_steps = settle_placement(codec, untimed_decode)    # the placement search ends before the warm-up: no timed step runs on a candidate
     elapsed, rec = timed_steps(torch, codec, d_in, N, L, outs, d_back, steps, warm, barrier)
     if not args.no_verify:   # the timed passes must have produced the same thing
         ok = ok and bool(torch.equal(outs["sizes"], first_sizes)) and bool(torch.equal(d_back, d_in)) and codec.status() == 0
@@ -358,7 +359,7 @@ def run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, world_n
     replay_ms = None
     try:
         codec.row_replay(d_in, N, L)                 # (first launch: untimed)
-        replay_ms = min(codec.row_replay(d_in, N, L) for _ in range(2))
+        replay_ms = codec.row_replay(d_in, N, L)
     except Exception as e:       # no replay instance for this configuration / cache organisation
         sys.stderr.write(f"bench: row replay not available ({e})\n")
     # algorithmic bytes per launch: decode reads C + writes raw; the model pass reads raw and hands
@@ -432,7 +433,7 @@ def run_decode_only(torch, da, po, args, dev, copies=4096, steps=None):
     replay_ms = None
     try:
         codec.row_replay(d_out, N, L, offsets=d_out_off, sizes=d_out_sz)
-        replay_ms = min(codec.row_replay(d_out, N, L, offsets=d_out_off, sizes=d_out_sz) for _ in range(2))
+        replay_ms = codec.row_replay(d_out, N, L, offsets=d_out_off, sizes=d_out_sz)
     except Exception as e:
         sys.stderr.write(f"bench: row replay not available ({e})\n")
     res = {
@@ -461,13 +462,15 @@ def main():
                     help="all = configs[1] as the headline + configs[2] and configs[3] as sub-records (N = 1); a single name runs only that one")
     ap.add_argument("--check-streams", type=int, default=4096, help="streams whose coded bytes are compared with the oracle before timing")
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
-    ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override (tuning)")
+    ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override of the STREAMING ENCODER pass (tuning; in the default build the decoder keeps "
+                    "its own caches: --decoder-generation / divans_gpu_codec_set_decoder shape those)")
     ap.add_argument("--decoder-generation", type=int, default=0, help="decode kernel: 1 = lit_kernels.hip, 2 / 3 = lit_decode2.hip direct-mapped / 2-way caches (tuning; 0 = the codec's default)")
-    ap.add_argument("--table-candidates", type=int, default=0, help="placements of the CDF tables the first (untimed) decode of a codec tries before it keeps "
-                    "the fastest: 0 = the library's own policy, i.e. what every divans_gpu_codec_create caller gets (tables of 2 GiB and more: 12); 1 = take the first allocation as it comes; k = exactly k (divans_gpu_codec_tune_tables)")
+    ap.add_argument("--table-candidates", type=int, default=0, help="placements of the CDF tables a codec tries before it keeps the fastest: 0 = the library's own policy, i.e. what "
+                    "every divans_gpu_codec_create caller gets (tables of 2 GiB and more: 12 placements, ONE PER DECODE CALL -- the untimed passes before the warm-up complete the search); "
+                    "1 = take the first allocation as it comes; k = the eager form, all k on the first decode (divans_gpu_codec_tune_tables)")
     ap.add_argument("--encode-path", type=int, default=0, help="encoder model pass: 0 automatic, 1 streaming, 2 bucketed (tuning)")
     ap.add_argument("--bucket-batch", type=int, default=0, help="streams per launch sequence of the two-model bucketed pass (tuning; default 32768)")
-    ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches (tuning)")
+    ap.add_argument("--split-cache", default="", help="HIGH,LOW rows of the split LDS caches of the streaming encoder pass (tuning; see --cache-rows)")
     ap.add_argument("--host-data", action="store_true", help="build the input with tests/workload.py on the host instead of on the GPU (same bytes; "
                     "keeps the tens of thousands of small torch kernels of the GPU generator out of profiler runs)")
     ap.add_argument("--input-cache", default="", help="with --host-data: directory that keeps the generated blocks between runs (profiler passes)")
@@ -575,12 +578,13 @@ def main():
     shard_text = (f"{total_streams} independent {L} B streams in total, split into contiguous ranges over the GPUs ({N} on this rank)" if strong
                   else f"{N} independent {L} B streams per GPU")
 
-    sub_steps = min(args.steps, 6)       # the sub-records time fewer steps than the headline's K (their own "steps" says how many)
+    sub_steps = min(args.steps, 5)       # the sub-records time fewer steps than the headline's K and warm up once (their "steps" says how many;
+    sub_warm = min(args.warmup, 1)       # the placement search's untimed decodes come before either)
 
-    def pair_record(name, d_in=d_in, traffic_name=None, byte_order=None, steps=None):
+    def pair_record(name, d_in=d_in, traffic_name=None, byte_order=None, steps=None, warmup=None):
         """One encode+decode configuration on every rank: verify, time (max over ranks), at world > 1 gather the coded streams
         to rank 0 and check them there.  Returns (record for rank 0, bit-exact on all ranks)."""
-        res, codec, outs = run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, traffic_name=traffic_name, byte_order=byte_order, steps=steps)
+        res, codec, outs = run_pair_config(torch, da, po, name, d_in, N, L, args, dev, barrier, traffic_name=traffic_name, byte_order=byte_order, steps=steps, warmup=warmup)
         elapsed = sharding.max_over_ranks(res["elapsed"], dev)
         coded_all, ok_count = sharding.sum_over_ranks([res["coded_total"], int(res["ok"])], dev)
         ok_all = ok_count == world
@@ -671,7 +675,7 @@ def main():
         sub = {}
         if args.config == "all":
             # configs[2] on the same streams; at world > 1 this is configs[4]'s second option set, with its own scatter/gather record
-            r2, ok2 = pair_record("mixing", steps=sub_steps)
+            r2, ok2 = pair_record("mixing", steps=sub_steps, warmup=sub_warm)
             r2 = dict(r2)
             r2.update({"workload": "BASELINE configs[2]: same streams, TestContextMixing: context map cm[i]=i&63, utf8, block type 1, dynamic_context_mixing=2 (BASELINE configs[2])",
                        "unit": "MB/s encode+decode"})
@@ -685,7 +689,7 @@ def main():
             with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
                 rtu_t = torch.from_numpy(np.frombuffer(f.read(), dtype=np.uint8).copy()).to(dev)
             d_bin = device_blocks(torch, rtu_t, first, N, L)
-            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", steps=sub_steps)
+            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", steps=sub_steps, warmup=sub_warm)
             rb = dict(rb)
             rb.update({"workload": f"BASELINE configs[1] options on non-text input: {N} x {L} B streams cut from testdata/random_then_unicode (stride 4099, 1% perturbation: random bytes and multi-script "
                                    "UTF-8), TestSimple options as the headline, the decoder's table order learned from this data like the headline's (byte_order)", "unit": "MB/s encode+decode"})

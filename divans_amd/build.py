@@ -43,7 +43,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags_now():
+    return " ".join(FLAGS + os.environ.get("DIVANS_EXTRA_HIPCC_FLAGS", "").split())
+
+
 def is_stale():
+    """sources or headers newer than the library -- or the library was built with other flags (e.g. the other value of
+    DIVANS_WITH_EXPERIMENTAL_DECODERS): the flavour on disk must be the one asked for"""
+    tag = os.path.join(OBJ, "flags.txt")
+    if not os.path.exists(tag) or open(tag).read() != _flags_now():
+        return True
     return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
@@ -55,7 +64,7 @@ def build(force=False, verbose=False):
     extra = os.environ.get("DIVANS_EXTRA_HIPCC_FLAGS", "").split()
     headers = _headers()
     flags_tag = os.path.join(OBJ, "flags.txt")
-    flags_now = " ".join(FLAGS + extra)
+    flags_now = _flags_now()
     if not os.path.exists(flags_tag) or open(flags_tag).read() != flags_now:
         force = True
 

@@ -68,7 +68,11 @@ int usable_threads() {
 }
 
 // A persistent pool: the calls below run dozens of short parallel sections per call (per slice: staging, assembly, copy-out),
-// and creating the threads each time costs more than the sections themselves.
+// and creating the threads each time costs more than the sections themselves.  The pool is the process's cores, shared by every
+// device: SEVERAL sections may be open at once (one per calling thread -- the device threads of a call that names all devices, or a
+// caller's own threads on different devices), each with its own width, i.e. its budget of threads; an idle worker joins whichever
+// open section still has items and fewer helpers than its width.  (Until round 6 a section held the whole pool: eight device
+// threads took turns for their host halves.)
 class ThreadPool {
 public:
     explicit ThreadPool(int workers) { for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); }); }
@@ -79,43 +83,42 @@ public:
     }
     int workers() const { return (int)threads_.size(); }
     // body(i) for i in [0, n) on at most `width` threads (the caller is one of them); returns when all are done
-    // Calls on different devices share the pool (it is the process's cores, not a device's): their sections take turns.
     void run(size_t n, int width, const std::function<void(size_t)>& body) {
         if (n == 0) return;
         const int helpers = (int)std::min<size_t>((size_t)std::max(0, std::min(width, workers() + 1) - 1), n - 1);
         if (helpers == 0) { for (size_t i = 0; i < n; ++i) body(i); return; }
-        std::lock_guard<std::mutex> turn(run_mu_);
+        Section sec; sec.body = &body; sec.n = n; sec.want = helpers;
+        { std::lock_guard<std::mutex> l(mu_); open_.push_back(&sec); }
+        if (helpers == 1) cv_.notify_one(); else cv_.notify_all();
+        for (size_t i = sec.next.fetch_add(1); i < n; i = sec.next.fetch_add(1)) body(i);
         std::unique_lock<std::mutex> l(mu_);
-        body_ = &body; n_ = n; next_.store(0); wanted_ = helpers; active_ = 0; epoch_ += 1;
-        l.unlock();
-        cv_.notify_all();
-        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) body(i);
-        l.lock();
-        done_cv_.wait(l, [this] { return wanted_ == 0 && active_ == 0; });
-        body_ = nullptr;
+        open_.erase(std::find(open_.begin(), open_.end(), &sec));      // no worker joins from here on
+        done_cv_.wait(l, [&] { return sec.active == 0; });              // the ones that did have left `sec` (it lives on this stack frame)
     }
 private:
+    struct Section { const std::function<void(size_t)>* body = nullptr; size_t n = 0; std::atomic<size_t> next{0}; int want = 0, joined = 0, active = 0; };
+    Section* pick() {          // mu_ held: an open section with items left and room for another helper
+        for (Section* s : open_) if (s->joined < s->want && s->next.load(std::memory_order_relaxed) < s->n) return s;
+        return nullptr;
+    }
     void loop() {
-        unsigned long seen = 0;
+        std::unique_lock<std::mutex> l(mu_);
         for (;;) {
-            std::unique_lock<std::mutex> l(mu_);
-            cv_.wait(l, [&] { return stop_ || (epoch_ != seen && wanted_ > 0); });
+            Section* sec = nullptr;
+            cv_.wait(l, [&] { return stop_ || (sec = pick()) != nullptr; });
             if (stop_) return;
-            seen = epoch_;
-            wanted_ -= 1; active_ += 1;
-            const std::function<void(size_t)>* body = body_; const size_t n = n_;
+            sec->joined += 1; sec->active += 1;
             l.unlock();
-            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*body)(i);
+            for (size_t i = sec->next.fetch_add(1); i < sec->n; i = sec->next.fetch_add(1)) (*sec->body)(i);
             l.lock();
-            active_ -= 1;
-            if (wanted_ == 0 && active_ == 0) done_cv_.notify_all();
+            sec->active -= 1;
+            if (sec->active == 0) done_cv_.notify_all();
         }
     }
     std::vector<std::thread> threads_;
-    std::mutex run_mu_;        // one parallel section at a time
     std::mutex mu_; std::condition_variable cv_, done_cv_;
-    const std::function<void(size_t)>* body_ = nullptr; size_t n_ = 0; std::atomic<size_t> next_{0};
-    int wanted_ = 0, active_ = 0; unsigned long epoch_ = 0; bool stop_ = false;
+    std::vector<Section*> open_;
+    bool stop_ = false;
 };
 ThreadPool& thread_pool() { static ThreadPool p(usable_threads() - 1); return p; }
 
@@ -351,10 +354,15 @@ size_t divans_batch_compress_bound(size_t n) {
     return 16 + 8 + 3 + payload + 3 * (payload / 16 + 8) + 64;
 }
 
-int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const* inputs, const size_t* sizes, size_t n_streams,
-                          uint8_t* out, size_t out_cap, size_t* out_offsets, size_t* out_sizes, divans_batch_timing* timing) {
-    if (!opt || (!inputs && n_streams) || (!sizes && n_streams) || !out || !out_offsets || !out_sizes) return set_last_error(DIVANS_GPU_EINVAL, "null argument");
-    if (n_streams == 0) return 0;
+}  // extern "C"
+
+namespace {
+
+// One device's share of a compress call (the whole call when it names one device).  `keep` != null: the containers stay in *keep
+// (one vector per stream) and the caller gathers them -- the all-devices form, whose output offsets depend on every device's sizes.
+int compress_on_device(const divans_batch_options* opt, const uint8_t* const* inputs, const size_t* sizes, size_t n_streams,
+                       uint8_t* out, size_t out_cap, size_t* out_offsets, size_t* out_sizes, divans_batch_timing* timing,
+                       std::vector<std::vector<uint8_t>>* keep) {
     if (n_streams >= (1u << 24)) return set_last_error(DIVANS_GPU_EINVAL, "too many streams in one batch");
     const double t_begin = now_ms();
     const divans_host::StreamOptions so = to_stream_options(*opt);
@@ -504,10 +512,13 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         if (k + kLanes < ns) { rc = issue(k + kLanes); if (rc) return rc; }
     }
     const double t_out0 = now_ms();
-    size_t pos = 0;
-    for (size_t i = 0; i < n_streams; ++i) { out_offsets[i] = pos; out_sizes[i] = results[i].size(); pos += results[i].size(); }
-    if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
-    parallel_for(n_streams, opt->host_threads, [&](size_t i) { stream_copy(out + out_offsets[i], results[i].data(), results[i].size()); });
+    if (keep) *keep = std::move(results);
+    else {
+        size_t pos = 0;
+        for (size_t i = 0; i < n_streams; ++i) { out_offsets[i] = pos; out_sizes[i] = results[i].size(); pos += results[i].size(); }
+        if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
+        parallel_for(n_streams, opt->host_threads, [&](size_t i) { stream_copy(out + out_offsets[i], results[i].data(), results[i].size()); });
+    }
     const double t_end = now_ms();
     ov.host(t_out0, t_end); g_phases[PH_GATHER] += t_end - t_out0;
     if (timing) {
@@ -517,11 +528,134 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     return 0;
 }
 
+// A decompress call that names all devices parses every container before the devices start (the output offsets of a device's range are
+// the decoded sizes of everything in front of it): the device shares then take the parsed streams and their first output offset from here.
+struct PreParsed { divans_host::ParsedStream* parsed; size_t pos0; size_t index_base; };
+
+int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* containers, const size_t* sizes, size_t n_streams,
+                         uint8_t* out, size_t out_cap, size_t* out_offsets, size_t* out_sizes, divans_batch_timing* timing, const PreParsed* pre);
+
+// ---- all devices behind one call (divans_batch_options::device = DIVANS_BATCH_ALL_DEVICES) --------------------------------------------
+// The streams are cut into contiguous ranges, one per device -- range r of D is [n * r / D, n * (r + 1) / D), the rule of
+// divans_amd/sharding.py shard_bounds and SURVEY.md 8e -- every range is driven by its own thread through that device's lanes, exactly
+// as a single-device call would, and the outputs land in stream order.  The host threads are divided between the device threads
+// (a budget each, open at the same time: ThreadPool); nothing moves between devices.  The reference's analogue: independent
+// compressor / decompressor states, one per thread (src/ffi/interface.rs:49-50, src/parallel_decompressor.rs:55-141).
+struct DeviceShare { size_t b = 0, e = 0; int device = 0; int rc = 0; std::string err; divans_batch_timing t = {0, 0, 0, 0}; double phases[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+
+int plan_shares(const divans_batch_options* opt, size_t n_streams, std::vector<DeviceShare>& shares, divans_batch_options& per_device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_last_error(DIVANS_GPU_EHIP, "no HIP device: the divans batch interface has no CPU fallback");
+    const size_t D = std::max<size_t>(1, std::min<size_t>((size_t)ndev, n_streams));
+    shares.resize(D);
+    for (size_t r = 0; r < D; ++r) { shares[r].b = n_streams * r / D; shares[r].e = n_streams * (r + 1) / D; shares[r].device = (int)r; }
+    per_device = *opt;
+    const int total = opt->host_threads > 0 ? opt->host_threads : usable_threads();
+    per_device.host_threads = std::max(1, total / (int)D);       // a device thread's budget; the budgets are open at the same time
+    return 0;
+}
+
+template <typename Body>
+void run_shares(std::vector<DeviceShare>& shares, Body&& body) {
+    int before = -1;
+    const bool have_before = hipGetDevice(&before) == hipSuccess;
+    auto one = [&](DeviceShare& sh) {
+        sh.rc = body(sh);
+        if (sh.rc) sh.err = divans_gpu_last_error();      // the message lives in the device thread: bring it home
+        divans_batch_last_phases(sh.phases, 8);
+    };
+    std::vector<std::thread> ts;
+    for (size_t r = 1; r < shares.size(); ++r) ts.emplace_back([&, r] { one(shares[r]); });
+    one(shares[0]);                                       // the calling thread drives the first device itself
+    for (auto& t : ts) t.join();
+    if (have_before) (void)hipSetDevice(before);          // the caller's current device is not ours to change
+}
+
+int finish_shares(const std::vector<DeviceShare>& shares, double t_begin, divans_batch_timing* timing) {
+    const DeviceShare* slowest = &shares[0];
+    for (const DeviceShare& sh : shares) {
+        if (sh.rc) return set_last_error(sh.rc, "device " + std::to_string(sh.device) + " (streams " + std::to_string(sh.b) + ".." + std::to_string(sh.e) + "): " + sh.err);
+        if (sh.t.total_ms > slowest->t.total_ms) slowest = &sh;
+    }
+    for (int i = 0; i < 8; ++i) g_phases[i] = slowest->phases[i];       // divans_batch_last_phases: the slowest device's thread
+    if (timing) { *timing = slowest->t; timing->total_ms = now_ms() - t_begin; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const* inputs, const size_t* sizes, size_t n_streams,
+                          uint8_t* out, size_t out_cap, size_t* out_offsets, size_t* out_sizes, divans_batch_timing* timing) {
+    if (!opt || (!inputs && n_streams) || (!sizes && n_streams) || !out || !out_offsets || !out_sizes) return set_last_error(DIVANS_GPU_EINVAL, "null argument");
+    if (n_streams == 0) return 0;
+    if (opt->device >= 0) return compress_on_device(opt, inputs, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
+    if (opt->device != DIVANS_BATCH_ALL_DEVICES) return set_last_error(DIVANS_GPU_EINVAL, "device must be a HIP device or DIVANS_BATCH_ALL_DEVICES");
+    const double t_begin = now_ms();
+    std::vector<DeviceShare> shares; divans_batch_options po;
+    int rc = plan_shares(opt, n_streams, shares, po); if (rc) return rc;
+    std::vector<std::vector<std::vector<uint8_t>>> kept(shares.size());
+    run_shares(shares, [&](DeviceShare& sh) {
+        divans_batch_options o = po; o.device = sh.device;
+        return compress_on_device(&o, inputs + sh.b, sizes + sh.b, sh.e - sh.b, nullptr, 0, out_offsets + sh.b, out_sizes + sh.b, &sh.t, &kept[&sh - shares.data()]);
+    });
+    rc = finish_shares(shares, t_begin, nullptr); if (rc) return rc;
+    // the containers of all devices, in stream order
+    const double tg = now_ms();
+    size_t pos = 0;
+    std::vector<const std::vector<uint8_t>*> flat(n_streams);
+    for (size_t r = 0; r < shares.size(); ++r)
+        for (size_t i = shares[r].b; i < shares[r].e; ++i) { flat[i] = &kept[r][i - shares[r].b]; out_offsets[i] = pos; out_sizes[i] = flat[i]->size(); pos += flat[i]->size(); }
+    if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
+    parallel_for(n_streams, opt->host_threads, [&](size_t i) { stream_copy(out + out_offsets[i], flat[i]->data(), flat[i]->size()); });
+    g_phases[PH_GATHER] += now_ms() - tg;
+    return finish_shares(shares, t_begin, timing);
+}
+
 int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* const* containers, const size_t* sizes, size_t n_streams,
                             uint8_t* out, size_t out_cap, size_t* out_offsets, size_t* out_sizes, divans_batch_timing* timing) {
     if (!opt || (!containers && n_streams) || (!sizes && n_streams) || !out || !out_offsets || !out_sizes) return set_last_error(DIVANS_GPU_EINVAL, "null argument");
     if (n_streams == 0) return 0;
+    if (opt->device >= 0) return decompress_on_device(opt, containers, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
+    if (opt->device != DIVANS_BATCH_ALL_DEVICES) return set_last_error(DIVANS_GPU_EINVAL, "device must be a HIP device or DIVANS_BATCH_ALL_DEVICES");
     const double t_begin = now_ms();
+    std::vector<DeviceShare> shares; divans_batch_options po;
+    int rc = plan_shares(opt, n_streams, shares, po); if (rc) return rc;
+    // every container's framing, CRC and CMD coder first: the decoded sizes place each device's range in the output
+    std::vector<divans_host::ParsedStream> parsed(n_streams);
+    std::vector<int> status(n_streams, 0);
+    {
+        divans_host::ParseMemo memo;
+        parallel_for(n_streams, opt->host_threads, [&](size_t i) {
+            status[i] = (int)divans_host::parse_container_host(containers[i], sizes[i], opt->skip_crc != 0, (size_t)1 << 30, parsed[i], nullptr, &memo, true);
+        });
+    }
+    size_t pos = 0;
+    for (size_t i = 0; i < n_streams; ++i) {
+        if (status[i] != divans_host::PARSE_OK) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ECORRUPT, "container " + std::to_string(i) + " is truncated, corrupt or not a literal-only stream"); }
+        out_offsets[i] = pos; pos += parsed[i].total;
+    }
+    if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
+    const double parse_ms = now_ms() - t_begin;
+    run_shares(shares, [&](DeviceShare& sh) {
+        divans_batch_options o = po; o.device = sh.device;
+        const PreParsed pre = {parsed.data() + sh.b, out_offsets[sh.b], sh.b};
+        return decompress_on_device(&o, containers + sh.b, sizes + sh.b, sh.e - sh.b, out, out_cap, out_offsets + sh.b, out_sizes + sh.b, &sh.t, &pre);
+    });
+    rc = finish_shares(shares, t_begin, timing);
+    if (rc == 0) { g_phases[PH_PARSE_OR_PLAN] += parse_ms; if (timing) timing->host_serial_ms += parse_ms; }
+    return rc;
+}
+
+}  // extern "C"
+
+namespace {
+
+int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* containers, const size_t* sizes, size_t n_streams,
+                         uint8_t* out, size_t out_cap, size_t* out_offsets, size_t* out_sizes, divans_batch_timing* timing, const PreParsed* pre) {
+    const double t_begin = now_ms();
+    const size_t index_base = pre ? pre->index_base : 0;      // (error messages name the caller's container index)
     HIP_OR_FAIL(hipSetDevice(opt->device));
     LanePool& lane_pool = registry().of(opt->device);
     std::lock_guard<std::mutex> pool_lock(lane_pool.mu);
@@ -539,10 +673,11 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     const size_t n_blocks = (n_streams + per - 1) / per;      // parse blocks; a block is then cut into the slices that are issued
     struct Range { size_t b, e; };
     std::vector<Range> slices;                                // in issue order; slice k runs on lane k % kLanes
-    std::vector<divans_host::ParsedStream> parsed(n_streams);
+    std::vector<divans_host::ParsedStream> own_parsed(pre ? 0 : n_streams);
+    divans_host::ParsedStream* const parsed = pre ? pre->parsed : own_parsed.data();
     std::vector<int> status(n_streams, 0);
     divans_host::ParseMemo memo;     // equal-length streams of one producer carry the same CMD bytes: decode them once (host_stream.h)
-    size_t pos = 0;
+    size_t pos = pre ? pre->pos0 : 0;
 
     struct Group { divans_lit_config cfg; int cfg_id; uint32_t bound; std::vector<size_t> members; size_t in_bytes = 0, out_bytes = 0, in_base = 0, out_base = 0, idx_base = 0; };
     std::vector<std::vector<Group>> slice_groups;
@@ -555,7 +690,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
         size_t sb = b, acc = 0;
         for (size_t i = b; i < e; ++i) {
             const size_t need = decode_bytes_of(i);
-            if (need > budget * 2) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ENOMEM, "container " + std::to_string(i) + " does not fit the device by itself"); }
+            if (need > budget * 2) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ENOMEM, "container " + std::to_string(index_base + i) + " does not fit the device by itself"); }
             if (i > sb && acc + need > budget) { slices.push_back({sb, i}); sb = i; acc = 0; }
             acc += need;
         }
@@ -566,6 +701,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
 
     auto parse = [&](size_t kb) -> int {
         const size_t b = kb * per, e = std::min(n_streams, b + per);
+        if (pre) return cut_block(b, e);        // parsed (and found whole) before the devices started
         const double t0 = now_ms();
         parallel_for(e - b, opt->host_threads, [&](size_t j) {
             const size_t i = b + j;
@@ -573,7 +709,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
         });
         ov.host(t0, now_ms()); g_phases[PH_PARSE_OR_PLAN] += now_ms() - t0;
         for (size_t i = b; i < e; ++i)
-            if (status[i] != divans_host::PARSE_OK) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ECORRUPT, "container " + std::to_string(i) + " is truncated, corrupt or not a literal-only stream"); }
+            if (status[i] != divans_host::PARSE_OK) { out_sizes[i] = (size_t)-1; return set_last_error(DIVANS_GPU_ECORRUPT, "container " + std::to_string(index_base + i) + " is truncated, corrupt or not a literal-only stream"); }
         return cut_block(b, e);
     };
 
@@ -673,7 +809,7 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
             if ((st & DIVANS_GPU_STATUS_BAD_STREAM) || flagged) {
                 size_t first = g.members.front();
                 for (size_t j = 0; j < g.members.size(); ++j) if (L.h_flags.as<uint8_t>()[g.idx_base + j]) { first = g.members[j]; out_sizes[first] = (size_t)-1; break; }
-                return set_last_error(DIVANS_GPU_ECORRUPT, "the LIT stream of container " + std::to_string(first) + " failed the decoder's integrity check");
+                return set_last_error(DIVANS_GPU_ECORRUPT, "the LIT stream of container " + std::to_string(index_base + first) + " failed the decoder's integrity check");
             }
         }
         if (e > b) {      // the host threads bring the slice home, 256 KiB at a time
@@ -705,6 +841,10 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     }
     return 0;
 }
+
+}  // namespace
+
+extern "C" {
 
 // Frees what the batch calls keep between calls (HIP streams, codecs, device scratch, page-locked staging buffers): of every device /
 // of one.  Waits for a call that is running on a device it releases.

@@ -356,7 +356,10 @@ constexpr uint32_t MW_IN_BYTES = 32u * MW_IN_STRIDE;
 // wave on the same SIMD only halves both, while a 32 768-stream sequence is exactly one wave for each of the chip's 1024 SIMDs.  Left
 // to the dispatcher, a CU's four workgroups do not always land on four different SIMDs: round 2's version happened to be safe because
 // its 257 registers allowed one wave per SIMD anyway; with 169 the kernel took 39.6 instead of 24.5 ms until this attribute came.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void mix_weights_kernel(const MixBucketBatch b) {
+// A sequence of more than 32 768 streams (round 6: 65 536 where the device has room for its work arrays) is two waves for every SIMD --
+// the WPE = 2 instance, pinned to exactly that: the second wave issues into the first one's dependency stalls.
+template <int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mix_weights_kernel(const MixBucketBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_in[2u * MW_IN_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t lds_out[32u * MW_OUT_STRIDE];
     const uint32_t lane = threadIdx.x;
@@ -455,7 +458,8 @@ hipError_t launch_bucket_mix_model(const MixBucketBatch& b, uint32_t num_cus, hi
         v.sfs = (bk_u32x2*)b.maxes[model]; v.sf = b.maxes[model]; v.sf_stride = b.pos_stride;
         launch_bucket_unsort32(v, st);
     }
-    hipLaunchKernelGGL(mix_weights_kernel, dim3((b.n_streams + 31u) / 32u), dim3(64), 0, st, b);
+    if ((b.n_streams + 31u) / 32u > num_cus * 4u) hipLaunchKernelGGL(mix_weights_kernel<2>, dim3((b.n_streams + 31u) / 32u), dim3(64), 0, st, b);
+    else hipLaunchKernelGGL(mix_weights_kernel<1>, dim3((b.n_streams + 31u) / 32u), dim3(64), 0, st, b);
     return hipGetLastError();
 }
 

@@ -38,11 +38,19 @@ typedef struct divans_batch_options {      /* DivansCompressorOptions fields the
     uint8_t has_literal_adaptation;
     divans_speed literal_adaptation[4];
     uint32_t call_buffer_size;             /* output buffer a per-stream caller would pass to each call (Mux slicing); default 65536 */
-    int32_t device;                        /* HIP device */
-    int32_t host_threads;                  /* threads for the CMD coders and the framing; 0 = hardware concurrency */
+    int32_t device;                        /* HIP device, or DIVANS_BATCH_ALL_DEVICES: the call shards its streams over every visible device (below) */
+    int32_t host_threads;                  /* threads for the CMD coders and the framing; 0 = what the process is granted (affinity, cgroup quota).
+                                              With DIVANS_BATCH_ALL_DEVICES: the total, divided evenly between the devices' driving threads */
     uint8_t skip_crc;                      /* decompress only */
 } divans_batch_options;
 void divans_batch_options_default(divans_batch_options *o);
+/* divans_batch_options::device = DIVANS_BATCH_ALL_DEVICES: ONE call drives every visible HIP device (north_star: "work shards naturally by
+ * metablock").  The n streams are cut into contiguous ranges, range r of D devices = [n * r / D, n * (r + 1) / D)
+ * (D = min(devices, n)); each range runs on its own device through that device's lanes, driven by its own thread inside the call,
+ * with its share of the host threads; outputs, offsets and sizes come back in stream order exactly as from a one-device call -- the
+ * containers / payloads are bit-identical to D calls on the D ranges, and to one call on one device.  No data moves between devices.
+ * divans_batch_timing then describes the slowest device's share (total_ms: the whole call).  A failure names the device and the range. */
+#define DIVANS_BATCH_ALL_DEVICES (-1)
 
 typedef struct divans_batch_timing {       /* milliseconds, wall clock */
     double total_ms;

@@ -18,9 +18,12 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemc
 #define hipEventDisableTiming 2u
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : "invalid value"; }
-// two "devices", the current one per thread as in the HIP runtime (the batch interface keeps one set of lanes per device)
+// FAKEHIP_DEVICES "devices" (environment, default 2, at most 8), the current one per thread as in the HIP runtime (the batch interface
+// keeps one set of lanes per device and can shard one call over all of them)
+static inline int fake_hip_device_count() { static const int n = [] { const char* e = std::getenv("FAKEHIP_DEVICES"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }(); return n; }
 static inline int& fake_hip_current_device() { static thread_local int d = 0; return d; }
-static inline hipError_t hipSetDevice(int d) { if (d < 0 || d > 1) return hipErrorInvalidValue; fake_hip_current_device() = d; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = fake_hip_device_count(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= fake_hip_device_count()) return hipErrorInvalidValue; fake_hip_current_device() = d; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = fake_hip_current_device(); return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }

@@ -7,6 +7,9 @@
 // devices = 2: the rounds run on two threads at once, one per stand-in device (fakehip knows two): the per-device lane pools of batch.cpp
 //  -- concurrent calls on different devices, divans_batch_release / _release_device from one thread while the other is
 // inside a call -- under ThreadSanitizer.
+// devices = -D (D = 2 .. 8): D stand-in devices; one thread makes every call with divans_batch_options::device = DIVANS_BATCH_ALL_DEVICES --
+// the call cuts its streams into D contiguous ranges and drives every device from its own thread -- and compares
+// what comes back with D one-device calls on the D ranges, while a second thread keeps device D - 1 busy with calls of its own.
 //
 // Per round: a batch of streams of mixed lengths (empty, tiny, around the 64 KiB class bound, now and then several hundred KB; every
 // fourth round incompressible ones) under
@@ -87,6 +90,7 @@ static Batch random_batch(const Bytes& data, size_t max_streams, size_t from = 0
 #define FAIL(...) do { std::fprintf(stderr, "device %d: ", t_device); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, " (%s)\n", divans_gpu_last_error()); return 1; } while (0)
 
 static std::atomic<size_t> n_containers{0}, bytes_in{0};
+static int g_fake_devices = 2;
 
 // the rounds of one device (its own thread when there are two)
 static int run_rounds(const Bytes& data, size_t noise_from, uint64_t seed, long rounds, size_t largest, int device) {
@@ -123,7 +127,22 @@ static int run_rounds(const Bytes& data, size_t noise_from, uint64_t seed, long 
             }
             n_containers += x.len.size(); for (size_t l : x.len) bytes_in += l;
         }
-        if (round % 3 == 1) { if ((round / 3) & 1) divans_batch_release_device(device); else divans_batch_release(); }    // (the other thread may be inside a call)
+        if (device == DIVANS_BATCH_ALL_DEVICES) {
+            // one call over all devices == one call per device on the contiguous ranges [n r / D, n (r + 1) / D), container for container
+            const size_t n = a.len.size(), D = std::min<size_t>((size_t)g_fake_devices, n);
+            for (size_t r = 0; r < D; ++r) {
+                const size_t b0 = n * r / D, e0 = n * (r + 1) / D;
+                divans_batch_options o1 = oa; o1.device = (int)r;
+                size_t cap = 0; for (size_t i = b0; i < e0; ++i) cap += divans_batch_compress_bound(a.len[i]);
+                Bytes out(cap + 1); std::vector<size_t> off(e0 - b0), sz(e0 - b0);
+                if (divans_batch_compress(&o1, a.ptr.data() + b0, a.len.data() + b0, e0 - b0, out.data(), out.size(), off.data(), sz.data(), nullptr) != 0)
+                    FAIL("round %ld: the one-device call on range %zu failed", round, r);
+                for (size_t i = b0; i < e0; ++i)
+                    if (sz[i - b0] != containers[i].size() || std::memcmp(out.data() + off[i - b0], containers[i].data(), sz[i - b0]) != 0)
+                        FAIL("round %ld: container %zu of the all-devices call differs from device %zu's own call", round, i, r);
+            }
+        }
+        if (round % 3 == 1) { if ((round / 3) & 1) divans_batch_release_device(device < 0 ? 0 : device); else divans_batch_release(); }    // (the other thread may be inside a call)
         // both batches interleaved through one decompress call
         std::vector<size_t> order;                               // index into `containers`
         { size_t ia = 0, ib = 0; while (ia < a.len.size() || ib < b.len.size()) { if (ib < b.len.size() && (ia >= a.len.size() || (rnd() & 3) == 0)) order.push_back(a.len.size() + ib++); else order.push_back(ia++); } }
@@ -178,10 +197,18 @@ int main(int argc, char** argv) {
     const long rounds = std::strtol(argv[3], nullptr, 0);
     const size_t largest = argc > 4 ? (size_t)std::strtoul(argv[4], nullptr, 0) : 700;
     const int devices = argc > 5 ? std::atoi(argv[5]) : 1;
+    if (devices < 0) { g_fake_devices = -devices; setenv("FAKEHIP_DEVICES", std::to_string(-devices).c_str(), 1); }      // before the first HIP call
     // the oracle is single-threaded test infrastructure with lazily built tables (CRC-32C, context lookups): build them before the threads start
     { Bytes warm; divans_batch_options wo; divans_batch_options_default(&wo); wo.dynamic_context_mixing = 2; (void)oracle_container(wo, data.data(), 3000, warm); }
     int rc = 0;
-    if (devices <= 1) rc = run_rounds(data, noise_from, seed ^ 0x5bd1e995u, rounds, largest, 0);
+    if (devices < 0) {
+        std::atomic<int> failed{0};
+        std::thread other([&]() { if (run_rounds(data, noise_from, seed ^ 0x9e3779b9u, rounds, std::min<size_t>(largest, 40), -devices - 1)) failed = 1; });
+        if (run_rounds(data, noise_from, seed ^ 0x5bd1e995u, rounds, largest, DIVANS_BATCH_ALL_DEVICES)) failed = 1;
+        other.join();
+        rc = failed.load();
+    }
+    else if (devices <= 1) rc = run_rounds(data, noise_from, seed ^ 0x5bd1e995u, rounds, largest, 0);
     else {
         std::atomic<int> failed{0};
         std::vector<std::thread> ts;
@@ -191,6 +218,7 @@ int main(int argc, char** argv) {
     }
     divans_batch_release();
     if (rc) return rc;
-    std::printf("%ld rounds on %d device(s): %zu containers, %zu bytes, all equal to the oracle's and back\n", rounds, devices > 1 ? 2 : 1, n_containers.load(), bytes_in.load());
+    std::printf("%ld rounds on %d device(s)%s: %zu containers, %zu bytes, all equal to the oracle's and back\n", rounds, devices < 0 ? -devices : (devices > 1 ? 2 : 1),
+                devices < 0 ? " through all-devices calls (+ a thread of its own on the last device)" : "", n_containers.load(), bytes_in.load());
     return 0;
 }

@@ -35,7 +35,7 @@ static int fail(int code, const char* msg) { g_err = msg; return code; }
 
 extern "C" int divans_gpu_codec_create(divans_gpu_codec** out, const divans_lit_config* cfg, int device, void* hip_stream, uint32_t max_stream_len) {
     (void)hip_stream;
-    if (!out || !cfg || device < 0 || device > 1 || max_stream_len == 0) return fail(DIVANS_GPU_EINVAL, "bad argument");     // two stand-in devices (fakehip)
+    if (!out || !cfg || device < 0 || device > 7 || max_stream_len == 0) return fail(DIVANS_GPU_EINVAL, "bad argument");     // up to eight stand-in devices (fakehip)
     for (const auto& s : cfg->literal_adaptation)
         if (s.inc < 0) return fail(DIVANS_GPU_EINVAL, "negative increment");      // divans_gpu_speed_accepted
     divans_gpu_codec* c = new divans_gpu_codec();

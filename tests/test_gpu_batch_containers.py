@@ -129,3 +129,39 @@ def test_batch_decompress_with_damaged_containers_in_bulk(corpus):
     # and the library is still in working order
     back, _ = da.batch_decompress(sets[0], total, da.batch_options())
     assert all((back[i] == inputs[i]).all() for i in range(6))
+
+
+def test_one_call_over_all_devices_equals_one_call_per_device(corpus):
+    """VERDICT r05 item 3: divans_batch_options::device = DIVANS_BATCH_ALL_DEVICES (-1) -- the split over the node's GPUs sits behind the C ABI:
+    contiguous stream ranges [n r / D, n (r + 1) / D), one driving thread per device inside the call, outputs in stream order.  The
+    containers and the payloads must be bit-identical to one-device calls (on a one-GPU box D = 1: the same path, one share)."""
+    import torch
+    import divans_amd as da
+    import workload
+    rng = np.random.default_rng(23)
+    n = 257
+    blocks = workload.make_blocks(corpus, 40, n, block_len=20000)
+    lens = rng.integers(0, 20001, size=n)
+    inputs = [blocks[i, :lens[i]] for i in range(n)]
+    D = torch.cuda.device_count()
+    for opts in (dict(), dict(dynamic_context_mixing=2, force_stride=0, window_size=18)):
+        all_c, t_all = da.batch_compress(inputs, da.batch_options(device=-1, host_threads=6, **opts))
+        assert t_all["total_ms"] > 0
+        ref = []
+        for r in range(D):          # one call per device on its contiguous range
+            b, e = n * r // D, n * (r + 1) // D
+            part, _ = da.batch_compress(inputs[b:e], da.batch_options(device=r, host_threads=6, **opts))
+            ref.extend(part)
+        assert len(all_c) == len(ref) == n
+        for i in range(n):
+            assert all_c[i].size == ref[i].size and (all_c[i] == ref[i]).all(), i
+        back, _ = da.batch_decompress(all_c, int(lens.sum()), da.batch_options(device=-1, host_threads=6))
+        for i in range(n):
+            assert back[i].size == inputs[i].size and (back[i] == inputs[i]).all(), i
+        bad = [c.copy() for c in all_c]
+        victim = n - 2
+        bad[victim][bad[victim].size // 2] ^= 0x20
+        with pytest.raises(da.DivansGpuError, match="container %d|device" % victim):
+            da.batch_decompress(bad, int(lens.sum()), da.batch_options(device=-1))
+    with pytest.raises(da.DivansGpuError):
+        da.batch_compress(inputs[:4], da.batch_options(device=-2))

@@ -995,7 +995,7 @@ def test_row_replay_runs_the_decoders_row_traffic_and_leaves_the_codec_usable(cf
     offsets = (torch.arange(n, dtype=torch.int64, device="cuda") * 4096)
     assert codec.row_replay(d_in, n, 4096, offsets=offsets, sizes=lens) > 0          # ragged batches too
     assert (codec.decode_host(packed, offs, sizes, 4096) == blocks).all() and codec.status() == 0
-    codec.set_decoder(3, (8, 8, 8, 0), (5, 5, 5, 5))             # a cache organisation the replay has no instance for
+    codec.set_decoder(3, (8, 8, 8, 0) if cfg_name == "simple" else (8, 8, 0, 8), (5, 5, 5, 5))      # a cache organisation (a low-row cache) the replay has no instance for
     with pytest.raises(da.DivansGpuError):
         codec.row_replay(d_in, n, 4096)
     codec.close()

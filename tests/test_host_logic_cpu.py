@@ -339,7 +339,8 @@ def test_option_stage_and_state_helpers(lib, corpus):
     assert lib.divans_decode(None, None, 0, None, None, 0, None) == 3
 
 
-@pytest.mark.parametrize("sanitizer,rounds,largest,devices", [("address,undefined", 3, 250, 1), ("thread", 3, 16, 2)])
+@pytest.mark.parametrize("sanitizer,rounds,largest,devices", [("address,undefined", 3, 250, 1), ("thread", 3, 16, 2), ("thread", 1, 40, -4),
+                                                              ("thread", 1, 60, -8), ("address,undefined", 1, 120, -3)])
 def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, devices, tmp_path, corpus):
     """include/divans_batch.h without a GPU: divans_amd/csrc/batch.cpp itself (length classes, slices on lanes, persistent thread pool,
     plans and parsing under the "GPU work", container assembly, error paths), compiled by g++ against a stand-in for the 16 HIP runtime
@@ -348,7 +349,10 @@ def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, devices, 
     has to be named -- under AddressSanitizer + UBSan, and again under ThreadSanitizer.  devices = 2: two host threads, each on its own
     stand-in device, at once -- batch.cpp keeps one set of lanes per device (one process drives all of a node's GPUs; the reference's states
     are independent, src/ffi/interface.rs:49-50), a call on one device does not wait for the other's, and divans_batch_release /
-    _release_device from one thread wait for the other thread's running call."""
+    _release_device from one thread wait for the other thread's running call.  devices = -D: D stand-in devices behind ONE call
+    (divans_batch_options::device = DIVANS_BATCH_ALL_DEVICES, VERDICT r05 item 3): contiguous ranges, one driving thread per device inside the
+    call, each with its budget of the host thread pool; the containers must equal the oracle's AND those of D one-device calls on the D
+    ranges, while another thread keeps the last device busy with calls of its own."""
     exe = hostsim.build_batch_test(sanitizer)
     src = tmp_path / "in.bin"
     corpus.tofile(src)
