@@ -737,7 +737,7 @@ def batch_last_phases():
     """divans_batch_last_phases: dict of the last batch call's host phases in milliseconds"""
     out = (ctypes.c_double * 8)()
     load_library().divans_batch_last_phases(out, 8)
-    return dict(zip(("cmd_coders_ms", "stage_ms", "wait_gpu_ms", "finish_ms", "gather_ms"), (round(float(x), 2) for x in out[:5])))
+    return dict(zip(("cmd_coders_ms", "stage_ms", "wait_gpu_ms", "finish_ms", "gather_ms", "stage_reserve_ms", "stage_copy_ms", "stage_codec_calls_ms"), (round(float(x), 2) for x in out[:8])))
 
 
 def probe_container(container, wire=WIRE_HEAD):

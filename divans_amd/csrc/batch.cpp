@@ -328,7 +328,7 @@ PoolRegistry& registry() { static PoolRegistry r; return r; }
 
 // Where the calling thread's time went in its last call (divans_batch_last_phases): a diagnostic, per thread, overwritten by every call
 thread_local double g_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-enum { PH_PARSE_OR_PLAN = 0, PH_STAGE = 1, PH_WAIT = 2, PH_FINISH = 3, PH_GATHER = 4 };
+enum { PH_PARSE_OR_PLAN = 0, PH_STAGE = 1, PH_WAIT = 2, PH_FINISH = 3, PH_GATHER = 4, PH_SETUP = 5, PH_TEARDOWN = 6 };
 
 // wall-clock bookkeeping of the overlap: host work counts as overlapped while at least one slice is in flight on the GPU
 struct Overlap {
@@ -431,7 +431,10 @@ int compress_on_device(const divans_batch_options* opt, const uint8_t* const* in
             uint64_t* off = L.h_off.as<uint64_t>(); uint32_t* sz = L.h_sz.as<uint32_t>(); uint8_t* dst = L.h_in.as<uint8_t>();
             uint64_t pos = 0;
             for (size_t j = 0; j < m; ++j) { off[j] = pos; sz[j] = (uint32_t)sizes[s.members[j]]; pos += sizes[s.members[j]]; }
+            const double tc0 = now_ms();
+            g_phases[PH_SETUP] += tc0 - t0;                  // (compress: buffer reservations + offsets, part of [1])
             parallel_for(m, opt->host_threads, [&](size_t j) { if (sz[j]) stream_copy(dst + off[j], inputs[s.members[j]], sz[j]); });
+            g_phases[PH_TEARDOWN] += now_ms() - tc0;         // (compress: the copy into page-locked memory, part of [1]; the rest of [1] is enqueueing)
         }
         divans_gpu_codec* codec = nullptr;
         int r = L.codec_for(probe.cfg, s.bound, opt->device, m, &codec); if (r) return r;
@@ -440,12 +443,14 @@ int compress_on_device(const divans_batch_options* opt, const uint8_t* const* in
         HIP_OR_FAIL(hipMemcpyAsync(L.d_sz.p, L.h_sz.p, 4 * m, hipMemcpyHostToDevice, L.stream));
         HIP_OR_FAIL(hipMemsetAsync(L.d_chunks.p, 0, 4ull * m * max_chunks, L.stream));
         r = divans_gpu_codec_clear_status(codec); if (r) return r;          // the codec outlives the call: no bit of an earlier, abandoned slice
+        const double te0 = now_ms();
         r = divans_gpu_lit_encode_batch_chunks(codec, L.d_in.as<uint8_t>(), L.d_off.as<uint64_t>(), L.d_sz.as<uint32_t>(), s.bound, (uint32_t)m,
                                                L.d_slots.as<uint8_t>(), slot, L.d_ooff.as<uint64_t>(), L.d_osz.as<uint32_t>(), L.d_chunks.as<uint32_t>(), max_chunks);
         if (r) return r;
         r = divans_gpu_pack_streams(codec, L.d_slots.as<uint8_t>(), L.d_ooff.as<uint64_t>(), L.d_osz.as<uint32_t>(), (uint32_t)m,
                                     L.d_packed.as<uint8_t>(), L.d_poff.as<uint64_t>(), L.d_total.as<uint64_t>());
         if (r) return r;
+        g_phases[7] += now_ms() - te0;        // (compress: inside the codec's encode + pack entry points, part of [1])
         HIP_OR_FAIL(L.h_status.reserve(64));
         r = divans_gpu_codec_status_async(codec, L.h_status.as<uint32_t>()); if (r) return r;     // read in complete(), behind the lane's event
         // the packed streams are at most slot * m bytes, in practice about half the input: copy what a stream can be at most only
@@ -664,6 +669,7 @@ int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* 
     struct Drain { Lane* l; ~Drain() { for (int i = 0; i < kLanes; ++i) if (l[i].stream) (void)hipStreamSynchronize(l[i].stream); } } drain{lanes};   // no early return with copies in flight
     Overlap ov;
     for (double& v : g_phases) v = 0;
+    const double t_setup0 = now_ms();
     const size_t budget = device_budget();
     // Slices in stream order (the output offsets are the running sum of the decoded sizes): one per lane, 128 .. 8192
     // containers.  While the GPU decodes the slices in flight (concurrently: a stream is a serial chain of tens of
@@ -678,6 +684,7 @@ int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* 
     std::vector<int> status(n_streams, 0);
     divans_host::ParseMemo memo;     // equal-length streams of one producer carry the same CMD bytes: decode them once (host_stream.h)
     size_t pos = pre ? pre->pos0 : 0;
+    g_phases[PH_SETUP] += now_ms() - t_setup0;
 
     struct Group { divans_lit_config cfg; int cfg_id; uint32_t bound; std::vector<size_t> members; size_t in_bytes = 0, out_bytes = 0, in_base = 0, out_base = 0, idx_base = 0; };
     std::vector<std::vector<Group>> slice_groups;
@@ -725,8 +732,8 @@ int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* 
             const uint32_t bound = class_bound(parsed[i].total);
             Group* g = nullptr;
             for (auto& q : groups)    // the memo's configuration ids spare the 25 KB comparison per container
-                if (q.bound == bound && ((q.cfg_id >= 0 && q.cfg_id == parsed[i].cfg_id) || ((q.cfg_id < 0 || parsed[i].cfg_id < 0) && std::memcmp(&q.cfg, &parsed[i].cfg, sizeof(divans_lit_config)) == 0))) { g = &q; break; }
-            if (!g) { groups.emplace_back(); g = &groups.back(); g->cfg = parsed[i].cfg; g->cfg_id = parsed[i].cfg_id; g->bound = bound; }
+                if (q.bound == bound && ((q.cfg_id >= 0 && q.cfg_id == parsed[i].cfg_id) || ((q.cfg_id < 0 || parsed[i].cfg_id < 0) && std::memcmp(&q.cfg, parsed[i].cfg.get(), sizeof(divans_lit_config)) == 0))) { g = &q; break; }
+            if (!g) { groups.emplace_back(); g = &groups.back(); g->cfg = *parsed[i].cfg; g->cfg_id = parsed[i].cfg_id; g->bound = bound; }
             g->members.push_back(i); g->in_bytes += parsed[i].lit_size; g->out_bytes += parsed[i].total;
         }
         if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");

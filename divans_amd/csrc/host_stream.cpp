@@ -992,16 +992,30 @@ int StreamEncoder::flush(uint8_t* out, size_t cap, size_t* out_off) {   // divan
 }
 
 struct ParseMemo::Impl {
-    struct Entry { uint64_t total; int cfg_id; };
+    struct Entry { std::string cmd; uint64_t total; int cfg_id; };
     std::mutex mu;
-    std::unordered_map<std::string, Entry> map;
-    std::vector<std::unique_ptr<divans_lit_config>> cfgs;   // the distinct LIT configurations seen (25 KB each): entries name one by index
+    // keyed by a 64-bit hash of the CMD bytes computed OUTSIDE the lock (a mixing configuration's CMD stream is 4-5 KB: hashing it and copying a
+    // 25 KB configuration under the lock serialised the parsing threads of a batch, round 6); the bytes themselves decide a hit
+    std::unordered_multimap<uint64_t, Entry> map;
+    std::vector<std::shared_ptr<const divans_lit_config>> cfgs;   // the distinct LIT configurations seen (25 KB each): entries name one by index
     static constexpr size_t kMaxEntries = 65536;    // ~100 bytes each: a batch of all-different lengths still fits
     static constexpr size_t kMaxConfigs = 64;
-    int intern(const divans_lit_config& c) {        // under mu
-        for (size_t i = 0; i < cfgs.size(); ++i) if (std::memcmp(cfgs[i].get(), &c, sizeof(c)) == 0) return (int)i;
+    static uint64_t hash(const uint8_t* p, size_t n) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+        for (; i < n; ++i) { h = (h ^ p[i]) * 0x100000001b3ull; }
+        return h ^ (h >> 29);
+    }
+    const Entry* find(uint64_t h, const uint8_t* p, size_t n) const {     // under mu
+        const auto range = map.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it) if (it->second.cmd.size() == n && std::memcmp(it->second.cmd.data(), p, n) == 0) return &it->second;
+        return nullptr;
+    }
+    int intern(std::shared_ptr<const divans_lit_config>& c) {        // under mu; c becomes the interned object
+        for (size_t i = 0; i < cfgs.size(); ++i) if (std::memcmp(cfgs[i].get(), c.get(), sizeof(divans_lit_config)) == 0) { c = cfgs[i]; return (int)i; }
         if (cfgs.size() >= kMaxConfigs) return -1;
-        cfgs.emplace_back(new divans_lit_config(c));
+        cfgs.push_back(c);
         return (int)cfgs.size() - 1;
     }
 };
@@ -1078,17 +1092,21 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
         if (total == 0 && ps.lit_size != 0) return PARSE_CORRUPT;
         return PARSE_OK;
     };
-    std::string key;
+    uint64_t key = 0;
     if (memo) {
-        key.assign((const char*)cmd_ptr, cmd_len);
-        std::lock_guard<std::mutex> g(memo->p_->mu);
-        auto it = memo->p_->map.find(key);
-        if (it != memo->p_->map.end()) {
-            const ParseMemo::Impl::Entry& e = it->second;
-            if (e.total > 0x7fffffffu) return PARSE_UNSUPPORTED;
-            if (e.total > most) return PARSE_CORRUPT;
-            ps.cfg = *memo->p_->cfgs[(size_t)e.cfg_id]; ps.cfg_id = e.cfg_id;
-            return finish(e.total);
+        key = ParseMemo::Impl::hash(cmd_ptr, cmd_len);
+        uint64_t hit_total = 0; bool hit = false;
+        {
+            std::lock_guard<std::mutex> g(memo->p_->mu);
+            if (const ParseMemo::Impl::Entry* e = memo->p_->find(key, cmd_ptr, cmd_len)) {
+                hit = true; hit_total = e->total;
+                ps.cfg = memo->p_->cfgs[(size_t)e->cfg_id]; ps.cfg_id = e->cfg_id;
+            }
+        }
+        if (hit) {
+            if (hit_total > 0x7fffffffu) return PARSE_UNSUPPORTED;
+            if (hit_total > most) return PARSE_CORRUPT;
+            return finish(hit_total);
         }
     }
     // CMD stream on the host
@@ -1120,17 +1138,20 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
         } else return PARSE_UNSUPPORTED;   // Copy / Dict / command- and distance- block switches
         if (cd.starved) return PARSE_CORRUPT;
     }
-    if (have_pm) model.fill_lit_config(ps.cfg, btype);
+    auto fresh = std::make_shared<divans_lit_config>();
+    if (have_pm) model.fill_lit_config(*fresh, btype);
     else {   // LiteralBookKeeping::new defaults, codec/interface.rs:244-262
-        std::memset(&ps.cfg, 0, sizeof(ps.cfg));
-        ps.cfg.btype = btype;
-        for (auto& s : ps.cfg.literal_adaptation) s = divans_speed{0x10, 0x2000};
+        std::memset(fresh.get(), 0, sizeof(divans_lit_config));
+        fresh->btype = btype;
+        for (auto& s : fresh->literal_adaptation) s = divans_speed{0x10, 0x2000};
     }
+    ps.cfg = fresh;
     if (memo) {
         std::lock_guard<std::mutex> g(memo->p_->mu);
         const int id = memo->p_->intern(ps.cfg);
         ps.cfg_id = id;
-        if (id >= 0 && memo->p_->map.size() < ParseMemo::Impl::kMaxEntries) memo->p_->map.emplace(std::move(key), ParseMemo::Impl::Entry{total, id});
+        if (id >= 0 && memo->p_->map.size() < ParseMemo::Impl::kMaxEntries && !memo->p_->find(key, cmd_ptr, cmd_len))
+            memo->p_->map.emplace(key, ParseMemo::Impl::Entry{std::string((const char*)cmd_ptr, cmd_len), total, id});
     }
     return finish(total);
 }

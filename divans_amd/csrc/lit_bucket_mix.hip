@@ -326,7 +326,15 @@ __device__ __forceinline__ uint32_t mix_nibble(Weights& w, uint32_t st_x, uint32
     const int cmax = (int)cm_max, smax = (int)st_max;
     const int p_s = average_rows(cm_s, st_s, cmax, smax, mix_rate);       // frequentist_cdf.rs:58-72, entry sym
     const int p_p = average_rows(cm_p, st_p, cmax, smax, mix_rate);       //   entry sym-1 (0 | 0 -> 0 when sym == 0)
-    const int pmax = average_rows(cmax, smax, cmax, smax, mix_rate);      //   entry 15
+    // entry 15: both rows contribute their own total, so the two products are equal, rs = ro = (cmax * smax) >> sh, and
+    // (rs * mix + rs * (2^15 - mix) + 1) >> 15 = rs whatever the weight -- the third average costs a multiply and a shift
+    int pmax;
+    {
+        const uint32_t prod = __umul24((uint32_t)cmax, (uint32_t)smax);
+        int lz = __clz((int)prod);
+        lz = lz > 17 ? 17 : lz;
+        pmax = (int)(prod >> (17 - lz));
+    }
     const float rp = biased_rcp15(pmax), rc = biased_rcp15(cmax), rs = biased_rcp15(smax);
     const uint32_t qp = scaled_div(p_p, pmax, rp);
     const uint32_t freq = scaled_div(p_s, pmax, rp) - qp - 1u;            // probability/interface.rs:97-108

@@ -87,7 +87,9 @@ void divans_batch_release_device(int device);
 
 /* Diagnostic: where the calling thread's time went in the last batch call, milliseconds: out[0] CMD coders (plans / container
  * parsing), [1] staging into page-locked memory + enqueueing, [2] waiting for the GPU, [3] container assembly / copy-out,
- * [4] final gather of the containers (compress only).  Per calling thread; overwritten by that thread's next call. */
+ * [4] final gather of the containers (compress only); parts of [1], compress: [5] reserving the lane's buffers, [6] the copy of the inputs
+ * into page-locked memory (the rest of [1] is enqueueing copies and launches); decompress: [5] set-up before the first parse.  Per calling
+ * thread (with DIVANS_BATCH_ALL_DEVICES: the slowest device's thread); overwritten by that thread's next call. */
 void divans_batch_last_phases(double *out, int n);
 
 /* Why does (or does not) this library take a container?  Host only, no GPU work: header, Mux framing, end marker, CRC-32C

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 run_config () {
   local CFG=$1; shift
   local FULL=$1; shift
-  local ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --host-data"
+  local ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --host-data --input-cache /tmp/divans_cache --check-streams 64 --table-candidates 1"
   local OUT=$REPO/gpurun_out/prof_$TAG/$CFG
   mkdir -p $OUT
   echo "python bench.py $ARGS" > $OUT/cmd.txt

@@ -251,7 +251,7 @@ static int fuzz_plan(const char* path, long iterations) {
         // and the whole-container parser takes it apart again
         divans_host::ParsedStream ps; size_t used = 0;
         if (divans_host::parse_container_host(mine.data(), mine.size(), false, n + 16, ps, &used) != divans_host::PARSE_OK || ps.total != n || used != mine.size()
-            || std::memcmp(&ps.cfg, &plan.cfg, sizeof(plan.cfg)) != 0) { std::fprintf(stderr, "iteration %ld: the parser disagrees with the plan\n", it); return 8; }
+            || !ps.cfg || std::memcmp(ps.cfg.get(), &plan.cfg, sizeof(plan.cfg)) != 0) { std::fprintf(stderr, "iteration %ld: the parser disagrees with the plan\n", it); return 8; }
         total_in += n; total_out += mine.size();
     }
     std::printf("%ld planned containers: %zu bytes in, %zu out, all equal to the oracle's\n", iterations, total_in, total_out);
@@ -306,7 +306,7 @@ int main(int argc, char** argv) {
         {   // and with the memo of CMD streams seen before (divans_batch_decompress uses one per call): the same answer
             divans_host::ParsedStream pm; size_t used_m = 0;
             const divans_host::ParseStatus sm = divans_host::parse_container_host(c.data(), c.size(), skip_crc, data.size() + (1u << 20), pm, &used_m, &memo);
-            if (sm != st || (st == divans_host::PARSE_OK && (used_m != used || pm.total != ps.total || pm.lit != ps.lit || std::memcmp(&pm.cfg, &ps.cfg, sizeof(ps.cfg)) != 0))) {
+            if (sm != st || (st == divans_host::PARSE_OK && (used_m != used || pm.total != ps.total || pm.lit != ps.lit || !pm.cfg || !ps.cfg || std::memcmp(pm.cfg.get(), ps.cfg.get(), sizeof(divans_lit_config)) != 0))) {
                 std::fprintf(stderr, "iteration %ld: the memo changes the parser's answer (%d vs %d)\n", it, (int)sm, (int)st); return 10;
             }
         }
@@ -320,7 +320,7 @@ int main(int argc, char** argv) {
                 if (same) {
                     if (!pp.lit_spans.empty()) pp.copy_lit(c.data(), gathered.data()); else if (pp.lit_size) std::memcpy(gathered.data(), pp.lit.data(), pp.lit_size);
                     gathered.resize(pp.lit_size);
-                    same = used_p == used && pp.total == ps.total && pp.lit_size == ps.lit.size() && gathered == ps.lit && std::memcmp(&pp.cfg, &ps.cfg, sizeof(ps.cfg)) == 0;
+                    same = used_p == used && pp.total == ps.total && pp.lit_size == ps.lit.size() && gathered == ps.lit && pp.cfg && ps.cfg && std::memcmp(pp.cfg.get(), ps.cfg.get(), sizeof(divans_lit_config)) == 0;
                 }
             }
             if (!same) { std::fprintf(stderr, "iteration %ld: the span parser disagrees with the copying parser (%d vs %d)\n", it, (int)sp, (int)st); return 11; }
