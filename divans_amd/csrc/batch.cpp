@@ -220,10 +220,14 @@ void make_slices(const std::vector<size_t>& order, const std::vector<uint32_t>& 
     }
 }
 
-size_t device_budget() {
+// Per lane, half of what is free in all -- asked ONCE per device, when its lanes are built (LanePool::acquire): the lanes' own buffers and
+// codecs then eat into the free memory, and a budget re-read on every call shrank with them, cut the same batch into different slices
+// from one call to the next and sent the odd last slice to a lane whose page-locked and device buffers had to be re-allocated -- 100 ms of
+// hipHostMalloc / hipMalloc per compress call of 16 384 containers in "steady state" (round 6, profiles/r06_batch_container_rate_*).
+size_t device_budget_now() {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)8 << 30;
-    return std::max<size_t>((size_t)1 << 30, free_b / (2 * kLanes));    // per lane, half of what is free in all
+    return std::max<size_t>((size_t)1 << 30, free_b / (2 * kLanes));
 }
 
 struct CodecKey {
@@ -292,10 +296,12 @@ struct LanePool {
     std::mutex mu;                       // held for the whole of a call on this device
     int device = -1;
     std::unique_ptr<Lane[]> lanes;
+    size_t budget = 0;                   // device bytes a slice may take on one lane: fixed while the lanes live (device_budget_now)
     int acquire(Lane** out) {
         if (!lanes) {
             std::unique_ptr<Lane[]> fresh(new Lane[kLanes]);
             for (int i = 0; i < kLanes; ++i) { const int rc = fresh[i].init(); if (rc) return rc; }
+            budget = device_budget_now();
             lanes = std::move(fresh);
         }
         *out = lanes.get();
@@ -382,12 +388,12 @@ int compress_on_device(const divans_batch_options* opt, const uint8_t* const* in
     std::vector<size_t> order(n_streams);
     for (size_t i = 0; i < n_streams; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bound_of[a] < bound_of[b]; });
-    std::vector<Slice> slices;
-    make_slices(order, bound_of, sizes, device_budget(), slices);
     LanePool& lane_pool = registry().of(opt->device);
     std::lock_guard<std::mutex> pool_lock(lane_pool.mu);
     Lane* lanes = nullptr;
     rc = lane_pool.acquire(&lanes); if (rc) return rc;
+    std::vector<Slice> slices;
+    make_slices(order, bound_of, sizes, lane_pool.budget, slices);
     struct Drain { Lane* l; ~Drain() { for (int i = 0; i < kLanes; ++i) if (l[i].stream) (void)hipStreamSynchronize(l[i].stream); } } drain{lanes};   // no early return with copies in flight
     Overlap ov;
 
@@ -670,7 +676,7 @@ int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* 
     Overlap ov;
     for (double& v : g_phases) v = 0;
     const double t_setup0 = now_ms();
-    const size_t budget = device_budget();
+    const size_t budget = lane_pool.budget;
     // Slices in stream order (the output offsets are the running sum of the decoded sizes): one per lane, 128 .. 8192
     // containers.  While the GPU decodes the slices in flight (concurrently: a stream is a serial chain of tens of
     // milliseconds), host threads parse the next one (framing, CRC, CMD coder -> decoded sizes and LIT configuration, which

@@ -373,8 +373,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const uint32_t lane = threadIdx.x;
     const uint32_t s0 = blockIdx.x * 32u;
     // consumer role: stream s0 + lane / 2, nibble half lane & 1
-    const uint32_t cs = s0 + (lane >> 1), half = lane & 1u;
-    const uint32_t len = cs < b.n_streams ? (b.in_sizes ? b.in_sizes[cs] : b.stream_len) : 0u;
+    const uint32_t half = lane & 1u;
     // mover role, xs: stream s0 + 8 g + lane / 8 of load g, records 2 (lane & 7), + 1 of the chunk; maxes: stream s0 + 16 g + lane / 4,
     // totals 4 (lane & 3) .. + 3; pairs out: as xs
     const uint32_t xq = lane % MW_XP, xj = lane / MW_XP, tq = lane % MW_TP, tj = lane / MW_TP;
@@ -418,9 +417,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         for (uint32_t k = 0; k < MW_CHUNK / 2u; ++k) {
             const u32x4 st = *(const u32x4*)(mine + k * 16u), cm = *(const u32x4*)(mine + MW_MODEL_BYTES + k * 16u);
             const u32x2 stt = *(const u32x2*)(mine + MW_CHUNK * 8u + k * 8u), cmt = *(const u32x2*)(mine + MW_MODEL_BYTES + MW_CHUNK * 8u + k * 8u);
-            const uint32_t p = p0 + 2u * k;
-            if (p < len) outp[4u * k] = mix_nibble(w, half ? st.y : st.x, (stt.x >> hs) & 0xffffu, half ? cm.y : cm.x, (cmt.x >> hs) & 0xffffu);
-            if (p + 1u < len) outp[4u * k + 2u] = mix_nibble(w, half ? st.w : st.z, (stt.y >> hs) & 0xffffu, half ? cm.w : cm.z, (cmt.y >> hs) & 0xffffu);
+            // No test against the stream's length: past its end the walk chews on whatever the staging buffers hold (loads are clamped to
+            // mapped memory, integer arithmetic does not trap), its Weights are never used again and the pairs are not stored (the
+            // store-out below tests the length) -- and without 32 branches per chunk the compiler schedules across positions.
+            outp[4u * k] = mix_nibble(w, half ? st.y : st.x, (stt.x >> hs) & 0xffffu, half ? cm.y : cm.x, (cmt.x >> hs) & 0xffffu);
+            outp[4u * k + 2u] = mix_nibble(w, half ? st.w : st.z, (stt.y >> hs) & 0xffffu, half ? cm.w : cm.z, (cmt.y >> hs) & 0xffffu);
         }
         __syncthreads();
         // pairs out: load-shaped again, 16 bytes = both nibbles of two positions per lane

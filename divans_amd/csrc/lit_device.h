@@ -92,7 +92,7 @@ struct Weights { int w0, w1; int norm; };  // weights.rs:4-8 (norm = normalized_
 // i64 product error * efficacy is (error * (prob_i - pmix)) << 15 with a factor that fits an int; its arithmetic shift by
 // lg = bit length of pmix * (2^15 - pmix) (< 2^28) and the wrapping i32 add are then one left or right shift of that int.
 __device__ __forceinline__ int new_weight(int prob_i, int pmix, int error, int lg, int wi) {
-    const int prod = error * (prob_i - pmix);
+    const int prod = __mul24(error, prob_i - pmix);      // |error| <= 2^15, |prob_i - pmix| < 2^16: the full-rate 24-bit multiply is exact
     const int l = 15 - lg;
     const int adj = l >= 0 ? (int)((uint32_t)prod << (l & 31)) : (prod >> ((-l) & 31));
     const int nw = (int)((uint32_t)wi + (uint32_t)adj);
@@ -107,7 +107,7 @@ __device__ __forceinline__ void weights_update(Weights& w, int p_cm, int p_strid
         if (ilog >= 24) { w.w0 >>= (ilog - 24); w.w1 >>= (ilog - 24); }
     }
     const int error = (1 << 15) - pmix;
-    const uint32_t geo = (uint32_t)(pmix * error);                 // full_model_sum_p1 * full_model_sum_p0, below 2^28
+    const uint32_t geo = (uint32_t)__mul24(pmix, error);           // full_model_sum_p1 * full_model_sum_p0, below 2^28 (both factors below 2^16)
     const int lg = geo ? 32 - __clz((int)geo) : 0;
     const int n0 = new_weight(p_cm, pmix, error, lg, w.w0);
     const int n1 = new_weight(p_stride, pmix, error, lg, w.w1);
@@ -118,7 +118,13 @@ __device__ __forceinline__ void weights_update(Weights& w, int p_cm, int p_strid
     const uint32_t t8 = (total >> shift) & 0xffu;
     const uint32_t num = ((uint32_t)(n0 >> shift) << 8) & 0xffffu;
     // fast_divide_16bit_by_8bit == exact '/' (make_div_lut.rs:11-23); RECIPROCAL8[0] == 0
-    const uint32_t q = t8 ? exact_div(num, t8, __builtin_amdgcn_rcpf((float)t8)) : 0u;
+    uint32_t q = 0u;
+    if (t8) {       // exact_div with the 24-bit multiply: num < 2^16, t8 < 2^8
+        q = (uint32_t)((float)num * __builtin_amdgcn_rcpf((float)t8));
+        const int32_t r = (int32_t)(num - __umul24(q, t8));
+        q = r < 0 ? q - 1u : q;
+        q = r >= (int32_t)t8 ? q + 1u : q;
+    }
     w.norm = (int)((q << 7) & 0xffffu);
 }
 
