@@ -758,7 +758,11 @@ int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* 
         HIP_OR_FAIL(L.d_in.reserve(in_total + 128)); HIP_OR_FAIL(L.d_off.reserve(8 * m_total)); HIP_OR_FAIL(L.d_sz.reserve(4 * m_total));
         HIP_OR_FAIL(L.d_ooff.reserve(8 * m_total)); HIP_OR_FAIL(L.d_osz.reserve(4 * m_total)); HIP_OR_FAIL(L.d_out.reserve(out_total + 64));
         HIP_OR_FAIL(L.d_flags.reserve(m_total + 64));
-        std::memset(L.h_in.p, 0, in_total + 128);     // the kernels read whole words past a stream's last byte
+        // the streams of a group lie back to back (whole 32-bit words each); only the padding behind a group and behind the slice is not
+        // overwritten below and is zeroed -- clearing the whole buffer (half a gigabyte per 16 384 containers, on the calling thread, in
+        // front of every slice's launch) was a third of the time the slices took to get under way
+        for (const auto& g : groups) std::memset(L.h_in.as<uint8_t>() + g.in_base + g.in_bytes, 0, ((g.in_bytes + 127) & ~(size_t)63) - g.in_bytes);
+        std::memset(L.h_in.as<uint8_t>() + in_total, 0, 128);
         for (auto& g : groups) {
             uint64_t ip = 0;
             std::vector<uint64_t> ioff(g.members.size());

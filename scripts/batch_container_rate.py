@@ -24,7 +24,8 @@ if mixed:
 else:
     inputs = [blocks[i] for i in range(n)]
 raw = int(sum(x.size for x in inputs))
-for mixing in (0, 2):
+order = tuple(int(x) for x in sys.argv[5].split(",")) if len(sys.argv) > 5 else (0, 2)   # e.g. "2,0,0": which configurations, in which order
+for mixing in order:
     opts = da.batch_options(dynamic_context_mixing=mixing, use_context_map=0 if mixing == 0 else 1, force_stride=1 if mixing == 0 else 0, host_threads=threads, device=device)
     da.batch_compress(inputs[:64], opts)          # module load
     # first call of this size: the lanes' codecs, device scratch and page-locked staging buffers are created inside it;
