@@ -554,7 +554,7 @@ struct Calls {
 // stream's buffer, pop; with coder bytes left and the caller's buffer full it reports NeedsMoreOutput -- which every caller hands
 // to the application (`retry`: the re-entered call repeats the drain) except code_nibble_array after the last byte of a Literal
 // (literal.rs:376-390: the command completes and the LIT coder keeps its bytes until the next LIT drain).
-static void drain(Mux& mux, Calls& calls, int id, const std::vector<uint8_t>& coder_out, size_t avail_end, size_t& drained, bool retry = true) {
+static void drain(Mux& mux, Calls& calls, int id, const uint8_t* coder_out, size_t avail_end, size_t& drained, bool retry = true) {
     CallSink& sink = calls.sink;
     while (drained < avail_end) {
         const size_t room = sink.room();
@@ -564,7 +564,7 @@ static void drain(Mux& mux, Calls& calls, int id, const std::vector<uint8_t>& co
         mux.prep(0, 16); mux.prep(1, 16);                                 // write_buffer :184-204
         Mux::Stream& b = mux.s[id];
         const size_t take = std::min(avail_end - drained, b.buf.size() - b.end);
-        std::memcpy(b.buf.data() + b.end, coder_out.data() + drained, take);
+        if (take) std::memcpy(b.buf.data() + b.end, coder_out + drained, take);
         b.end += take; drained += take;
         if (drained < avail_end && sink.room() == 0) {
             if (!retry) return;
@@ -780,16 +780,15 @@ int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_si
             const size_t room = sink.room(), k = std::min<size_t>(16 - done, room); std::memcpy(sink.reserve(k), hdr + done, k); sink.commit(k, k); done += k;
         }
     }
-    std::vector<uint8_t> lit_copy(lit, lit + lit_size);
-    size_t cmd_drained = 0, lit_drained = 0, lit_avail = 0;
+    size_t cmd_drained = 0, lit_drained = 0, lit_avail = 0;      // (the coders' bytes are read where they lie: no per-container copy of the LIT stream)
     for (const StreamPlan::Step& st : plan.steps) {
         if (st.kind == StreamPlan::NewCall) calls.next_call();
         else if (st.kind == StreamPlan::InputDone) calls.input_done = true;
-        else if (st.kind == StreamPlan::CmdAvail) drain(mux, calls, 0, plan.cmd, st.value, cmd_drained);
-        else if (st.kind == StreamPlan::LitDrain) drain(mux, calls, 1, lit_copy, lit_avail, lit_drained);
+        else if (st.kind == StreamPlan::CmdAvail) drain(mux, calls, 0, plan.cmd.data(), st.value, cmd_drained);
+        else if (st.kind == StreamPlan::LitDrain) drain(mux, calls, 1, lit, lit_avail, lit_drained);
         else {
             lit_avail += chunk_bytes[st.value]; if (lit_avail > lit_size) return DIVANS_GPU_EINVAL;
-            drain(mux, calls, 1, lit_copy, lit_avail, lit_drained, st.kind != StreamPlan::LitChunkLast);
+            drain(mux, calls, 1, lit, lit_avail, lit_drained, st.kind != StreamPlan::LitChunkLast);
         }
     }
     if (lit_avail != lit_size || cmd_drained != plan.cmd.size()) return DIVANS_GPU_EINVAL;

@@ -5,6 +5,7 @@
 set -u
 TAG=${1:-r02}
 REPO=$(pwd)
+mkdir -p /tmp/divans_cache
 cd /tmp && export TMPDIR=/tmp
 run_config () {
   local CFG=$1; shift

@@ -339,8 +339,8 @@ def test_option_stage_and_state_helpers(lib, corpus):
     assert lib.divans_decode(None, None, 0, None, None, 0, None) == 3
 
 
-@pytest.mark.parametrize("sanitizer,rounds,largest,devices", [("address,undefined", 3, 250, 1), ("thread", 3, 16, 2), ("thread", 1, 40, -4),
-                                                              ("thread", 1, 60, -8), ("address,undefined", 1, 120, -3)])
+@pytest.mark.parametrize("sanitizer,rounds,largest,devices", [("address,undefined", 3, 250, 1), ("thread", 2, 16, 2), ("thread", 1, 24, -4),
+                                                              ("thread", 1, 40, -8), ("address,undefined", 1, 120, -3)])
 def test_batch_interface_on_the_host_logic(sanitizer, rounds, largest, devices, tmp_path, corpus):
     """include/divans_batch.h without a GPU: divans_amd/csrc/batch.cpp itself (length classes, slices on lanes, persistent thread pool,
     plans and parsing under the "GPU work", container assembly, error paths), compiled by g++ against a stand-in for the 16 HIP runtime
