@@ -209,7 +209,10 @@ void make_slices(const std::vector<size_t>& order, const std::vector<uint32_t>& 
         size_t j = i;
         while (j < order.size() && bound_of[order[j]] == bound) ++j;
         const size_t n_class = j - i;
-        size_t per = std::min<size_t>(16384, std::max<size_t>(256, (n_class + 1) / 2));
+#ifndef DIVANS_BATCH_ENCODE_SLICES      // experiment knob (scripts/r06_decode_slices.sh): slices a length class is cut into by a compress call
+#define DIVANS_BATCH_ENCODE_SLICES 2
+#endif
+        size_t per = std::min<size_t>(16384, std::max<size_t>(256, (n_class + DIVANS_BATCH_ENCODE_SLICES - 1) / DIVANS_BATCH_ENCODE_SLICES));
         per = std::max<size_t>(1, std::min(per, budget_bytes / device_bytes_per_stream(bound)));
         for (size_t b = i; b < j; b += per) {
             Slice s; s.bound = bound;
@@ -699,7 +702,14 @@ int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* 
     // containers.  While the GPU decodes the slices in flight (concurrently: a stream is a serial chain of tens of
     // milliseconds), host threads parse the next one (framing, CRC, CMD coder -> decoded sizes and LIT configuration, which
     // the launch needs) and copy out the ones that have finished.
-    const size_t per = std::min<size_t>(8192, std::max<size_t>(128, (n_streams + kLanes - 1) / kLanes));
+    // FOUR slices in flight, not one per lane: the decode kernels of more than four HIP streams do not run at the same time (the runtime gives a
+    // process four hardware queues by default, GPU_MAX_HW_QUEUES), and a slice whose kernel waits behind another's costs a whole decode chain --
+    // 16 384 x 64 KiB: 2 slices 11.4 GB/s, 3: 10.5, 4: 13.1, 5 / 6 / 8: 8.7-8.9, 16: 6.0 (profiles/r06_decode_slices.txt; rounds 3-5 ran eight)
+#ifndef DIVANS_BATCH_DECODE_SLICES      // (experiment knob, scripts/r06_decode_slices.sh)
+#define DIVANS_BATCH_DECODE_SLICES 4
+#endif
+    constexpr size_t kDecodeInFlight = DIVANS_BATCH_DECODE_SLICES;
+    const size_t per = std::min<size_t>(8192, std::max<size_t>(128, (n_streams + kDecodeInFlight - 1) / kDecodeInFlight));
     const size_t n_blocks = (n_streams + per - 1) / per;      // parse blocks; a block is then cut into the slices that are issued
     struct Range { size_t b, e; };
     std::vector<Range> slices;                                // in issue order; slice k runs on lane k % kLanes
@@ -865,7 +875,7 @@ int decompress_on_device(const divans_batch_options* opt, const uint8_t* const* 
     for (size_t kb = 0; kb < n_blocks; ++kb) {
         rc = parse(kb); if (rc) return rc;
         while (issued < slices.size()) {
-            if (issued - completed >= (size_t)kLanes) { rc = complete(completed++); if (rc) return rc; }
+            if (issued - completed >= std::min<size_t>(kLanes, kDecodeInFlight)) { rc = complete(completed++); if (rc) return rc; }
             rc = issue(issued++); if (rc) return rc;
         }
     }

@@ -10,10 +10,11 @@
  *
  * How a call runs: the streams are binned into length classes (<= 64 KiB, then powers of two).  Compression cuts every class
  * into two slices (the encoder passes fill the GPU whatever the slice size): the host assembles the first while the GPU codes
- * the second.  Decompression cuts the batch into eight slices in stream order, all in flight at once, each on its own HIP stream
+ * the second.  Decompression cuts the batch into slices in stream order, FOUR in flight at once, each on its own HIP stream
  * with its own codec and page-locked staging buffers -- a decoded stream is a serial chain of tens of milliseconds however few
- * of them run, so the slices' kernels run side by side -- while the host threads parse the next slice and copy out the finished
- * ones.  Device memory is sized per slice from
+ * of them run, so the slices' kernels run side by side (four: more HIP streams than the runtime's four hardware queues take turns,
+ * and a slice that waits behind another costs a whole chain) -- while the host threads parse the next slice and copy out the
+ * finished ones.  Device memory is sized per slice from
  * its class bound -- roughly 64 bytes per byte of the bound and stream, never more than a sixteenth of the free device memory per
  * slice -- so a long stream among many short ones only costs its own slice.  A single stream whose class does not fit that
  * budget fails with DIVANS_GPU_ENOMEM.
