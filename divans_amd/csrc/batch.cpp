@@ -627,6 +627,10 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     const double t_begin = now_ms();
     std::vector<DeviceShare> shares; divans_batch_options po;
     int rc = plan_shares(opt, n_streams, shares, po); if (rc) return rc;
+    if (shares.size() == 1) {        // one device (or one stream): the one-device call, with its pipeline intact
+        divans_batch_options o = *opt; o.device = shares[0].device;
+        return compress_on_device(&o, inputs, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
+    }
     std::vector<std::vector<std::vector<uint8_t>>> kept(shares.size());
     run_shares(shares, [&](DeviceShare& sh) {
         divans_batch_options o = po; o.device = sh.device;
@@ -654,6 +658,10 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     const double t_begin = now_ms();
     std::vector<DeviceShare> shares; divans_batch_options po;
     int rc = plan_shares(opt, n_streams, shares, po); if (rc) return rc;
+    if (shares.size() == 1) {        // one device: no range needs another's sizes, the one-device pipeline parses under its GPU work
+        divans_batch_options o = *opt; o.device = shares[0].device;
+        return decompress_on_device(&o, containers, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
+    }
     // every container's framing, CRC and CMD coder first: the decoded sizes place each device's range in the output
     std::vector<divans_host::ParsedStream> parsed(n_streams);
     std::vector<int> status(n_streams, 0);
