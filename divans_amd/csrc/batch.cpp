@@ -623,11 +623,11 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
     if (!opt || (!inputs && n_streams) || (!sizes && n_streams) || !out || !out_offsets || !out_sizes) return set_last_error(DIVANS_GPU_EINVAL, "null argument");
     if (n_streams == 0) return 0;
     if (opt->device >= 0) return compress_on_device(opt, inputs, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
-    if (opt->device != DIVANS_BATCH_ALL_DEVICES) return set_last_error(DIVANS_GPU_EINVAL, "device must be a HIP device or DIVANS_BATCH_ALL_DEVICES");
+    if (opt->device != DIVANS_BATCH_ALL_DEVICES && opt->device != DIVANS_BATCH_ALL_DEVICES_SHARDED) return set_last_error(DIVANS_GPU_EINVAL, "device must be a HIP device or DIVANS_BATCH_ALL_DEVICES");
     const double t_begin = now_ms();
     std::vector<DeviceShare> shares; divans_batch_options po;
     int rc = plan_shares(opt, n_streams, shares, po); if (rc) return rc;
-    if (shares.size() == 1) {        // one device (or one stream): the one-device call, with its pipeline intact
+    if (shares.size() == 1 && opt->device == DIVANS_BATCH_ALL_DEVICES) {        // one device (or one stream): the one-device call, with its pipeline intact
         divans_batch_options o = *opt; o.device = shares[0].device;
         return compress_on_device(&o, inputs, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
     }
@@ -654,11 +654,11 @@ int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* cons
     if (!opt || (!containers && n_streams) || (!sizes && n_streams) || !out || !out_offsets || !out_sizes) return set_last_error(DIVANS_GPU_EINVAL, "null argument");
     if (n_streams == 0) return 0;
     if (opt->device >= 0) return decompress_on_device(opt, containers, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
-    if (opt->device != DIVANS_BATCH_ALL_DEVICES) return set_last_error(DIVANS_GPU_EINVAL, "device must be a HIP device or DIVANS_BATCH_ALL_DEVICES");
+    if (opt->device != DIVANS_BATCH_ALL_DEVICES && opt->device != DIVANS_BATCH_ALL_DEVICES_SHARDED) return set_last_error(DIVANS_GPU_EINVAL, "device must be a HIP device or DIVANS_BATCH_ALL_DEVICES");
     const double t_begin = now_ms();
     std::vector<DeviceShare> shares; divans_batch_options po;
     int rc = plan_shares(opt, n_streams, shares, po); if (rc) return rc;
-    if (shares.size() == 1) {        // one device: no range needs another's sizes, the one-device pipeline parses under its GPU work
+    if (shares.size() == 1 && opt->device == DIVANS_BATCH_ALL_DEVICES) {        // one device: no range needs another's sizes, the one-device pipeline parses under its GPU work
         divans_batch_options o = *opt; o.device = shares[0].device;
         return decompress_on_device(&o, containers, sizes, n_streams, out, out_cap, out_offsets, out_sizes, timing, nullptr);
     }

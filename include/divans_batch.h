@@ -52,6 +52,9 @@ void divans_batch_options_default(divans_batch_options *o);
  * containers / payloads are bit-identical to D calls on the D ranges, and to one call on one device.  No data moves between devices.
  * divans_batch_timing then describes the slowest device's share (total_ms: the whole call).  A failure names the device and the range. */
 #define DIVANS_BATCH_ALL_DEVICES (-1)
+/* The same, but through the sharded code path even when there is one device (where DIVANS_BATCH_ALL_DEVICES simply makes the one-device
+ * call): for tests and measurements of that path on a one-GPU box. */
+#define DIVANS_BATCH_ALL_DEVICES_SHARDED (-2)
 
 typedef struct divans_batch_timing {       /* milliseconds, wall clock */
     double total_ms;

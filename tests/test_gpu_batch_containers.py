@@ -144,8 +144,8 @@ def test_one_call_over_all_devices_equals_one_call_per_device(corpus):
     lens = rng.integers(0, 20001, size=n)
     inputs = [blocks[i, :lens[i]] for i in range(n)]
     D = torch.cuda.device_count()
-    for opts in (dict(), dict(dynamic_context_mixing=2, force_stride=0, window_size=18)):
-        all_c, t_all = da.batch_compress(inputs, da.batch_options(device=-1, host_threads=6, **opts))
+    for all_devices, opts in ((-1, dict()), (-2, dict()), (-2, dict(dynamic_context_mixing=2, force_stride=0, window_size=18))):     # -2: the sharded code path even at D = 1
+        all_c, t_all = da.batch_compress(inputs, da.batch_options(device=all_devices, host_threads=6, **opts))
         assert t_all["total_ms"] > 0
         ref = []
         for r in range(D):          # one call per device on its contiguous range
@@ -155,13 +155,13 @@ def test_one_call_over_all_devices_equals_one_call_per_device(corpus):
         assert len(all_c) == len(ref) == n
         for i in range(n):
             assert all_c[i].size == ref[i].size and (all_c[i] == ref[i]).all(), i
-        back, _ = da.batch_decompress(all_c, int(lens.sum()), da.batch_options(device=-1, host_threads=6))
+        back, _ = da.batch_decompress(all_c, int(lens.sum()), da.batch_options(device=all_devices, host_threads=6))
         for i in range(n):
             assert back[i].size == inputs[i].size and (back[i] == inputs[i]).all(), i
         bad = [c.copy() for c in all_c]
         victim = n - 2
         bad[victim][bad[victim].size // 2] ^= 0x20
         with pytest.raises(da.DivansGpuError, match="container %d|device" % victim):
-            da.batch_decompress(bad, int(lens.sum()), da.batch_options(device=-1))
+            da.batch_decompress(bad, int(lens.sum()), da.batch_options(device=all_devices))
     with pytest.raises(da.DivansGpuError):
-        da.batch_compress(inputs[:4], da.batch_options(device=-2))
+        da.batch_compress(inputs[:4], da.batch_options(device=-3))
