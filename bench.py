@@ -458,8 +458,9 @@ def main():
     ap.add_argument("--total-streams", type=int, default=0, help="strong scaling (BASELINE configs[4]): this many streams in total, split over the GPUs "
                     "(131072 = 8 GiB); 0 = weak scaling with --streams per GPU")
     ap.add_argument("--block-len", type=int, default=65536)
-    ap.add_argument("--config", choices=["all", "simple", "mixing", "decode_only"], default="all",
-                    help="all = configs[1] as the headline + configs[2] and configs[3] as sub-records (N = 1); a single name runs only that one")
+    ap.add_argument("--config", choices=["all", "simple", "mixing", "decode_only", "simple_binary"], default="all",
+                    help="all = configs[1] as the headline + configs[2] and configs[3] as sub-records (N = 1); a single name runs only that one "
+                         "(simple_binary = configs[1]'s options on non-text input, a sub-record of `all`: for profiler passes)")
     ap.add_argument("--check-streams", type=int, default=4096, help="streams whose coded bytes are compared with the oracle before timing")
     ap.add_argument("--blocks-per-cu", type=float, default=0, help="persistent-grid override (tuning)")
     ap.add_argument("--cache-rows", type=int, default=-1, help="per-stream LDS row cache override of the STREAMING ENCODER pass (tuning; in the default build the decoder keeps "
@@ -671,7 +672,7 @@ def main():
                 print(json.dumps(line))
             sys.exit("bench: GPU output is NOT bit-exact / round-trip failed")
 
-    if args.config in ("all", "mixing", "decode_only"):
+    if args.config in ("all", "mixing", "decode_only", "simple_binary"):
         sub = {}
         if args.config == "all":
             # configs[2] on the same streams; at world > 1 this is configs[4]'s second option set, with its own scatter/gather record
@@ -682,14 +683,14 @@ def main():
             sub["mixing"] = r2
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 sub["mixing"]["cpu_baseline"] = cpu_baseline("mixing", workload, corpus, L)
-        if world == 1 and args.config == "all" and args.diag_data == "corpus":
+        if world == 1 and args.config in ("all", "simple_binary") and args.diag_data == "corpus":
             # configs[1]'s options on input that is not English text: the same cut (stride 4099, 1 % perturbation) out of testdata/
             # random_then_unicode (random bytes, then UTF-8 in several scripts); the decoder's table order is learned from the data here as in the headline
             import lzma
             with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
                 rtu_t = torch.from_numpy(np.frombuffer(f.read(), dtype=np.uint8).copy()).to(dev)
             d_bin = device_blocks(torch, rtu_t, first, N, L)
-            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", steps=sub_steps, warmup=sub_warm)
+            rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", steps=sub_steps if args.config == "all" else None, warmup=sub_warm if args.config == "all" else None)
             rb = dict(rb)
             rb.update({"workload": f"BASELINE configs[1] options on non-text input: {N} x {L} B streams cut from testdata/random_then_unicode (stride 4099, 1% perturbation: random bytes and multi-script "
                                    "UTF-8), TestSimple options as the headline, the decoder's table order learned from this data like the headline's (byte_order)", "unit": "MB/s encode+decode"})

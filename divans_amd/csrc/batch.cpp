@@ -645,8 +645,11 @@ int divans_batch_compress(const divans_batch_options* opt, const uint8_t* const*
         for (size_t i = shares[r].b; i < shares[r].e; ++i) { flat[i] = &kept[r][i - shares[r].b]; out_offsets[i] = pos; out_sizes[i] = flat[i]->size(); pos += flat[i]->size(); }
     if (pos > out_cap) return set_last_error(DIVANS_GPU_ECAP, "output buffer too small");
     parallel_for(n_streams, opt->host_threads, [&](size_t i) { stream_copy(out + out_offsets[i], flat[i]->data(), flat[i]->size()); });
-    g_phases[PH_GATHER] += now_ms() - tg;
-    return finish_shares(shares, t_begin, timing);
+    const double gather_ms = now_ms() - tg;
+    rc = finish_shares(shares, t_begin, timing);      // (sets the phases to the slowest share's; the gather is this thread's own)
+    g_phases[PH_GATHER] += gather_ms;
+    if (timing) timing->host_serial_ms += gather_ms;
+    return rc;
 }
 
 int divans_batch_decompress(const divans_batch_options* opt, const uint8_t* const* containers, const size_t* sizes, size_t n_streams,

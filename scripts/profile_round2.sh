@@ -60,7 +60,8 @@ PY
 }
 run_config simple 1
 run_config mixing 1
-run_config decode_only 0
+run_config decode_only ${PROFILE_FULL_ALL:-0}
+if [ "${PROFILE_BINARY:-0}" = "1" ]; then run_config simple_binary ${PROFILE_FULL_ALL:-0}; fi
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
 cd $REPO && python bench.py > gpurun_out/prof_$TAG/bench_line.json 2> gpurun_out/prof_$TAG/bench_line.err
 tail -c 600 gpurun_out/prof_$TAG/bench_line.json
