@@ -689,7 +689,14 @@ def main():
             import lzma
             with lzma.open(os.path.join(ROOT, "tests", "golden", "random_then_unicode.xz")) as f:
                 rtu_t = torch.from_numpy(np.frombuffer(f.read(), dtype=np.uint8).copy()).to(dev)
-            d_bin = device_blocks(torch, rtu_t, first, N, L)
+            if args.host_data:      # profiler passes: no generator kernels on the GPU (tests/workload.py builds the same bytes on the host)
+                rtu_h = rtu_t.cpu().numpy()
+                d_bin = torch.empty((N, L), dtype=torch.uint8, device=dev)
+                for c0 in range(0, N, 2048):
+                    c1 = min(N, c0 + 2048)
+                    d_bin[c0:c1].copy_(torch.from_numpy(workload.make_blocks(rtu_h, first + c0, c1 - c0, block_len=L)))
+            else:
+                d_bin = device_blocks(torch, rtu_t, first, N, L)
             rb, okb = pair_record("simple", d_in=d_bin, traffic_name="simple_binary", steps=sub_steps if args.config == "all" else None, warmup=sub_warm if args.config == "all" else None)
             rb = dict(rb)
             rb.update({"workload": f"BASELINE configs[1] options on non-text input: {N} x {L} B streams cut from testdata/random_then_unicode (stride 4099, 1% perturbation: random bytes and multi-script "

@@ -902,9 +902,25 @@ static int maybe_learn_rank(divans_gpu_codec* c, const uint8_t* d_data, const ui
     return 0;
 }
 
+// A new policy while a call-by-call search is running: the search ends on the best placement it has seen (the candidate under test, whose
+// time is not known yet, is given back) and the next qualifying call starts over under the new policy.
+static int abort_search(divans_gpu_codec* c) {
+    if (!c->ps.active) return 0;
+    if (c->ps.best_tm.p) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        table_free(c->tm, false);
+        c->tm = std::move(c->ps.best_tm); c->ps.best_tm = TableMem();
+        c->d_tables = c->tm.p;
+    }
+    c->ps.active = c->ps.pending = false;
+    return 0;
+}
+
 extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t candidates) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (candidates > 16u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [0, 16] (0 = the library's policy, 1 = off)");
+    { const int rc = abort_search(c); if (rc) return rc; }
     c->table_candidates = candidates;
     c->eager_tune = candidates >= 2u;
     c->tables_tuned = false;
@@ -914,6 +930,7 @@ extern "C" int divans_gpu_codec_tune_tables(divans_gpu_codec* c, uint32_t candid
 extern "C" int divans_gpu_codec_search_tables(divans_gpu_codec* c, uint32_t candidates) {
     if (!c) return fail(DIVANS_GPU_EINVAL, "null codec");
     if (candidates > 16u) return fail(DIVANS_GPU_EINVAL, "candidates must be in [0, 16] (0 = the library's policy, 1 = off)");
+    { const int rc = abort_search(c); if (rc) return rc; }
     c->table_candidates = candidates;
     c->eager_tune = false;
     c->tables_tuned = false;

@@ -975,6 +975,17 @@ def test_placement_search_one_candidate_per_call_changes_no_byte(cfg_name, corpu
     for _ in range(3):
         codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
     assert torch.equal(back, d_in) and codec.status() == 0 and not codec.table_placement()["searching"]
+    # a new policy in the middle of a search ends it on the best placement seen so far (the candidate under test goes back); the eager form
+    # then runs from there, and nothing decodes wrongly on the way
+    codec.search_tables(6)
+    for _ in range(3):
+        codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
+    assert codec.table_placement()["searching"] and torch.equal(back, d_in)
+    codec.tune_tables(3)
+    assert not codec.table_placement()["searching"]
+    codec.decode_batch(outs["out"], outs["offsets"], outs["sizes"], n, 2048, back)
+    pl = codec.table_placement()
+    assert pl["tried"] == 3 and not pl["searching"] and torch.equal(back, d_in) and codec.status() == 0
     codec.close()
 
 
