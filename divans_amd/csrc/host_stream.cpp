@@ -528,15 +528,19 @@ class Mux {
 // ---------------------------------------------------------------- output as the caller sees it: one buffer per call
 class CallSink {
   public:
-    CallSink(std::vector<uint8_t>& out, size_t call_buffer) : out_(out), buf_(call_buffer ? call_buffer : 65536) {}
+    CallSink(std::vector<uint8_t>& out, size_t call_buffer) : out_(out), buf_(call_buffer ? call_buffer : 65536), len_(out.size()) {}
     // A full buffer does not by itself end the call: the codec goes back to its caller only where a drain cannot finish or the
     // Mux / header need room (new_call() at exactly those points); until then it keeps coding and the Mux keeps the bytes.
     size_t room() const { return buf_ - used_; }
-    uint8_t* reserve(size_t n) { out_.resize(out_.size() + n); return out_.data() + out_.size() - n; }
-    void commit(size_t reserved, size_t used) { out_.resize(out_.size() - (reserved - used)); used_ += used; }
+    // n writable bytes behind what has been committed.  The vector only grows here and finish() cuts it to the committed length: growing and
+    // shrinking it per reservation zero-filled up to a whole call buffer about ten times per container -- two thirds of the time a container's
+    // assembly took (17 -> 6 us per 64 KiB stream, round 6).
+    uint8_t* reserve(size_t n) { if (out_.size() < len_ + n) out_.resize(std::max(len_ + n, 2 * out_.size())); return out_.data() + len_; }
+    void commit(size_t /*reserved*/, size_t used) { len_ += used; used_ += used; }
+    void finish() { out_.resize(len_); }
     void new_call() { used_ = 0; }
   private:
-    std::vector<uint8_t>& out_; size_t buf_, used_ = 0;
+    std::vector<uint8_t>& out_; size_t buf_, used_ = 0, len_;
 };
 
 // The application around the compressor (c/example.c:26-60): a call that returns NEEDS_MORE_OUTPUT is followed by another call with
@@ -799,6 +803,7 @@ int assemble_container(const StreamPlan& plan, const uint8_t* lit, size_t lit_si
         const size_t k = mux.close(p, room);
         sink.commit(room, k);
     }
+    sink.finish();
     const uint32_t crc = crc32c(0, out.data(), out.size());
     const uint8_t tr[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
     out.insert(out.end(), tr, tr + 8);
