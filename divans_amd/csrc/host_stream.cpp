@@ -41,9 +41,50 @@ static uint32_t crc32c_table(uint32_t crc, const uint8_t* p, size_t n) {
     return ~crc;
 }
 #if defined(__x86_64__)
+// The crc32 instruction has a latency of three cycles and a throughput of one per cycle: one dependent chain runs at a third of what the core
+// can do.  Three chains over three adjacent blocks, each then advanced over the blocks behind it (CRC(A || B) = shift(CRC(A), |B|) ^ CRC(B);
+// shifting over a FIXED number of zero bytes is a linear map of the 32 register bits, tabulated byte by byte).  A 30 KB container: 3.8 -> 1.4 us
+// -- it was two thirds of parse_container_host and half of assemble_container (round 6).
+struct CrcShift {
+    uint32_t t[4][256];
+    static uint32_t times(const uint32_t* mat, uint32_t vec) { uint32_t sum = 0; for (; vec; vec >>= 1, ++mat) if (vec & 1u) sum ^= *mat; return sum; }
+    static void square(uint32_t* sq, const uint32_t* mat) { for (int n = 0; n < 32; ++n) sq[n] = times(mat, mat[n]); }
+    explicit CrcShift(size_t len) {      // the operator that advances a (raw, un-inverted) register over `len` zero bytes; len a power of two >= 4
+        uint32_t even[32], odd[32];
+        odd[0] = 0x82F63B78u;            // one zero BIT: reflected polynomial in row 0, then the shift
+        uint32_t row = 1;
+        for (int n = 1; n < 32; ++n) { odd[n] = row; row <<= 1; }
+        square(even, odd);               // two bits
+        square(odd, even);               // four bits
+        // from four bits: every squaring doubles; len bytes = 8 len bits
+        uint32_t* cur = odd; uint32_t* nxt = even;
+        for (size_t bits = 4; bits < 8 * len; bits <<= 1) { square(nxt, cur); std::swap(cur, nxt); }
+        for (uint32_t n = 0; n < 256; ++n) { t[0][n] = times(cur, n); t[1][n] = times(cur, n << 8); t[2][n] = times(cur, n << 16); t[3][n] = times(cur, n << 24); }
+    }
+    uint32_t operator()(uint32_t c) const { return t[0][c & 0xffu] ^ t[1][(c >> 8) & 0xffu] ^ t[2][(c >> 16) & 0xffu] ^ t[3][c >> 24]; }
+};
+// three blocks of `block` bytes at a time while they last; returns the register, advances p / n
+__attribute__((target("sse4.2"))) static uint64_t crc32c_hw_three(uint64_t c, const uint8_t*& p, size_t& n, size_t block, const CrcShift& shift) {
+    while (n >= 3 * block) {
+        uint64_t c1 = 0, c2 = 0;
+        for (size_t i = 0; i < block; i += 8) {
+            uint64_t v0, v1, v2;
+            std::memcpy(&v0, p + i, 8); std::memcpy(&v1, p + block + i, 8); std::memcpy(&v2, p + 2 * block + i, 8);
+            c = __builtin_ia32_crc32di(c, v0); c1 = __builtin_ia32_crc32di(c1, v1); c2 = __builtin_ia32_crc32di(c2, v2);
+        }
+        c = shift((uint32_t)c) ^ (uint32_t)c1;
+        c = shift((uint32_t)c) ^ (uint32_t)c2;
+        p += 3 * block; n -= 3 * block;
+    }
+    return c;
+}
 __attribute__((target("sse4.2"))) static uint32_t crc32c_hw(uint32_t crc, const uint8_t* p, size_t n) {
+    constexpr size_t kLong = 4096, kShort = 256;
+    static const CrcShift shift_long(kLong), shift_short(kShort);
     uint64_t c = (uint32_t)~crc;
     while (n && ((uintptr_t)p & 7u)) { c = __builtin_ia32_crc32qi((uint32_t)c, *p++); --n; }
+    c = crc32c_hw_three(c, p, n, kLong, shift_long);
+    c = crc32c_hw_three(c, p, n, kShort, shift_short);
     for (; n >= 8; n -= 8, p += 8) { uint64_t v; std::memcpy(&v, p, 8); c = __builtin_ia32_crc32di(c, v); }
     while (n) { c = __builtin_ia32_crc32qi((uint32_t)c, *p++); --n; }
     return ~(uint32_t)c;
