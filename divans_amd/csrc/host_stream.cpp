@@ -1113,7 +1113,7 @@ ParseStatus parse_container_host(const uint8_t* in, size_t n, bool skip_crc, siz
     }
     if (n - 16 - used < 8) return PARSE_NEED_MORE;
     const uint8_t* tr = in + 16 + used;
-    const uint32_t crc = crc32c(0, in, 16 + used);
+    const uint32_t crc = skip_crc ? 0u : crc32c(0, in, 16 + used);      // (not even computed when the caller does not want it checked)
     const uint8_t want[8] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24), 'a', 'n', 's', '~'};
     if (std::memcmp(tr + 4, want + 4, 4) != 0) return PARSE_CORRUPT;               // codec/mod.rs:949-1017
     if (!skip_crc && std::memcmp(tr, want, 4) != 0) return PARSE_CORRUPT;
