@@ -81,7 +81,8 @@ int divans_batch_decompress(const divans_batch_options *opt, const uint8_t *cons
                             uint8_t *out, size_t out_cap, size_t *out_offsets, size_t *out_sizes, divans_batch_timing *timing);
 
 /* The batch calls keep their eight lanes (HIP streams, codecs with their tables and scratch, page-locked staging buffers) alive
- * between calls -- creating them costs more than coding a few thousand streams.  There is one set of lanes PER DEVICE: calls that
+ * between calls -- creating them costs more than coding a few thousand streams -- and, per device, the host vectors the containers of a
+ * compress call are assembled in (about the size of the largest batch's containers).  There is one set of lanes PER DEVICE: calls that
  * name different devices (divans_batch_options::device) run concurrently from different host threads -- one process drives all of a
  * node's GPUs this way, like independent states of the reference (src/ffi/interface.rs:49-50) -- and calls on one device take turns.
  * Naming another device tears nothing down.  divans_batch_release returns every device's lanes, divans_batch_release_device one
